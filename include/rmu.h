@@ -1,0 +1,126 @@
+/* rmu.h -- C-ABI of librmu.so: the MI355X-native retrieval hot path of RAGMeUp.
+ *
+ * The reference (AI-Commandos/RAGMeUp @ 2025-01-03) has no FFI for this path: its boundary is the
+ * LangChain plug-in surface that server/RAGHelper.py touches.  librmu.so is what
+ * OUR implementations of those plug-ins bind through ctypes; every entry point below names the
+ * reference call it serves.  Plain pointers and sizes only -- no torch / C++ types cross this line.
+ *
+ * Conventions
+ *   - return 0 = OK, <0 = error class (RMU_E_*); rmu_last_error() gives the thread-local message.
+ *   - never throws; the caller owns every in/out buffer; the library owns what *_create made.
+ *   - device pointers are plain HIP device addresses (e.g. torch.Tensor.data_ptr()).
+ *   - hip_stream: 0 = an internal per-thread stream, results complete on return;
+ *                 non-zero = a hipStream_t the work is ordered on (caller synchronises).
+ *   - thread-safe: searches on one index run concurrently (shared lock); add/remove are exclusive.
+ *   - row ids are int64 row numbers in insertion order; pk/metadata mapping stays in the host language.
+ */
+#ifndef RMU_H_
+#define RMU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMU_OK 0
+#define RMU_E_INVALID (-1) /* bad argument / unsupported shape */
+#define RMU_E_HIP (-2)     /* HIP runtime error */
+#define RMU_E_OOM (-3)     /* device or host allocation failed */
+#define RMU_E_RCCL (-4)    /* reserved: collective error */
+
+#define RMU_METRIC_IP 0     /* larger = better */
+#define RMU_METRIC_COSINE 1 /* rows are stored L2-normalised, queries normalised per call */
+#define RMU_METRIC_L2SQ 2   /* reported as squared distance, smaller = better (Milvus "L2") */
+
+/* flags for rmu_index_search / rmu_topk_merge */
+#define RMU_F_Q_DEVICE 1u   /* query pointer is a device address */
+#define RMU_F_OUT_DEVICE 2u /* output pointers are device addresses */
+
+#define RMU_MAX_K 112       /* largest k the fused scan keeps in LDS */
+#define RMU_MAX_DIM 768
+
+typedef struct rmu_index rmu_index_t;
+typedef struct rmu_bert rmu_bert_t;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+/* hipSetDevice(device_ordinal); idempotent.  Serves: RAGHelper_local.py:107-117 (device choice). */
+int rmu_init(int device_ordinal);
+const char* rmu_last_error(void);
+/* "librmu <ver> gfx950" -- lets the host fail loudly on a wrong build. */
+const char* rmu_version(void);
+
+/* ---- HBM-resident flat index ------------------------------------------------------------------
+ * Serves: RAGHelper.py:385-404 (Milvus.from_documents / PGVector ctor -> an empty collection). */
+int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t capacity_hint);
+int rmu_index_free(rmu_index_t* idx);
+int rmu_index_size(rmu_index_t* idx, int64_t* n_rows);
+int rmu_index_dim(rmu_index_t* idx, int* dim);
+
+/* Append n rows ([n, dim] fp32 row-major, host or device).  *first_row = row id of vecs[0].
+ * Serves: RAGHelper.py:431, :525 (db.add_documents -> add_texts -> insert). */
+int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int is_device, int64_t* first_row);
+
+/* Tombstone rows (they stop appearing in results; storage is not compacted).  *n_removed counts rows
+ * that were live.  Serves: server.py:373-377 (collection.delete('source == ...') -> delete_count). */
+int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, int64_t* n_removed);
+
+/* Gather stored rows to the host ([n, dim] fp32).  Serves: the MMR retriever's
+ * `col.query(expr="pk in [...]", output_fields=[vector])` round trip (RAGHelper.py:497-499). */
+int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, float* out_host);
+
+/* Exact top-k of every query against all live rows.
+ *   q [nq, dim] fp32; out_scores [nq, k] fp32, out_rows [nq, k] int64, best first,
+ *   order (score, then lower row id); slots beyond the live row count hold (-inf | +inf for L2SQ, -1).
+ *   row_base is added to every returned row id (shard offset).
+ * Serves: RAGHelper.py:497-499 -> vector-store similarity search (Milvus col.search FLAT). */
+int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, int k, unsigned flags,
+                     int64_t row_base, float* out_scores, int64_t* out_rows, uint64_t hip_stream);
+
+/* Merge `parts` per-shard top-k lists ([parts, nq, k] each, best first, larger score = better)
+ * into one [nq, k].  Ties: lower part index first (give shards in ascending row order).
+ * Serves: the 8-GPU shard merge after the RCCL all-gather; no reference counterpart. */
+int rmu_topk_merge(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
+                   unsigned flags, float* out_scores, int64_t* out_rows, uint64_t hip_stream);
+
+/* Timing hook for bench.py: duration in ms of the last fused scan kernel launched by the calling
+ * thread, measured with hipEvents on the stream the kernel ran on; <0 if none. */
+float rmu_last_scan_ms(void);
+/* Same for the whole search (scan + merge), and the launch geometry of the last scan. */
+float rmu_last_search_ms(void);
+int rmu_last_scan_geometry(int* grid, int* block, int* lds_bytes, int* passes);
+/* Enable (1) / disable (0) the event timing above for the calling thread (off by default). */
+int rmu_set_timing(int on);
+
+/* ---- BERT-6x384 encoder (bi-encoder and cross-encoder forwards) -------------------------------
+ * Serves: HuggingFaceEmbeddings.embed_documents / embed_query (RAGHelper_local.py:107-117 via
+ * RAGHelper.py:423-434) and HuggingFaceCrossEncoder.score (RAGHelper.py:483-486 ->
+ * ScoredCrossEncoderReranker.py:42). */
+typedef struct rmu_bert_cfg {
+    int vocab_size;   /* 30522 */
+    int hidden;       /* 384 (must be 384 in this build) */
+    int layers;       /* 6 */
+    int heads;        /* 12 (head_dim 32) */
+    int ffn;          /* 1536 */
+    int max_pos;      /* 512 */
+    int type_vocab;   /* 2 */
+    float ln_eps;     /* 1e-12 */
+    int has_head;     /* 1: pooler.dense + classifier (cross-encoder) weights are supplied */
+} rmu_bert_cfg;
+
+/* weights: array of DEVICE pointers to fp32 tensors in HF layout, order documented in
+ * ragmeup_amd/bert.py (WEIGHT_ORDER).  The library converts them to bf16 MFMA operand layout once. */
+int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const void* const* weight_ptrs, int n_weights);
+int rmu_bert_free(rmu_bert_t* m);
+/* ids/type_ids: device int32 [batch, max_len] (row padded), lens: device int32 [batch].
+ * mode 0: masked mean-pool + L2-normalise -> out_dev fp32 [batch, out_stride] (first `hidden` cols).
+ * mode 1: pooler tanh + Linear(hidden,1) logit -> out_dev fp32 [batch]. */
+int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens,
+                    int batch, int max_len, int mode, float* out_dev, int64_t out_stride,
+                    uint64_t hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMU_H_ */

@@ -1,0 +1,420 @@
+// rmu_api.hip -- C-ABI of librmu.so (see include/rmu.h): HBM-resident flat index + search orchestration.
+//
+// Reference call sites served (server/ = /root/reference/server):
+//   rmu_index_create      RAGHelper.py:385-404   (Milvus.from_documents([],...) / PGVector(...))
+//   rmu_index_add         RAGHelper.py:431, 525  (db.add_documents(documents, ids=ids))
+//   rmu_index_search      RAGHelper.py:497-499   (dense retriever -> FLAT similarity search)
+//   rmu_index_get_rows    RAGHelper.py:497-499   (search_type="mmr": re-fetch the fetch_k vectors)
+//   rmu_index_remove_rows server.py:373-377      (collection.delete('source == ...'))
+//   rmu_topk_merge        no counterpart (8-GPU shard merge)
+//
+// Data layout in HBM: one row-major [capacity, dpad] fp32 matrix, dpad = dim rounded up to 192/384/768
+// (zero padded), base 256-B aligned so every 1536-B row of the 384-d flagship is 12 full 128-B lines.
+// Tombstoned rows are NaN-poisoned in place: every score against them is NaN and fails the scan's
+// `score > threshold` compare, so deletion costs nothing in the hot loop.
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "rmu_common.h"
+#include "../../include/rmu.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? RMU_E_OOM : RMU_E_HIP,                       \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+extern "C" const char* rmu_last_error(void) { return g_err.c_str(); }
+extern "C" const char* rmu_version(void) { return "librmu 0.1 gfx950"; }
+
+static int g_device = -1;
+extern "C" int rmu_init(int device_ordinal) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(RMU_E_INVALID, "rmu_init: no such device");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    g_device = device_ordinal;
+    return RMU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-thread context: stream, events, grow-only workspace
+// ------------------------------------------------------------------------------------------------
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return RMU_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return RMU_E_OOM; }
+        cap = want;
+        return RMU_OK;
+    }
+};
+struct Tls {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    Buf q, partial, out_s, out_r, in_s, in_r, qn;
+    bool timing = false;
+    float scan_ms = -1.f, search_ms = -1.f;
+    int grid = 0, block = 0, lds = 0, passes = 0;
+    int device = -1;
+    int ensure_stream() {
+        if (g_device >= 0 && device != g_device) { (void)hipSetDevice(g_device); device = g_device; }
+        if (!stream) {
+            if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return RMU_E_HIP;
+            for (auto& e : ev)
+                if (hipEventCreate(&e) != hipSuccess) return RMU_E_HIP;
+        }
+        return RMU_OK;
+    }
+};
+static thread_local Tls g_tls;
+
+extern "C" int rmu_set_timing(int on) { g_tls.timing = on != 0; return RMU_OK; }
+extern "C" float rmu_last_scan_ms(void) { return g_tls.scan_ms; }
+extern "C" float rmu_last_search_ms(void) { return g_tls.search_ms; }
+extern "C" int rmu_last_scan_geometry(int* grid, int* block, int* lds_bytes, int* passes) {
+    if (grid) *grid = g_tls.grid;
+    if (block) *block = g_tls.block;
+    if (lds_bytes) *lds_bytes = g_tls.lds;
+    if (passes) *passes = g_tls.passes;
+    return RMU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_poison_rows(float* x, int dpad, const int64_t* rows, int64_t n) {
+    const int64_t r = blockIdx.x;
+    if (r >= n) return;
+    float* row = x + rows[r] * (int64_t)dpad;
+    for (int c = threadIdx.x; c < dpad; c += blockDim.x) row[c] = __builtin_nanf("");
+}
+
+// one wave per row: x <- x / max(|x|, 1e-12) (rows of `dpad` floats, pad columns are zero);
+// optionally also writes |x|^2 (before normalisation) to norm2[r]
+__global__ void k_row_norm(float* x, int dpad, int64_t n, int normalise, float* norm2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float* row = x + r * (int64_t)dpad;
+    float s = 0.f;
+    for (int c = lane; c < dpad; c += 64) s = fmaf(row[c], row[c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (norm2 && lane == 0) norm2[r] = s;
+    if (normalise) {
+        const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+        for (int c = lane; c < dpad; c += 64) row[c] *= inv;
+    }
+}
+
+__global__ void k_gather_rows(const float* x, int dpad, int dim, const int64_t* rows, int64_t n, float* out) {
+    const int64_t r = blockIdx.x;
+    if (r >= n) return;
+    const float* row = x + rows[r] * (int64_t)dpad;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) out[r * dim + c] = row[c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// index
+// ------------------------------------------------------------------------------------------------
+struct rmu_index {
+    int dim = 0, dpad = 0, metric = 0;
+    int64_t n = 0, cap = 0, n_live = 0;
+    float* x = nullptr;
+    std::vector<uint8_t> alive;
+    std::shared_mutex mu;
+};
+
+static int pad_dim(int d) { return d <= 192 ? 192 : (d <= 384 ? 384 : (d <= 768 ? 768 : -1)); }
+
+extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t capacity_hint) {
+    if (!out) return fail(RMU_E_INVALID, "rmu_index_create: out is null");
+    if (dim < 1 || dim > RMU_MAX_DIM) return fail(RMU_E_INVALID, "rmu_index_create: dim must be in [1, 768]");
+    if (metric != RMU_METRIC_IP && metric != RMU_METRIC_COSINE)
+        return fail(RMU_E_INVALID, "rmu_index_create: metric must be RMU_METRIC_IP or RMU_METRIC_COSINE in this build "
+                                   "(L2SQ on unit-norm rows = 2 - 2*IP is applied by the host adapter)");
+    int rc = g_tls.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_create: stream");
+    auto* idx = new (std::nothrow) rmu_index();
+    if (!idx) return fail(RMU_E_OOM, "rmu_index_create: host alloc");
+    idx->dim = dim;
+    idx->dpad = pad_dim(dim);
+    idx->metric = metric;
+    int64_t cap = capacity_hint > 0 ? capacity_hint : 4096;
+    hipError_t e = hipMalloc((void**)&idx->x, (size_t)cap * idx->dpad * sizeof(float));
+    if (e != hipSuccess) { delete idx; return fail(RMU_E_OOM, "rmu_index_create: hipMalloc"); }
+    if (idx->dpad != dim) (void)hipMemset(idx->x, 0, (size_t)cap * idx->dpad * sizeof(float));
+    idx->cap = cap;
+    *out = idx;
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_free(rmu_index_t* idx) {
+    if (!idx) return RMU_OK;
+    {
+        std::unique_lock<std::shared_mutex> lk(idx->mu);
+        (void)hipDeviceSynchronize();
+        if (idx->x) (void)hipFree(idx->x);
+        idx->x = nullptr;
+    }
+    delete idx;
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_size(rmu_index_t* idx, int64_t* n_rows) {
+    if (!idx || !n_rows) return fail(RMU_E_INVALID, "rmu_index_size: null");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    *n_rows = idx->n;
+    return RMU_OK;
+}
+extern "C" int rmu_index_dim(rmu_index_t* idx, int* dim) {
+    if (!idx || !dim) return fail(RMU_E_INVALID, "rmu_index_dim: null");
+    *dim = idx->dim;
+    return RMU_OK;
+}
+
+static int grow(rmu_index* idx, int64_t need) {
+    if (need <= idx->cap) return RMU_OK;
+    int64_t cap = idx->cap;
+    while (cap < need) cap = cap + cap / 2 + 1024;
+    float* nx = nullptr;
+    if (hipMalloc((void**)&nx, (size_t)cap * idx->dpad * sizeof(float)) != hipSuccess) {
+        cap = need;  // retry with the exact size before giving up
+        if (hipMalloc((void**)&nx, (size_t)cap * idx->dpad * sizeof(float)) != hipSuccess)
+            return fail(RMU_E_OOM, "rmu_index_add: hipMalloc for growth");
+    }
+    HIP_TRY(hipDeviceSynchronize());  // nobody may still be scanning the old matrix
+    if (idx->dpad != idx->dim)
+        HIP_TRY(hipMemset(nx + idx->n * idx->dpad, 0, (size_t)(cap - idx->n) * idx->dpad * sizeof(float)));
+    if (idx->n) HIP_TRY(hipMemcpy(nx, idx->x, (size_t)idx->n * idx->dpad * sizeof(float), hipMemcpyDeviceToDevice));
+    (void)hipFree(idx->x);
+    idx->x = nx;
+    idx->cap = cap;
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int is_device, int64_t* first_row) {
+    if (!idx || (!vecs && n > 0) || n < 0) return fail(RMU_E_INVALID, "rmu_index_add: bad argument");
+    int rc = g_tls.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_add: stream");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    if (first_row) *first_row = idx->n;
+    if (n == 0) return RMU_OK;
+    if (idx->n + n > 0xFFFFFFF0ll) return fail(RMU_E_INVALID, "rmu_index_add: row ids are 32-bit inside the scan");
+    rc = grow(idx, idx->n + n);
+    if (rc) return rc;
+    float* dst = idx->x + idx->n * (int64_t)idx->dpad;
+    hipStream_t s = g_tls.stream;
+    const hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (idx->dpad == idx->dim)
+        HIP_TRY(hipMemcpyAsync(dst, vecs, (size_t)n * idx->dim * sizeof(float), kind, s));
+    else
+        HIP_TRY(hipMemcpy2DAsync(dst, (size_t)idx->dpad * sizeof(float), vecs, (size_t)idx->dim * sizeof(float),
+                                 (size_t)idx->dim * sizeof(float), (size_t)n, kind, s));
+    if (idx->metric == RMU_METRIC_COSINE) {
+        const int wpb = 4;
+        hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, dst, idx->dpad, n, 1,
+                           (float*)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    idx->alive.resize((size_t)(idx->n + n), 1);
+    idx->n += n;
+    idx->n_live += n;
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, int64_t* n_removed) {
+    if (!idx || (!rows && n > 0) || n < 0) return fail(RMU_E_INVALID, "rmu_index_remove_rows: bad argument");
+    int rc = g_tls.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_remove_rows: stream");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    std::vector<int64_t> todo;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = rows[i];
+        if (r < 0 || r >= idx->n) return fail(RMU_E_INVALID, "rmu_index_remove_rows: row out of range");
+        if (idx->alive[(size_t)r]) { idx->alive[(size_t)r] = 0; todo.push_back(r); }
+    }
+    if (n_removed) *n_removed = (int64_t)todo.size();
+    if (todo.empty()) return RMU_OK;
+    Buf& b = g_tls.in_r;
+    if (b.ensure(todo.size() * sizeof(int64_t))) return fail(RMU_E_OOM, "rmu_index_remove_rows: workspace");
+    hipStream_t s = g_tls.stream;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyAsync(b.p, todo.data(), todo.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, idx->x, idx->dpad,
+                       (const int64_t*)b.p, (int64_t)todo.size());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    idx->n_live -= (int64_t)todo.size();
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, float* out_host) {
+    if (!idx || (!rows && n > 0) || (!out_host && n > 0) || n < 0)
+        return fail(RMU_E_INVALID, "rmu_index_get_rows: bad argument");
+    if (n == 0) return RMU_OK;
+    int rc = g_tls.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_get_rows: stream");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    for (int64_t i = 0; i < n; ++i)
+        if (rows[i] < 0 || rows[i] >= idx->n) return fail(RMU_E_INVALID, "rmu_index_get_rows: row out of range");
+    Buf& br = g_tls.in_r;
+    Buf& bo = g_tls.out_s;
+    if (br.ensure((size_t)n * sizeof(int64_t)) || bo.ensure((size_t)n * idx->dim * sizeof(float)))
+        return fail(RMU_E_OOM, "rmu_index_get_rows: workspace");
+    hipStream_t s = g_tls.stream;
+    HIP_TRY(hipMemcpyAsync(br.p, rows, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n), dim3(128), 0, s, idx->x, idx->dpad, idx->dim,
+                       (const int64_t*)br.p, n, (float*)bo.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, bo.p, (size_t)n * idx->dim * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------
+static const int64_t kMaxQueriesPerLaunch = 8192;
+
+extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, int k, unsigned flags, int64_t row_base,
+                                float* out_scores, int64_t* out_rows, uint64_t hip_stream) {
+    if (!idx || !q || !out_scores || !out_rows) return fail(RMU_E_INVALID, "rmu_index_search: null pointer");
+    if (nq < 1) return fail(RMU_E_INVALID, "rmu_index_search: nq must be >= 1");
+    if (k < 1 || k > RMU_MAX_K) return fail(RMU_E_INVALID, "rmu_index_search: k must be in [1, 112]");
+    Tls& t = g_tls;
+    int rc = t.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_search: stream");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : t.stream;
+    const bool q_dev = flags & RMU_F_Q_DEVICE, out_dev = flags & RMU_F_OUT_DEVICE;
+    const bool timed = t.timing && !hip_stream;
+
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    const int dpad = idx->dpad, dim = idx->dim;
+    t.scan_ms = -1.f; t.search_ms = -1.f; t.passes = 0;
+    float scan_total = 0.f;
+    if (timed) HIP_TRY(hipEventRecord(t.ev[0], s));
+
+    for (int64_t q0 = 0; q0 < nq; q0 += kMaxQueriesPerLaunch) {
+        const int64_t nb = (nq - q0) < kMaxQueriesPerLaunch ? (nq - q0) : kMaxQueriesPerLaunch;
+        // ---- queries -> device, padded to dpad, normalised for COSINE -----------------------------
+        const float* qsrc = q + q0 * dim;
+        const float* qdev = qsrc;
+        const bool need_copy = !q_dev || dpad != dim || idx->metric == RMU_METRIC_COSINE;
+        if (need_copy) {
+            if (t.q.ensure((size_t)nb * dpad * sizeof(float))) return fail(RMU_E_OOM, "rmu_index_search: q workspace");
+            if (dpad != dim) HIP_TRY(hipMemsetAsync(t.q.p, 0, (size_t)nb * dpad * sizeof(float), s));
+            HIP_TRY(hipMemcpy2DAsync(t.q.p, (size_t)dpad * sizeof(float), qsrc, (size_t)dim * sizeof(float),
+                                     (size_t)dim * sizeof(float), (size_t)nb,
+                                     q_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+            if (idx->metric == RMU_METRIC_COSINE) {
+                hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, (float*)t.q.p, dpad, nb, 1,
+                                   (float*)nullptr);
+                HIP_TRY(hipGetLastError());
+            }
+            qdev = (const float*)t.q.p;
+        }
+        // ---- plan + workspace ------------------------------------------------------------------------
+        ScanLaunch L{};
+        L.x = idx->x; L.n_rows = idx->n; L.dpad = dpad; L.q = qdev; L.nq = (int)nb; L.k = k;
+        rc = rmu_scan_plan(&L);
+        if (rc) return fail(rc, "rmu_index_search: no scan geometry for this (dim, k)");
+        const size_t pbytes = (size_t)L.parts * nb * k * sizeof(u64);
+        if (t.partial.ensure(pbytes)) return fail(RMU_E_OOM, "rmu_index_search: partial workspace");
+        L.partial = (u64*)t.partial.p;
+        float* d_s = out_scores + q0 * k;
+        int64_t* d_r = out_rows + q0 * k;
+        if (!out_dev) {
+            if (t.out_s.ensure((size_t)nb * k * sizeof(float)) || t.out_r.ensure((size_t)nb * k * sizeof(int64_t)))
+                return fail(RMU_E_OOM, "rmu_index_search: output workspace");
+            d_s = (float*)t.out_s.p;
+            d_r = (int64_t*)t.out_r.p;
+        }
+        // ---- fused scan ------------------------------------------------------------------------------
+        if (idx->n > 0) {
+            if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
+            rc = rmu_scan_launch(&L, s);
+            if (rc) return fail(rc, std::string("rmu_index_search: scan launch: ") + hipGetErrorString(hipGetLastError()));
+            if (timed) HIP_TRY(hipEventRecord(t.ev[3], s));
+            t.grid = L.grid; t.block = 256; t.lds = L.lds_bytes; t.passes += 1;
+        } else {
+            HIP_TRY(hipMemsetAsync(L.partial, 0, pbytes, s));
+        }
+        rc = rmu_merge_keys_launch(L.partial, L.parts, nb, k, row_base, 0, nullptr, d_s, d_r, s);
+        if (rc) return fail(rc, "rmu_index_search: merge launch");
+        if (!out_dev) {
+            HIP_TRY(hipMemcpyAsync(out_scores + q0 * k, d_s, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(out_rows + q0 * k, d_r, (size_t)nb * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        }
+        // workspace is reused by the next query block (and host outputs must land): drain per block
+        if (!hip_stream || q0 + nb < nq || !out_dev) HIP_TRY(hipStreamSynchronize(s));
+        if (timed && idx->n > 0) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms;
+        }
+    }
+    if (timed) {
+        HIP_TRY(hipEventRecord(t.ev[1], s));
+        HIP_TRY(hipEventSynchronize(t.ev[1]));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.ev[0], t.ev[1]) == hipSuccess) t.search_ms = ms;
+        t.scan_ms = scan_total;
+    }
+    return RMU_OK;
+}
+
+extern "C" int rmu_topk_merge(const float* scores, const int64_t* rows, int parts, int64_t nq, int k, unsigned flags,
+                              float* out_scores, int64_t* out_rows, uint64_t hip_stream) {
+    if (!scores || !rows || !out_scores || !out_rows) return fail(RMU_E_INVALID, "rmu_topk_merge: null pointer");
+    if (parts < 1 || nq < 1 || k < 1 || k > 128) return fail(RMU_E_INVALID, "rmu_topk_merge: parts/nq >= 1, k in [1,128]");
+    Tls& t = g_tls;
+    int rc = t.ensure_stream();
+    if (rc) return fail(rc, "rmu_topk_merge: stream");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : t.stream;
+    const bool in_dev = flags & RMU_F_Q_DEVICE, out_dev = flags & RMU_F_OUT_DEVICE;
+    const size_t cnt = (size_t)parts * nq * k;
+    const float* ds = scores;
+    const int64_t* dr = rows;
+    if (!in_dev) {
+        if (t.in_s.ensure(cnt * sizeof(float)) || t.in_r.ensure(cnt * sizeof(int64_t)))
+            return fail(RMU_E_OOM, "rmu_topk_merge: input workspace");
+        HIP_TRY(hipMemcpyAsync(t.in_s.p, scores, cnt * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(t.in_r.p, rows, cnt * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        ds = (const float*)t.in_s.p;
+        dr = (const int64_t*)t.in_r.p;
+    }
+    float* os = out_scores;
+    int64_t* orr = out_rows;
+    if (!out_dev) {
+        if (t.out_s.ensure((size_t)nq * k * sizeof(float)) || t.out_r.ensure((size_t)nq * k * sizeof(int64_t)))
+            return fail(RMU_E_OOM, "rmu_topk_merge: output workspace");
+        os = (float*)t.out_s.p;
+        orr = (int64_t*)t.out_r.p;
+    }
+    rc = rmu_merge_lists_launch(ds, dr, parts, nq, k, os, orr, nullptr, s);
+    if (rc) return fail(rc, "rmu_topk_merge: launch");
+    if (!out_dev) {
+        HIP_TRY(hipMemcpyAsync(out_scores, os, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_rows, orr, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    }
+    if (!hip_stream || !out_dev || !in_dev) HIP_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}

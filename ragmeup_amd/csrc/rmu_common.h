@@ -1,0 +1,113 @@
+// rmu_common.h -- shared device/host helpers for librmu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ---- candidate key: one u64 compares as (score desc, row asc) ---------------------------------
+// hi 32 bits: order-preserving image of the fp32 score; lo 32 bits: ~row (smaller row = larger key).
+// key 0 is the "no candidate" sentinel (smaller than every real key).
+__host__ __device__ inline u32 rmu_f2ord(float f) {
+    union { float f; u32 u; } c; c.f = f;
+    return c.u ^ ((c.u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__host__ __device__ inline float rmu_ord2f(u32 o) {
+    union { float f; u32 u; } c;
+    c.u = o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return c.f;
+}
+__host__ __device__ inline u64 rmu_make_key(float score, u32 row) {
+    return ((u64)rmu_f2ord(score) << 32) | (u64)(u32)(~row);
+}
+__host__ __device__ inline float rmu_key_score(u64 k) { return rmu_ord2f((u32)(k >> 32)); }
+__host__ __device__ inline u32 rmu_key_row(u64 k) { return ~(u32)k; }
+
+// ---- wave-wide bitonic sort, descending, 64*NPL keys (lane holds elements lane + 64*p) ---------
+template <int NPL>
+__device__ __forceinline__ void rmu_bitonic_sort_desc(u64 (&key)[NPL], int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64 * NPL; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64) {
+                const int ps = stride >> 6;
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    if ((p & ps) == 0) {
+                        const int p2 = p | ps;
+                        const bool desc = (((lane + 64 * p) & size) == 0);
+                        const u64 a = key[p], b = key[p2];
+                        const u64 mx = a > b ? a : b, mn = a > b ? b : a;
+                        key[p] = desc ? mx : mn;
+                        key[p2] = desc ? mn : mx;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) {
+                    const u64 other = __shfl_xor(key[p], stride);
+                    const bool desc = (((lane + 64 * p) & size) == 0);
+                    const bool lower = ((lane & stride) == 0);
+                    const u64 mx = key[p] > other ? key[p] : other;
+                    const u64 mn = key[p] > other ? other : key[p];
+                    key[p] = (desc == lower) ? mx : mn;
+                }
+            }
+        }
+    }
+}
+
+// bitonic MERGE (input is a bitonic sequence of 64*NPL keys) -> sorted descending
+template <int NPL>
+__device__ __forceinline__ void rmu_bitonic_merge_desc(u64 (&key)[NPL], int lane) {
+#pragma unroll
+    for (int stride = 32 * NPL; stride > 0; stride >>= 1) {
+        if (stride >= 64) {
+            const int ps = stride >> 6;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                if ((p & ps) == 0) {
+                    const int p2 = p | ps;
+                    const u64 a = key[p], b = key[p2];
+                    key[p] = a > b ? a : b;
+                    key[p2] = a > b ? b : a;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const u64 other = __shfl_xor(key[p], stride);
+                const bool lower = ((lane & stride) == 0);
+                const u64 mx = key[p] > other ? key[p] : other;
+                const u64 mn = key[p] > other ? other : key[p];
+                key[p] = lower ? mx : mn;
+            }
+        }
+    }
+}
+
+// ---- launch descriptors shared between rmu_api.hip and the kernel translation units -------------
+struct ScanLaunch {
+    const float* x;        // [n_rows, dpad] fp32 row-major, HBM resident
+    int64_t n_rows;
+    int dpad;              // row stride in floats (multiple of 96)
+    const float* q;        // [nq, dpad] fp32 device (padded like the rows)
+    int nq;
+    int k;
+    u64* partial;          // [parts, nq, k] keys
+    int parts;             // filled by the planner
+    // filled by rmu_scan_plan
+    int wq, kv, s_chunks, nqt, tiles_per_chunk, grid, lds_bytes;
+};
+
+int rmu_scan_plan(ScanLaunch* p);                        // chooses geometry; returns 0 or RMU_E_INVALID
+int rmu_scan_launch(const ScanLaunch* p, hipStream_t s); // launches the fused scan
+int rmu_merge_keys_launch(const u64* partial, int parts, int64_t nq, int k, int64_t row_base,
+                          int l2_out, const float* qnorm2, float* out_scores, int64_t* out_rows,
+                          hipStream_t s);
+int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
+                           float* out_scores, int64_t* out_rows, u64* scratch_keys, hipStream_t s);

@@ -1,0 +1,130 @@
+// topk_merge.hip -- k-way merge of per-chunk / per-shard top-k lists (gfx950 only).
+//
+// Serves: the last step of the dense search (server/RAGHelper.py:497-499 -> top-`fetch_k` per query)
+// and the 8-GPU shard merge after the RCCL all-gather.  One wave per query streams
+// the `parts*k` candidate keys in batches of 64, sorts each batch with a shuffle bitonic network and
+// folds it into the running (sorted) top-K with one half-cleaner + bitonic merge.
+#include "rmu_common.h"
+#include "../../include/rmu.h"
+
+namespace {
+
+// NPL = 1 -> k <= 64, NPL = 2 -> k <= 128
+template <int NPL, class LoadKey>
+__device__ __forceinline__ void merge_stream(u64 (&top)[NPL], int64_t m, int lane, LoadKey load) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) top[p] = 0ull;
+    for (int64_t b0 = 0; b0 < m; b0 += 64) {
+        u64 bk[1];
+        const int64_t idx = b0 + lane;
+        bk[0] = idx < m ? load(idx) : 0ull;
+        rmu_bitonic_sort_desc<1>(bk, lane);
+        // reversed batch against the LAST 64 slots of the running list -> bitonic sequence holding the
+        // best 64*NPL of the union
+        const u64 rev = __shfl(bk[0], 63 - lane);
+        u64& tail = top[NPL - 1];
+        tail = tail > rev ? tail : rev;
+        rmu_bitonic_merge_desc<NPL>(top, lane);
+    }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ partial, int parts, int64_t nq,
+                                                         int k, int64_t row_base, int l2_out,
+                                                         const float* __restrict__ qnorm2,
+                                                         float* __restrict__ out_scores,
+                                                         int64_t* __restrict__ out_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int64_t m = (int64_t)parts * k;
+    u64 top[NPL];
+    merge_stream<NPL>(top, m, lane, [&](int64_t idx) {
+        const int64_t part = idx / k, pos = idx % k;
+        return partial[(part * nq + q) * k + pos];
+    });
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        const int e = lane + 64 * p;
+        if (e < k) {
+            const u64 key = top[p];
+            float s;
+            int64_t r;
+            if (key == 0ull) {
+                s = l2_out ? INFINITY : -INFINITY;
+                r = -1;
+            } else {
+                s = rmu_key_score(key);
+                if (l2_out) s = fmaxf(qnorm2[q] - s, 0.f);
+                r = (int64_t)rmu_key_row(key) + row_base;
+            }
+            out_scores[q * k + e] = s;
+            out_rows[q * k + e] = r;
+        }
+    }
+}
+
+// generic lists (scores fp32 + int64 rows, [parts, nq, k]); ties resolve to the lower candidate index,
+// i.e. the lower part, then the earlier position -- equal to (score, row) order when parts arrive in
+// ascending row ranges.
+template <int NPL>
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ scores,
+                                                          const int64_t* __restrict__ rows, int parts,
+                                                          int64_t nq, int k, float* __restrict__ out_scores,
+                                                          int64_t* __restrict__ out_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int64_t m = (int64_t)parts * k;
+    u64 top[NPL];
+    merge_stream<NPL>(top, m, lane, [&](int64_t idx) -> u64 {
+        const int64_t part = idx / k, pos = idx % k;
+        const int64_t src = (part * nq + q) * k + pos;
+        const float s = scores[src];
+        if (rows[src] < 0 || !(s == s)) return 0ull;
+        return rmu_make_key(s + 0.0f, (u32)idx);
+    });
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        const int e = lane + 64 * p;
+        if (e < k) {
+            const u64 key = top[p];
+            if (key == 0ull) {
+                out_scores[q * k + e] = -INFINITY;
+                out_rows[q * k + e] = -1;
+            } else {
+                const int64_t idx = rmu_key_row(key);
+                const int64_t part = idx / k, pos = idx % k;
+                out_scores[q * k + e] = rmu_key_score(key);
+                out_rows[q * k + e] = rows[(part * nq + q) * k + pos];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int rmu_merge_keys_launch(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out,
+                          const float* qnorm2, float* out_scores, int64_t* out_rows, hipStream_t s) {
+    if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
+    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (k <= 64)
+        hipLaunchKernelGGL(merge_keys_kernel<1>, grid, block, 0, s, partial, parts, nq, k, row_base, l2_out, qnorm2,
+                           out_scores, out_rows);
+    else
+        hipLaunchKernelGGL(merge_keys_kernel<2>, grid, block, 0, s, partial, parts, nq, k, row_base, l2_out, qnorm2,
+                           out_scores, out_rows);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+
+int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
+                           float* out_scores, int64_t* out_rows, u64* /*scratch_keys*/, hipStream_t s) {
+    if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
+    if ((int64_t)parts * k >= (1ll << 32)) return RMU_E_INVALID;
+    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (k <= 64)
+        hipLaunchKernelGGL(merge_lists_kernel<1>, grid, block, 0, s, scores, rows, parts, nq, k, out_scores, out_rows);
+    else
+        hipLaunchKernelGGL(merge_lists_kernel<2>, grid, block, 0, s, scores, rows, parts, nq, k, out_scores, out_rows);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}

@@ -1,0 +1,146 @@
+"""FlatIndex -- Python handle on the HBM-resident flat index behind librmu.so.
+
+Host-side mirror of what the reference reaches through langchain_milvus.Milvus /
+langchain_postgres.PGVector (server/RAGHelper.py:385-434, 497-499): insert, exact top-k,
+row fetch for MMR, delete.  Arrays are numpy on the host or torch CUDA tensors (device pointers
+cross the C-ABI as integers); nothing here computes a score on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+
+
+def _is_torch_cuda(t) -> bool:
+    return hasattr(t, "data_ptr") and hasattr(t, "is_cuda") and bool(t.is_cuda)
+
+
+class FlatIndex:
+    def __init__(self, dim: int, metric: int = N.METRIC_IP, capacity_hint: int = 0, device: int | None = None):
+        self._lib = N.lib()
+        if device is not None:
+            N.check(self._lib.rmu_init(int(device)), "rmu_init")
+        self.dim = int(dim)
+        self.metric = int(metric)
+        h = ctypes.c_void_p()
+        N.check(self._lib.rmu_index_create(ctypes.byref(h), self.dim, self.metric, int(capacity_hint)),
+                "rmu_index_create")
+        self._h = h
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rmu_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = ctypes.c_int64()
+        N.check(self._lib.rmu_index_size(self._h, ctypes.byref(n)), "rmu_index_size")
+        return int(n.value)
+
+    # -- mutation ----------------------------------------------------------------------------------
+    def add(self, vecs) -> int:
+        """Append rows; returns the row id of the first one."""
+        first = ctypes.c_int64()
+        if _is_torch_cuda(vecs):
+            import torch
+            v = vecs.detach().to(torch.float32).contiguous()
+            if v.ndim != 2 or v.shape[1] != self.dim:
+                raise ValueError(f"expected [n, {self.dim}] got {tuple(v.shape)}")
+            torch.cuda.current_stream().synchronize()
+            N.check(self._lib.rmu_index_add(self._h, v.data_ptr(), v.shape[0], 1, ctypes.byref(first)), "rmu_index_add")
+        else:
+            v = np.ascontiguousarray(vecs, dtype=np.float32)
+            if v.ndim != 2 or v.shape[1] != self.dim:
+                raise ValueError(f"expected [n, {self.dim}] got {v.shape}")
+            N.check(self._lib.rmu_index_add(self._h, v.ctypes.data, v.shape[0], 0, ctypes.byref(first)), "rmu_index_add")
+        return int(first.value)
+
+    def remove_rows(self, rows) -> int:
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        cnt = ctypes.c_int64()
+        N.check(self._lib.rmu_index_remove_rows(self._h, r.ctypes.data, r.shape[0], ctypes.byref(cnt)),
+                "rmu_index_remove_rows")
+        return int(cnt.value)
+
+    def get_rows(self, rows) -> np.ndarray:
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((r.shape[0], self.dim), dtype=np.float32)
+        N.check(self._lib.rmu_index_get_rows(self._h, r.ctypes.data, r.shape[0], out.ctypes.data), "rmu_index_get_rows")
+        return out
+
+    # -- search ------------------------------------------------------------------------------------
+    def search(self, q, k: int, row_base: int = 0):
+        """Exact top-k.  numpy in -> numpy out; torch CUDA in -> torch CUDA out (same device)."""
+        if _is_torch_cuda(q):
+            import torch
+            qq = q.detach().to(torch.float32).contiguous()
+            if qq.ndim == 1:
+                qq = qq[None]
+            nq = qq.shape[0]
+            out_s = torch.empty((nq, k), dtype=torch.float32, device=qq.device)
+            out_r = torch.empty((nq, k), dtype=torch.int64, device=qq.device)
+            torch.cuda.current_stream().synchronize()
+            N.check(self._lib.rmu_index_search(self._h, qq.data_ptr(), nq, int(k), N.F_Q_DEVICE | N.F_OUT_DEVICE,
+                                               int(row_base), out_s.data_ptr(), out_r.data_ptr(), 0),
+                    "rmu_index_search")
+            return out_s, out_r
+        qq = np.ascontiguousarray(q, dtype=np.float32)
+        if qq.ndim == 1:
+            qq = qq[None]
+        if qq.shape[1] != self.dim:
+            raise ValueError(f"expected [nq, {self.dim}] got {qq.shape}")
+        nq = qq.shape[0]
+        out_s = np.empty((nq, k), dtype=np.float32)
+        out_r = np.empty((nq, k), dtype=np.int64)
+        N.check(self._lib.rmu_index_search(self._h, qq.ctypes.data, nq, int(k), 0, int(row_base),
+                                           out_s.ctypes.data, out_r.ctypes.data, 0), "rmu_index_search")
+        return out_s, out_r
+
+    # -- measurement hooks (bench.py) ----------------------------------------------------------------
+    def set_timing(self, on: bool = True):
+        self._lib.rmu_set_timing(1 if on else 0)
+
+    def last_scan_ms(self) -> float:
+        return float(self._lib.rmu_last_scan_ms())
+
+    def last_search_ms(self) -> float:
+        return float(self._lib.rmu_last_search_ms())
+
+    def last_geometry(self) -> dict:
+        g, b, l, p = (ctypes.c_int() for _ in range(4))
+        self._lib.rmu_last_scan_geometry(ctypes.byref(g), ctypes.byref(b), ctypes.byref(l), ctypes.byref(p))
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value, "launches": p.value}
+
+
+def topk_merge(part_scores, part_rows, k: int | None = None):
+    """Merge [parts, nq, k] shard lists (numpy or torch CUDA) -> [nq, k]."""
+    lib = N.lib()
+    if _is_torch_cuda(part_scores):
+        import torch
+        s = part_scores.detach().to(torch.float32).contiguous()
+        r = part_rows.detach().to(torch.int64).contiguous()
+        parts, nq, kk = s.shape
+        out_s = torch.empty((nq, kk), dtype=torch.float32, device=s.device)
+        out_r = torch.empty((nq, kk), dtype=torch.int64, device=s.device)
+        torch.cuda.current_stream().synchronize()
+        N.check(lib.rmu_topk_merge(s.data_ptr(), r.data_ptr(), parts, nq, kk, N.F_Q_DEVICE | N.F_OUT_DEVICE,
+                                   out_s.data_ptr(), out_r.data_ptr(), 0), "rmu_topk_merge")
+        return out_s, out_r
+    s = np.ascontiguousarray(part_scores, dtype=np.float32)
+    r = np.ascontiguousarray(part_rows, dtype=np.int64)
+    parts, nq, kk = s.shape
+    out_s = np.empty((nq, kk), dtype=np.float32)
+    out_r = np.empty((nq, kk), dtype=np.int64)
+    N.check(lib.rmu_topk_merge(s.ctypes.data, r.ctypes.data, parts, nq, kk, 0, out_s.ctypes.data, out_r.ctypes.data, 0),
+            "rmu_topk_merge")
+    return out_s, out_r
