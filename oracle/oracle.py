@@ -104,6 +104,27 @@ def flat_search(q: np.ndarray, x: np.ndarray, k: int, metric: int = METRIC_IP,
     return best_s, best_r
 
 
+def flat_search_f32_blas(q: np.ndarray, x: np.ndarray, k: int, block: int = 131072):
+    """CPU *baseline* form of the same search (what a SIMD FLAT scan such as Milvus-Lite's does):
+    fp32 sgemm (OpenBLAS, all host threads) + argpartition + sort of the k survivors.
+    Inner product only.  Used by bench.py's cpu_baseline leg; ordering ties are not normalised here.
+    """
+    nq = q.shape[0]
+    best_s = np.full((nq, k), -np.inf, dtype=np.float32)
+    best_r = np.full((nq, k), -1, dtype=np.int64)
+    for b0 in range(0, x.shape[0], block):
+        b1 = min(x.shape[0], b0 + block)
+        s = q @ x[b0:b1].T
+        kk = min(k, b1 - b0)
+        part = np.argpartition(-s, kk - 1, axis=1)[:, :kk]
+        cs = np.concatenate([best_s, np.take_along_axis(s, part, axis=1)], axis=1)
+        cr = np.concatenate([best_r, part + b0], axis=1)
+        order = np.argsort(-cs, axis=1, kind="stable")[:, :k]
+        best_s = np.take_along_axis(cs, order, axis=1)
+        best_r = np.take_along_axis(cr, order, axis=1)
+    return best_s, best_r
+
+
 def merge_topk(part_scores: np.ndarray, part_rows: np.ndarray, k: int):
     """Merge per-shard top-k lists [parts, nq, k'] -> [nq, k] by (-score, row)  (SURVEY 8e)."""
     parts, nq, kk = part_scores.shape

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "rmu_common.h"
 #include "../../include/rmu.h"
@@ -68,7 +69,7 @@ struct Buf {
 struct Tls {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    Buf q, partial, out_s, out_r, in_s, in_r, qn;
+    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr;
     bool timing = false;
     float scan_ms = -1.f, search_ms = -1.f;
     int grid = 0, block = 0, lds = 0, passes = 0;
@@ -142,6 +143,8 @@ struct rmu_index {
     std::shared_mutex mu;
 };
 
+// the scan's LDS-DMA reads whole 128-row tiles: keep that many allocated rows past the last one
+static const int64_t kSlackRows = 128;
 static int pad_dim(int d) { return d <= 192 ? 192 : (d <= 384 ? 384 : (d <= 768 ? 768 : -1)); }
 
 extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t capacity_hint) {
@@ -158,9 +161,9 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
     idx->dpad = pad_dim(dim);
     idx->metric = metric;
     int64_t cap = capacity_hint > 0 ? capacity_hint : 4096;
-    hipError_t e = hipMalloc((void**)&idx->x, (size_t)cap * idx->dpad * sizeof(float));
+    hipError_t e = hipMalloc((void**)&idx->x, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float));
     if (e != hipSuccess) { delete idx; return fail(RMU_E_OOM, "rmu_index_create: hipMalloc"); }
-    if (idx->dpad != dim) (void)hipMemset(idx->x, 0, (size_t)cap * idx->dpad * sizeof(float));
+    (void)hipMemset(idx->x, 0, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float));
     idx->cap = cap;
     *out = idx;
     return RMU_OK;
@@ -195,14 +198,13 @@ static int grow(rmu_index* idx, int64_t need) {
     int64_t cap = idx->cap;
     while (cap < need) cap = cap + cap / 2 + 1024;
     float* nx = nullptr;
-    if (hipMalloc((void**)&nx, (size_t)cap * idx->dpad * sizeof(float)) != hipSuccess) {
+    if (hipMalloc((void**)&nx, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float)) != hipSuccess) {
         cap = need;  // retry with the exact size before giving up
-        if (hipMalloc((void**)&nx, (size_t)cap * idx->dpad * sizeof(float)) != hipSuccess)
+        if (hipMalloc((void**)&nx, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float)) != hipSuccess)
             return fail(RMU_E_OOM, "rmu_index_add: hipMalloc for growth");
     }
     HIP_TRY(hipDeviceSynchronize());  // nobody may still be scanning the old matrix
-    if (idx->dpad != idx->dim)
-        HIP_TRY(hipMemset(nx + idx->n * idx->dpad, 0, (size_t)(cap - idx->n) * idx->dpad * sizeof(float)));
+    HIP_TRY(hipMemset(nx + idx->n * idx->dpad, 0, (size_t)(cap + kSlackRows - idx->n) * idx->dpad * sizeof(float)));
     if (idx->n) HIP_TRY(hipMemcpy(nx, idx->x, (size_t)idx->n * idx->dpad * sizeof(float), hipMemcpyDeviceToDevice));
     (void)hipFree(idx->x);
     idx->x = nx;
@@ -335,11 +337,20 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // ---- plan + workspace ------------------------------------------------------------------------
         ScanLaunch L{};
         L.x = idx->x; L.n_rows = idx->n; L.dpad = dpad; L.q = qdev; L.nq = (int)nb; L.k = k;
+        static u64* g_dbg = nullptr;
+        if (getenv("RMU_SCAN_EXP") && atoi(getenv("RMU_SCAN_EXP")) == 7 && !g_dbg) { (void)hipMalloc((void**)&g_dbg, 128); }
+        if (g_dbg) (void)hipMemsetAsync(g_dbg, 0, 128, s);
+        L.dbg = g_dbg;
         rc = rmu_scan_plan(&L);
         if (rc) return fail(rc, "rmu_index_search: no scan geometry for this (dim, k)");
         const size_t pbytes = (size_t)L.parts * nb * k * sizeof(u64);
         if (t.partial.ensure(pbytes)) return fail(RMU_E_OOM, "rmu_index_search: partial workspace");
         L.partial = (u64*)t.partial.p;
+        // shared per-query thresholds: padded to whole 128-query tiles, zero = no bound yet
+        const size_t gbytes = (size_t)((nb + 127) / 128 * 128 + 64) * sizeof(u32);
+        if (t.gthr.ensure(gbytes)) return fail(RMU_E_OOM, "rmu_index_search: threshold workspace");
+        HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
+        L.gthr = (u32*)t.gthr.p;
         float* d_s = out_scores + q0 * k;
         int64_t* d_r = out_rows + q0 * k;
         if (!out_dev) {
@@ -366,6 +377,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         }
         // workspace is reused by the next query block (and host outputs must land): drain per block
         if (!hip_stream || q0 + nb < nq || !out_dev) HIP_TRY(hipStreamSynchronize(s));
+        if (g_dbg) { u64 h[16]; (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg] slow_tiles=%llu compactions=%llu appends=%llu tiles=%llu slow_clk=%llu compact_clk=%llu addwait_clk=%llu endwait_clk=%llu check_clk=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]); }
         if (timed && idx->n > 0) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms;

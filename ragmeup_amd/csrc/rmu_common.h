@@ -99,7 +99,9 @@ struct ScanLaunch {
     int nq;
     int k;
     u64* partial;          // [parts, nq, k] keys
+    u32* gthr;             // [nq] shared per-query threshold (order-preserving u32 image, 0 = none), zeroed per launch
     int parts;             // filled by the planner
+    u64* dbg;              // optional debug counters (nullptr in production): [0] slow tiles, [1] compactions, [2] appends, [3] tiles
     // filled by rmu_scan_plan
     int wq, kv, s_chunks, nqt, tiles_per_chunk, grid, lds_bytes;
 };

@@ -26,13 +26,15 @@
 // LDS image of a chunk: [RT rows][U16 16-byte units], unit index XOR-swizzled by the row so that the
 // 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte bank slots.  LDS-DMA writes
 // lane-linear, so the swizzle is applied to the per-lane GLOBAL source address (guide rule 21).
+#include <cstdlib>
 #include "rmu_common.h"
 #include "../../include/rmu.h"
 
 namespace {
 
-template <int D_, int WQ_, int CKF_, int RING_, int CAP_, int NCHECK_>
+template <int D_, int WQ_, int CKF_, int RING_, int CAP_, int NCHECK_, int EXP_ = 0>
 struct Cfg {
+    static constexpr int EXP = EXP_;        // 0 = product; 1..3 = timing ablations (wrong results)
     static constexpr int D = D_;            // padded row length (floats)
     static constexpr int WQ = WQ_;          // query groups per workgroup
     static constexpr int RP = 4 / WQ_;      // row parts per tile
@@ -51,41 +53,87 @@ struct Cfg {
     static constexpr int SWB = (U16 % 16 == 8) ? 8 : 4;  // swizzle block (units)
     static constexpr int RING_BYTES = RING_ * SLOT_BYTES;
     static constexpr int CAND_BYTES = 4 * 32 * CAP_ * 8;
-    static constexpr int LDS_BYTES = RING_BYTES + CAND_BYTES + 4 * 32 * 4 + 4 * 32 * 4;
+    static constexpr int TRASH_OFF = RING_BYTES + CAND_BYTES + 4 * 32 * 4 + 4 * 32 * 4;
+    static constexpr int GT_OFF = TRASH_OFF + 256 * 8;       // + one private 8-B trash slot per lane
+    static constexpr int LDS_BYTES = GT_OFF + 4 * 256;       // + per-wave landing zone of the shared thresholds
     static_assert(D_ % CKF_ == 0 && CKF_ % 8 == 0, "chunking");
     static_assert((RT * U16) % 256 == 0, "DMA split");
     static_assert(U16 % 16 == 8 || U16 % 16 == 4 || U16 % 16 == 12, "swizzle classes");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-    static_assert(NI * (RING_ - 2) <= 63, "vmcnt field");
+    static_assert(NI * (RING_ - 2) <= 63 && RING_ >= 2, "vmcnt field");
 };
 
 __device__ __forceinline__ int swz(int row, int swb) { return swb == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
+// LDS byte address of a pointer into dynamic shared memory
+__device__ __forceinline__ u32 lds_addr(const void* p) {
+    return (u32)(uintptr_t)(__attribute__((address_space(3))) char*)(char*)p;
+}
+// LDS stores as inline asm: a compiler-generated LDS write is ordered behind the in-flight LDS-DMA with
+// s_waitcnt vmcnt(0) and would drain the ring.
+__device__ __forceinline__ void lds_store_b64(u32 addr, u64 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// same, without the "memory" clobber: the compiler may move its own ring reads across it (the targets never
+// alias the ring); a clobbering wait follows before anything reads the stored data back
+__device__ __forceinline__ void lds_store_b64_nofence(u32 addr, u64 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v));
+}
+__device__ __forceinline__ void lds_store_b32(u32 addr, u32 v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// rank[p] = number of the wave's n keys that are larger than key[p]  (keys are distinct or 0).
+// Enumeration sort: broadcast key i with v_readlane (no LDS traffic), every lane counts.  ~6 instructions
+// per candidate; a compaction runs while the other three waves of the workgroup wait at the ring barrier,
+// so its latency is paid four times -- the shuffle bitonic sort used here before cost 10% of the kernel.
+template <int NPL>
+__device__ __forceinline__ void rank_keys(const u64 (&key)[NPL], u32 n, u32 (&rank)[NPL]) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) rank[p] = 0;
+#pragma unroll
+    for (int sp = 0; sp < NPL; ++sp) {
+        const u32 lim = n > 64u * sp ? (n - 64u * sp < 64u ? n - 64u * sp : 64u) : 0u;
+        const u32 lo = (u32)key[sp], hi = (u32)(key[sp] >> 32);
+        for (u32 i = 0; i < lim; ++i) {
+            const u64 ki = ((u64)(u32)__builtin_amdgcn_readlane((int)hi, (int)i) << 32) |
+                           (u64)(u32)__builtin_amdgcn_readlane((int)lo, (int)i);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) rank[p] += (ki > key[p]) ? 1u : 0u;
+        }
+    }
+}
+
+// keep the best k of slot j (sorted, best first), refresh its threshold and count
 template <class C>
-__device__ __forceinline__ void compact_slot(int j, u64* cand_w, u32* cnt_w, float* thr_w, int k, int lane) {
+__device__ __forceinline__ void compact_slot(int j, u64* cand_w, u32* cnt_w, float* thr_w, int k, int lane,
+                                             u32* gthr_w /* global, this wave's 32 queries */) {
     const u32 n = cnt_w[j];
     u64 key[C::NPL];
+    u32 rank[C::NPL];
 #pragma unroll
     for (int p = 0; p < C::NPL; ++p) {
         const u32 e = lane + 64 * p;
         key[p] = (e < n) ? cand_w[j * C::CAP + e] : 0ull;
     }
-    rmu_bitonic_sort_desc<C::NPL>(key, lane);
-    const u32 nn = n < (u32)k ? n : (u32)k;
+    rank_keys<C::NPL>(key, n, rank);
+    const u32 base = lds_addr(cand_w + j * C::CAP);
 #pragma unroll
     for (int p = 0; p < C::NPL; ++p) {
         const u32 e = lane + 64 * p;
-        if (e < nn) cand_w[j * C::CAP + e] = key[p];
+        if (e < n && rank[p] < (u32)k) {
+            lds_store_b64(base + rank[p] * 8u, key[p]);
+            if (rank[p] == (u32)(k - 1)) {
+                lds_store_b32(lds_addr(thr_w + j), __float_as_uint(rmu_key_score(key[p])));
+                // publish: this chunk's k-th best is a lower bound of the query's global k-th best
+                __hip_atomic_fetch_max(gthr_w + j, (u32)(key[p] >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
-    if (n >= (u32)k) {
-        u64 sel = key[0];
-        if (C::NPL > 1 && ((k - 1) >> 6)) sel = key[C::NPL > 1 ? 1 : 0];
-        const u64 kth = __shfl(sel, (k - 1) & 63);
-        if (lane == 0) thr_w[j] = rmu_key_score(kth);
-    }
-    if (lane == 0) cnt_w[j] = nn;
+    if (lane == 0) lds_store_b32(lds_addr(cnt_w + j), n < (u32)k ? n : (u32)k);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 template <class C>
@@ -124,48 +172,48 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
 
     const int q_idx = (qt * C::WQ + g) * 32 + j;
     const bool q_ok = q_idx < a.nq;
+    ((u32*)(smem + C::GT_OFF))[w * 64 + lane] = 0u;   // landing zone of the shared thresholds: 0 = no bound
     if (lane < 32) {
         cnt_w[lane] = 0;
         thr_w[lane] = q_ok ? -INFINITY : INFINITY;
     }
-    float thr = q_ok ? -INFINITY : INFINITY;
+    float thr = q_ok ? -INFINITY : INFINITY;       // effective filter = max(local k-th best, shared bound)
+    float thr_loc = thr, thr_g = -INFINITY;
+    // shared thresholds of this wave's 32 queries (global) and their LDS landing zone
+    u32* gthr_w = a.gthr + (qt * C::WQ + g) * 32;
+    const u32* gt_lds = (const u32*)(smem + C::GT_OFF) + w * 64;
 
     // ---- query fragments -> registers --------------------------------------------------------------
     f32x4 qf[C::D / 8];
     {
+        // padded query columns read row 0 (valid memory): their threshold is +inf and nothing is emitted.
+        // No select here: pure load -> MFMA operand lets the allocator park fragments in AGPRs.
         const float* qrow = a.q + (size_t)(q_ok ? q_idx : 0) * C::D + 4 * h;
 #pragma unroll
-        for (int t = 0; t < C::D / 8; ++t) {
-            f32x4 v = *(const f32x4*)(qrow + 8 * t);
-            if (!q_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            qf[t] = v;
-        }
+        for (int t = 0; t < C::D / 8; ++t) qf[t] = *(const f32x4*)(qrow + 8 * t);
     }
 
     // ---- per-lane DMA source map (constant over the kernel) ----------------------------------------
-    int dma_row[C::NI];   // row inside the tile
-    int dma_col[C::NI];   // float offset inside the chunk (already de-swizzled)
+    // byte offset of this lane's 16-B unit inside a [RT x D] tile (de-swizzled); the per-chunk base is a
+    // scalar, so a DMA issue is one global_load_lds with saddr + 32-bit voffset and no VALU at all.
+    // Rows past n_rows are read (the index keeps >= 128 slack rows) and dropped by the epilogue.
+    u32 dma_off[C::NI];
 #pragma unroll
     for (int n = 0; n < C::NI; ++n) {
         const int f = (n * 4 + w) * 64 + lane;
         const int i = f / C::U16, p = f % C::U16;
-        dma_row[n] = i;
-        dma_col[n] = 4 * (p ^ swz(i, C::SWB));
+        dma_off[n] = (u32)(i * C::D + 4 * (p ^ swz(i, C::SWB))) * 4u;
     }
-    const int64_t last_row = a.n_rows - 1;
 
     auto issue_chunk = [&](int cc) {   // cc = running chunk number inside this workgroup
         int tl = cc / C::NCH;
         const int c = cc % C::NCH;
         if (tl >= ntiles) tl = ntiles - 1;   // tail: harmless reloads keep the vmcnt bookkeeping uniform
-        const int64_t row0 = (t0 + tl) * C::RT;
+        const char* sbase = (const char*)(a.x + ((t0 + tl) * C::RT) * (int64_t)C::D + c * C::CKF);
         char* slot = ring + (cc % C::RING) * C::SLOT_BYTES;
 #pragma unroll
         for (int n = 0; n < C::NI; ++n) {
-            int64_t r = row0 + dma_row[n];
-            r = r > last_row ? last_row : r;
-            const float* src = a.x + r * (int64_t)C::D + c * C::CKF + dma_col[n];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
                                              (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024),
                                              16, 0, 0);
         }
@@ -186,64 +234,218 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
         const u64 bal = __ballot(c > (u32)(C::CAP - C::A));
         u32 mask = (u32)bal | (u32)(bal >> 32);
         if (mask) {
+            const long long tc0 = (C::EXP == 7) ? clock64() : 0;
             while (mask) {
                 const int jj = __builtin_ctz(mask);
                 mask &= mask - 1;
-                compact_slot<C>(jj, cand_w, cnt_w, thr_w, a.k, lane);
+                compact_slot<C>(jj, cand_w, cnt_w, thr_w, a.k, lane, gthr_w);
+                if (C::EXP == 7 && lane == 0 && a.dbg) atomicAdd((unsigned long long*)a.dbg + 1, 1ull);
             }
-            thr = thr_w[j];
+            thr_loc = thr_w[j];
+            thr = fmaxf(thr_loc, thr_g);
+            if (C::EXP == 7 && lane == 0 && a.dbg) atomicAdd((unsigned long long*)a.dbg + 5, (unsigned long long)(clock64() - tc0));
+        }
+    };
+
+    // A-fragment of step t of the chunk living in ring slot `slot_off` (bytes)
+    auto read_frag = [&](int slot_off, int t) -> f32x4 {
+        const int off = abase[t % (C::SWB / 2)] + (t / (C::SWB / 2)) * (C::SWB * 16);
+        return *(const f32x4*)(ring + slot_off + off);
+    };
+    // LA (look-ahead): chunk cc+1 has landed when barrier cc is passed, so the first fragment of the
+    // next chunk is read BEFORE its barrier and the MFMA pipe never waits on an LDS round trip.
+    constexpr bool LA = C::RING >= 3;
+    constexpr int WAITN = LA ? C::NI * (C::RING - 3) : C::NI * (C::RING - 2);
+
+    // ---- threshold filter of the PREVIOUS tile, hidden behind this tile's MFMAs ------------------------
+    // Two accumulators alternate.  While the first 16 MFMAs of a tile issue, each gap builds one bit of a
+    // per-lane pass mask (prev[r] > thr; tombstoned rows are NaN and never pass).  ONE uniform branch per
+    // tile then picks a plain continuation or a "slow" one whose MFMA gaps carry the appends:
+    // one ds_add_rtn by popcount reserves slots, 16 exec-predicated ds_write_b64 store the keys.
+    // (On a lone wave per SIMD every skip-branch costs ~100 cycles -- 16 per tile was 13% of the kernel.)
+    // All LDS writes are inline asm: a compiler-generated LDS write is ordered behind the in-flight
+    // LDS-DMA with s_waitcnt vmcnt(0) and would drain the ring.
+    u32 pmask = 0;
+    auto mask_slot = [&](const f32x16& prev, int r) { pmask |= (prev[r] > thr) ? (1u << r) : 0u; };
+    u32 wr_addr = 0;
+    u32 res_pos = 0;
+    auto slow_issue = [&](u32 bits) {   // reserve popc(pmask & bits) entries of this lane's query slot
+        const u32 n = __builtin_popcount(pmask & bits);
+        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(res_pos) : "v"(cnt_addr), "v"(n));
+    };
+    auto slow_wait = [&]() {            // ... one K-step later the returned position is consumed
+        const long long tw0 = (C::EXP == 7) ? clock64() : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(res_pos));
+        if (C::EXP == 7 && lane == 0 && a.dbg) atomicAdd((unsigned long long*)a.dbg + 6, (unsigned long long)(clock64() - tw0));
+        if (C::EXP == 5) res_pos &= 31u;   // ablation: appends every tile, never compacted
+        wr_addr = cand_addr + res_pos * 8u;
+    };
+    auto slow_begin = [&](u32 bits) { slow_issue(bits); slow_wait(); };
+    // store prev[r]'s key at wr_addr (and advance it) in the lanes whose pass bit r is set.  No branch and
+    // no EXEC games (32 EXEC rewrites per tile stalled the MFMA stream for thousands of cycles): every
+    // lane stores, the non-passing ones into their private trash slot.
+    const u32 trash_addr = lds_addr(smem + C::TRASH_OFF) + threadIdx.x * 8u;
+    auto slow_slot_r = [&](const f32x16& prev, int r, int64_t rbase) {
+        const u64 key = rmu_make_key(prev[r] + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+        const bool pass = (pmask >> r) & 1u;   // r is a compile-time constant after unrolling
+        lds_store_b64_nofence(pass ? wr_addr : trash_addr, key);
+        wr_addr += pass ? 8u : 0u;
+    };
+    auto slow_end = [&]() {
+        const long long te0 = (C::EXP == 7) ? clock64() : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long te1 = (C::EXP == 7) ? clock64() : 0;
+        if (C::EXP != 5) check_compact();
+        if (C::EXP == 7 && lane == 0 && a.dbg) {
+            atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(te1 - te0));
+            atomicAdd((unsigned long long*)a.dbg + 8, (unsigned long long)(clock64() - te1));
+        }
+    };
+    int cc = 0;
+    f32x4 a_cur = {0.f, 0.f, 0.f, 0.f};
+    // one K-step: prefetch the next fragment, 4 MFMAs, hook(i) after MFMA i (i = 0..3)
+    auto do_step = [&](f32x16& acc, int c, int t, int slot_off, int next_off, bool pin, auto&& hook) {
+        f32x4 a_nxt = a_cur;
+        if (t + 1 < C::TS) a_nxt = read_frag(slot_off, t + 1);
+        else if (LA) a_nxt = read_frag(next_off, 0);
+        const f32x4 qv = qf[c * C::TS + t];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, qv.x, acc, 0, 0, 0);
+        hook(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, qv.y, acc, 0, 0, 0);
+        hook(1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, qv.z, acc, 0, 0, 0);
+        hook(2);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, qv.w, acc, 0, 0, 0);
+        hook(3);
+        a_cur = a_nxt;
+        if (pin) {
+            // pin the software pipeline: the NEXT fragment's ds_read issues ahead of this step's four
+            // MFMAs (hipcc otherwise sinks it behind them and exposes the LDS round trip)
+            if (t + 1 < C::TS || LA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    };
+    auto no_hook = [](int) {};
+
+    // One tile: a single MFMA chain into `acc`; the previous tile's accumulator `prev` is filtered in its
+    // gaps, keyed on the global step gs = c*TS + t:
+    //   gs 0..3  pass-mask bits (slot r behind MFMA r+1, when prev's last MFMA has retired)
+    //   gs 4     the ONE branch of the tile: if any lane passed, an out-of-line block (no MFMAs inside)
+    //            reserves slots with one ds_add_rtn by popcount and stores the keys; ~7% of tiles at 10M.
+    // Measured alternatives on MI355X (10M x 384, B=1024): 16 skip-branches/tile 128 TF; a fast and a slow copy
+    // of the MFMA chain (appends in MFMA gaps) 135.6 TF but hipcc then copies 16 AGPRs + drains the pipe
+    // at every tile end; ~20 not-taken scalar branches/tile 132 TF (every branch stalls a lone in-order wave).
+    auto tile_body = [&](f32x16& acc, f32x16& prev, int64_t prev_rbase) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        pmask = 0;
+        bool anyp = false;
+#pragma unroll
+        for (int c = 0; c < C::NCH; ++c, ++cc) {
+            // own DMA of chunk cc (+1 with look-ahead) has landed; own LDS reads have returned
+            if (C::EXP == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
+            if (C::EXP != 2) __builtin_amdgcn_s_barrier();
+            if (c == 0) {
+                // shared threshold fetched by last tile's DMA: pass iff v >= bound  <=>  v > nextbelow(bound)
+                const u32 go = gt_lds[j];
+                thr_g = go ? rmu_ord2f(go - 1u) : -INFINITY;
+                thr = fmaxf(thr_loc, thr_g);
+            }
+            if (c == C::NCH - 1) {
+                // refresh for the next tile: one 4-B-per-lane LDS-DMA, issued BEFORE this chunk's group so the
+                // next counted vmcnt covers it; sc1 = skip the (never refreshed) per-CU L1
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gthr_w + j),
+                                                 (__attribute__((address_space(3))) void*)(smem + C::GT_OFF + w * 256), 4, 0, 16);
+            }
+            issue_chunk(cc + C::RING - 1);   // refills the slot every wave finished reading last round
+            const int slot_off = (cc % C::RING) * C::SLOT_BYTES;
+            const int next_off = ((cc + 1) % C::RING) * C::SLOT_BYTES;
+            if (!LA) a_cur = read_frag(slot_off, 0);
+#pragma unroll
+            for (int t = 0; t < C::TS; ++t) {
+                const int gs = c * C::TS + t;
+                if (C::EXP == 3 || gs > 4) {
+                    do_step(acc, c, t, slot_off, next_off, true, no_hook);
+                } else if (gs < 4) {
+                    do_step(acc, c, t, slot_off, next_off, false, [&](int i) {
+                        const int m = 4 * gs + i;
+                        if (m >= 1) mask_slot(prev, m - 1);
+                        if (m == 15) mask_slot(prev, 15);
+                    });
+                } else {   // gs == 4: the one branch of the tile
+                    anyp = __any(pmask != 0) && C::EXP != 4;
+                    if (C::EXP == 7 && lane == 0 && a.dbg) atomicAdd((unsigned long long*)a.dbg + 3, 1ull);
+                    if (__builtin_expect(anyp, 0)) {
+                        if (C::EXP == 7 && a.dbg) {
+                            if (lane == 0) atomicAdd((unsigned long long*)a.dbg + 0, 1ull);
+                            atomicAdd((unsigned long long*)a.dbg + 2, (unsigned long long)__builtin_popcount(pmask));
+                        }
+                        slow_begin(C::NCHECK == 2 ? 0x00FFu : 0xFFFFu);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if (C::NCHECK == 2 && r == 8) { slow_end(); slow_begin(0xFF00u); }
+                            slow_slot_r(prev, r, prev_rbase);
+                        }
+                        slow_end();
+                    }
+                    do_step(acc, c, t, slot_off, next_off, true, no_hook);
+                }
+            }
         }
     };
 
     if (ntiles > 0) {
         // ---- prologue: RING-1 chunks in flight -----------------------------------------------------
 #pragma unroll
-        for (int cc = 0; cc < C::RING - 1; ++cc) issue_chunk(cc);
-
-        int cc = 0;
-        for (int tl = 0; tl < ntiles; ++tl) {
-            f32x16 acc = {0.f};
+        for (int c0 = 0; c0 < C::RING - 1; ++c0) issue_chunk(c0);
+        if (LA) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NI * (C::RING - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            a_cur = read_frag(0, 0);
+        }
+        f32x16 accA, accB;
 #pragma unroll
-            for (int c = 0; c < C::NCH; ++c, ++cc) {
-                // chunk cc has landed once at most (RING-2) younger groups are outstanding
-                // lgkmcnt(0): this wave's LDS reads of the slot about to be refilled have returned too
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::NI * (C::RING - 2)) : "memory");
-                __builtin_amdgcn_s_barrier();
-                issue_chunk(cc + C::RING - 1);   // overwrites the slot every wave finished last round
-                const char* slot = ring + (cc % C::RING) * C::SLOT_BYTES;
-#pragma unroll
-                for (int t = 0; t < C::TS; ++t) {
-                    const int off = abase[t % (C::SWB / 2)] + (t / (C::SWB / 2)) * (C::SWB * 16);
-                    const f32x4 av = *(const f32x4*)(slot + off);
-                    const f32x4 qv = qf[c * C::TS + t];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, qv.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, qv.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, qv.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qv.w, acc, 0, 0, 0);
-                }
-            }
-            // ---- epilogue: threshold filter + LDS append ---------------------------------------------
-            const int64_t rbase = (t0 + tl) * C::RT + 32 * rp + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-                const float v = acc[r] + 0.0f;   // canonicalise -0
-                // tombstoned rows are NaN-poisoned in HBM (rmu_index_remove_rows): NaN > thr is false
-                if (v > thr && row < a.n_rows) {
-                    // inline asm: a compiler-generated LDS write would be ordered behind the in-flight
-                    // LDS-DMA with s_waitcnt vmcnt(0), draining the ring on most tiles
-                    const u64 key = rmu_make_key(v, (u32)row);
-                    u32 pos;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=v"(pos) : "v"(cnt_addr), "v"(1u) : "memory");
-                    const u32 dst = cand_addr + pos * 8u;
-                    asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(dst), "v"(key) : "memory");
-                }
-                if (C::NCHECK == 2 && r == 7) check_compact();
-            }
-            check_compact();
+        for (int r = 0; r < 16; ++r) accB[r] = -INFINITY;   // "previous tile" of tile 0: nothing passes
+        const int64_t lane_r0 = t0 * C::RT + 32 * rp + 4 * h;   // this lane's first row in tile 0
+        auto rb = [&](int t) { return lane_r0 + (int64_t)t * C::RT; };
+        // peel + two-tile loop: at the loop head accA always holds the tile to be filtered next
+        tile_body(accA, accB, rb(-1));
+        int tl = 1;
+        for (; tl + 1 < ntiles; tl += 2) {
+            tile_body(accB, accA, rb(tl - 1));
+            tile_body(accA, accB, rb(tl));
+        }
+        bool last_in_a = true;
+        if (tl < ntiles) {
+            tile_body(accB, accA, rb(tl - 1));
+            last_in_a = false;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- filter of the chunk's last tile (not overlapped).  Rows >= n_rows exist only here (the
+        // globally last tile is some chunk's last tile): blank them with a per-lane validity mask.
+        {
+            f32x16 last;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) last[r] = last_in_a ? accA[r] : accB[r];
+            if (C::EXP == 3) asm volatile("" ::"v"(last[0]), "v"(last[15]));
+            const int64_t rbl = rb(ntiles - 1);
+            pmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                mask_slot(last, r);
+                if (rbl + (r & 3) + 8 * (r >> 2) >= a.n_rows) pmask &= ~(1u << r);
+            }
+            if (__any(pmask != 0) && C::EXP != 3) {
+                slow_begin(C::NCHECK == 2 ? 0x00FFu : 0xFFFFu);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (C::NCHECK == 2 && r == 8) { slow_end(); slow_begin(0xFF00u); }
+                    slow_slot_r(last, r, rbl);
+                }
+                slow_end();
+            }
+        }
     }
 
     // ---- final: sort every slot, emit k keys per (part, query) ---------------------------------------
@@ -253,17 +455,22 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
         if (qq >= a.nq) break;
         const u32 n = cnt_w[jj];
         u64 key[C::NPL];
+        u32 rank[C::NPL];
 #pragma unroll
         for (int p = 0; p < C::NPL; ++p) {
             const u32 e = lane + 64 * p;
             key[p] = (e < n) ? cand_w[jj * C::CAP + e] : 0ull;
         }
-        rmu_bitonic_sort_desc<C::NPL>(key, lane);
+        rank_keys<C::NPL>(key, n, rank);
         u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
 #pragma unroll
         for (int p = 0; p < C::NPL; ++p) {
-            const int e = lane + 64 * p;
-            if (e < a.k) dst[e] = key[p];
+            const u32 e = lane + 64 * p;
+            if (e < n) {
+                if (rank[p] < (u32)a.k) dst[rank[p]] = key[p];
+            } else if (e < (u32)a.k) {
+                dst[e] = 0ull;   // fewer than k candidates: pad (e >= n are exactly the unfilled ranks)
+            }
         }
     }
 }
@@ -292,7 +499,17 @@ template <int D> using C_w1_k0 = Cfg<D, 1, 48, 3, 64, 1>;    // 72 KiB ring
 template <int D>
 int launch_d(const ScanLaunch* p, hipStream_t s) {
     switch (p->wq * 2 + p->kv) {
-        case 8: return launch_cfg<C_w4_k0<D>>(p, s);
+        case 8: {
+            static const int exp = getenv("RMU_SCAN_EXP") ? atoi(getenv("RMU_SCAN_EXP")) : 0;
+            if (D == 384 && exp == 1) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 1>>(p, s);
+            if (D == 384 && exp == 2) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 2>>(p, s);
+            if (D == 384 && exp == 3) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 3>>(p, s);
+            if (D == 384 && exp == 4) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 4>>(p, s);
+            if (D == 384 && exp == 5) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 5>>(p, s);
+            if (D == 384 && exp == 6) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 6>>(p, s);
+            if (D == 384 && exp == 7) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 7>>(p, s);
+            return launch_cfg<C_w4_k0<D>>(p, s);
+        }
         case 9: return launch_cfg<C_w4_k1<D>>(p, s);
         case 4: return launch_cfg<C_w2_k0<D>>(p, s);
         case 5: return launch_cfg<C_w2_k1<D>>(p, s);
