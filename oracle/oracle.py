@@ -142,34 +142,40 @@ def merge_topk(part_scores: np.ndarray, part_rows: np.ndarray, k: int):
 #     3P langchain_core.vectorstores.utils.maximal_marginal_relevance, fetch_k=20, lambda=0.5)
 # ----------------------------------------------------------------------------------------------
 def _cosine_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """langchain_core.vectorstores.utils.cosine_similarity (numpy branch): dot(X, Y^T)/outer(|X|,|Y|) in
+    float64, NaN/inf -> 0."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     an = np.linalg.norm(a, axis=1)
     bn = np.linalg.norm(b, axis=1)
     with np.errstate(divide="ignore", invalid="ignore"):
-        s = (a @ b.T) / np.outer(an, bn)
+        s = np.dot(a, b.T) / np.outer(an, bn)
     s[np.isnan(s) | np.isinf(s)] = 0.0
     return s
 
 
 def mmr(query_vec: np.ndarray, cand: np.ndarray, k: int = 4, lambda_mult: float = 0.5) -> list[int]:
-    """Greedy maximal marginal relevance; strict '>' so the lowest index wins ties."""
+    """Greedy maximal marginal relevance; strict '>' so the lowest index wins ties.  The similarity to the
+    selected set is re-evaluated against the growing `selected` matrix each round, as published."""
+    cand = np.asarray(cand)
     n = cand.shape[0]
     if min(k, n) <= 0:
         return []
     sim_q = _cosine_matrix(np.asarray(query_vec).reshape(1, -1), cand)[0]
     first = int(np.argmax(sim_q))
     picked = [first]
+    selected = np.array([cand[first]])
     while len(picked) < min(k, n):
-        sim_sel = _cosine_matrix(cand, cand[picked])
+        sim_sel = _cosine_matrix(cand, selected)
         best, best_i = -np.inf, -1
-        for i in range(n):
+        for i, qs in enumerate(sim_q):
             if i in picked:
                 continue
-            val = lambda_mult * sim_q[i] - (1.0 - lambda_mult) * sim_sel[i].max()
+            val = lambda_mult * qs - (1.0 - lambda_mult) * max(sim_sel[i])
             if val > best:
                 best, best_i = val, i
         picked.append(best_i)
+        selected = np.append(selected, [cand[best_i]], axis=0)
     return picked
 
 

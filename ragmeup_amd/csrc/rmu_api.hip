@@ -163,7 +163,14 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
     int64_t cap = capacity_hint > 0 ? capacity_hint : 4096;
     hipError_t e = hipMalloc((void**)&idx->x, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float));
     if (e != hipSuccess) { delete idx; return fail(RMU_E_OOM, "rmu_index_create: hipMalloc"); }
-    (void)hipMemset(idx->x, 0, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float));
+    // zero fill ON OUR STREAM and wait: a null-stream hipMemset is asynchronous to the host and is not ordered
+    // with a hipStreamNonBlocking stream, so it could land after (and wipe) the first rows uploaded on it
+    if (hipMemsetAsync(idx->x, 0, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float), g_tls.stream) != hipSuccess ||
+        hipStreamSynchronize(g_tls.stream) != hipSuccess) {
+        (void)hipFree(idx->x);
+        delete idx;
+        return fail(RMU_E_HIP, "rmu_index_create: zero fill");
+    }
     idx->cap = cap;
     *out = idx;
     return RMU_OK;
@@ -204,8 +211,11 @@ static int grow(rmu_index* idx, int64_t need) {
             return fail(RMU_E_OOM, "rmu_index_add: hipMalloc for growth");
     }
     HIP_TRY(hipDeviceSynchronize());  // nobody may still be scanning the old matrix
-    HIP_TRY(hipMemset(nx + idx->n * idx->dpad, 0, (size_t)(cap + kSlackRows - idx->n) * idx->dpad * sizeof(float)));
-    if (idx->n) HIP_TRY(hipMemcpy(nx, idx->x, (size_t)idx->n * idx->dpad * sizeof(float), hipMemcpyDeviceToDevice));
+    hipStream_t s = g_tls.stream;     // same stream as the uploads that follow (see rmu_index_create)
+    HIP_TRY(hipMemsetAsync(nx + idx->n * idx->dpad, 0, (size_t)(cap + kSlackRows - idx->n) * idx->dpad * sizeof(float), s));
+    if (idx->n)
+        HIP_TRY(hipMemcpyAsync(nx, idx->x, (size_t)idx->n * idx->dpad * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(idx->x);
     idx->x = nx;
     idx->cap = cap;
@@ -351,6 +361,8 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         if (t.gthr.ensure(gbytes)) return fail(RMU_E_OOM, "rmu_index_search: threshold workspace");
         HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
         L.gthr = (u32*)t.gthr.p;
+        static const int share = getenv("RMU_NO_SHARED_THR") ? 0 : 1;
+        L.share_thr = share;
         float* d_s = out_scores + q0 * k;
         int64_t* d_r = out_rows + q0 * k;
         if (!out_dev) {

@@ -99,6 +99,7 @@ struct ScanLaunch {
     int nq;
     int k;
     u64* partial;          // [parts, nq, k] keys
+    int share_thr;         // 1 = read the shared thresholds (0: publish only; debugging aid)
     u32* gthr;             // [nq] shared per-query threshold (order-preserving u32 image, 0 = none), zeroed per launch
     int parts;             // filled by the planner
     u64* dbg;              // optional debug counters (nullptr in production): [0] slow tiles, [1] compactions, [2] appends, [3] tiles

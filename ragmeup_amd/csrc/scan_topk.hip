@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
             if (c == 0) {
                 // shared threshold fetched by last tile's DMA: pass iff v >= bound  <=>  v > nextbelow(bound)
                 const u32 go = gt_lds[j];
-                thr_g = go ? rmu_ord2f(go - 1u) : -INFINITY;
+                thr_g = (go && a.share_thr) ? rmu_ord2f(go - 1u) : -INFINITY;
                 thr = fmaxf(thr_loc, thr_g);
             }
             if (c == C::NCH - 1) {

@@ -1,0 +1,304 @@
+"""MI355XVectorStore -- the VectorStore the reference builds at server/RAGHelper.py:385-404 and queries at
+:497-499, backed by the HBM-resident flat index (librmu.so).
+
+Surface actually touched by the reference, all provided here:
+  * ``MI355XVectorStore.from_documents([], embedding, drop_old=..., connection_args={"uri":...},
+    collection_name=...)``  (Milvus form, RAGHelper.py:388-394) and
+    ``MI355XVectorStore(embeddings=..., collection_name=..., connection=..., use_jsonb=True)``
+    (PGVector form, :399-404);
+  * ``add_documents(documents, ids=ids) -> ids``  (:431, :525);
+  * ``as_retriever(search_type="mmr", search_kwargs={"k": K})`` -> object with ``invoke(str)`` that
+    composes with ``|`` (:497-499, RAGHelper_local.py:158,256);
+  * returned ``Document.metadata`` carries ``source``, ``id`` and ``pk`` (server.py:278-281);
+  * ``delete(...)`` incl. the ``source == "<path>"`` expression server.py:373-377 sends to Milvus.
+
+Scores: the index ranks by inner product (embeddings are unit-norm, as sentence-transformers' Normalize
+module makes them).  ``score_mode`` converts to what the replaced store would report:
+"l2" -> 2 - 2*ip (Milvus metric_type "L2", smaller = better), "cosine_distance" -> 1 - ip (pgvector `<=>`),
+"ip" -> raw.  MMR restates langchain_core's maximal_marginal_relevance (fetch_k=20, lambda_mult=0.5,
+strict '>' so the lowest index wins ties) on the fetch_k vectors gathered from HBM.
+"""
+from __future__ import annotations
+
+import re
+import threading
+from typing import Any, Iterable, Optional
+
+import numpy as np
+
+from . import _native as N
+from .documents import Document, RunnableShim
+from .index import FlatIndex
+
+
+def _cosine_similarity(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """dot(X, Y^T) / outer(|X|, |Y|), NaN/inf -> 0 -- the float64 expression the replaced MMR uses.  Kept in
+    exactly this form: when the query equals a stored vector every second-pick score is 0 in exact
+    arithmetic and rounding noise picks the winner, so an algebraically equivalent shortcut diverges."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    xn = np.linalg.norm(x, axis=1)
+    yn = np.linalg.norm(y, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sim = np.dot(x, y.T) / np.outer(xn, yn)
+    sim[np.isnan(sim) | np.isinf(sim)] = 0.0
+    return sim
+
+
+def maximal_marginal_relevance(query_vec: np.ndarray, cand: np.ndarray, k: int = 4,
+                               lambda_mult: float = 0.5) -> list[int]:
+    """Greedy MMR over `cand` [n, d] (cosine similarities, float64), as the reference's dense retriever
+    applies it (server/RAGHelper.py:497-499, search_type="mmr" -> langchain_core maximal_marginal_relevance):
+    first pick = argmax sim to the query; then repeatedly the candidate maximising
+    lambda*sim_q - (1-lambda)*max(sim to picked), strict '>' so the lowest index wins ties."""
+    cand = np.asarray(cand)
+    n = int(cand.shape[0])
+    if min(k, n) <= 0:
+        return []
+    sim_q = _cosine_similarity(np.asarray(query_vec).reshape(1, -1), cand)[0]
+    picked = [int(np.argmax(sim_q))]
+    selected = np.array([cand[picked[0]]])
+    while len(picked) < min(k, n):
+        best, best_i = -np.inf, -1
+        sim_sel = _cosine_similarity(cand, selected)
+        for i in range(n):
+            if i in picked:
+                continue
+            val = lambda_mult * sim_q[i] - (1.0 - lambda_mult) * max(sim_sel[i])
+            if val > best:
+                best, best_i = val, i
+        picked.append(best_i)
+        selected = np.append(selected, [cand[best_i]], axis=0)
+    return picked
+
+
+class MI355XRetriever(RunnableShim):
+    """What ``as_retriever`` returns: ``invoke(query) -> list[Document]``."""
+
+    def __init__(self, store: "MI355XVectorStore", search_type: str = "similarity", search_kwargs: dict | None = None):
+        if search_type not in ("similarity", "mmr", "similarity_score_threshold"):
+            raise ValueError(f"search_type of {search_type} not allowed.")
+        self.vectorstore = store
+        self.search_type = search_type
+        self.search_kwargs = dict(search_kwargs or {})
+
+    def invoke(self, query: str, config: Any = None, **kw) -> list[Document]:
+        if self.search_type == "mmr":
+            return self.vectorstore.max_marginal_relevance_search(query, **self.search_kwargs)
+        if self.search_type == "similarity_score_threshold":
+            thr = self.search_kwargs.get("score_threshold")
+            kw2 = {k: v for k, v in self.search_kwargs.items() if k != "score_threshold"}
+            pairs = self.vectorstore.similarity_search_with_relevance_scores(query, **kw2)
+            return [d for d, s in pairs if thr is None or s >= thr]
+        return self.vectorstore.similarity_search(query, **self.search_kwargs)
+
+    def batch_invoke(self, queries: list[str]) -> list[list[Document]]:
+        """New capability beside the LangChain API: one fused scan for a whole query batch."""
+        k = int(self.search_kwargs.get("k", 4))
+        if self.search_type == "mmr":
+            return self.vectorstore.max_marginal_relevance_search_batch(queries, **self.search_kwargs)
+        return [[d for d, _ in row] for row in self.vectorstore.similarity_search_with_score_batch(queries, k=k)]
+
+
+class MI355XVectorStore:
+    _collections: dict[str, "MI355XVectorStore"] = {}   # drop_old=False re-attaches to a live collection
+    _collections_lock = threading.Lock()
+
+    def __init__(self, embeddings: Any = None, collection_name: str = "LangChainCollection", connection: Any = None,
+                 use_jsonb: bool = True, *, embedding_function: Any = None, connection_args: dict | None = None,
+                 drop_old: bool = False, score_mode: str = "l2", dim: int | None = None, device: int | None = None):
+        self.embeddings = embeddings if embeddings is not None else embedding_function
+        if self.embeddings is None:
+            raise ValueError("an Embeddings object is required")
+        self.collection_name = collection_name
+        self.connection = connection if connection is not None else (connection_args or {}).get("uri")
+        if score_mode not in ("l2", "cosine_distance", "ip"):
+            raise ValueError("score_mode must be 'l2', 'cosine_distance' or 'ip'")
+        self.score_mode = score_mode
+        self._device = device
+        self._dim = dim
+        self._index: FlatIndex | None = None
+        self._lock = threading.RLock()       # writer lock (add/delete); searches take the C-side shared lock
+        self._texts: list[str] = []
+        self._metas: list[dict] = []
+        self._pks: list[str] = []
+        self._alive: list[bool] = []
+        self._pk_to_row: dict[str, int] = {}
+
+    # ---- construction as the reference does it (RAGHelper.py:388-394) --------------------------------
+    @classmethod
+    def from_documents(cls, documents: list[Document], embedding: Any, drop_old: bool = False,
+                       connection_args: dict | None = None, collection_name: str = "LangChainCollection",
+                       ids: list[str] | None = None, **kw) -> "MI355XVectorStore":
+        key = f"{(connection_args or {}).get('uri')}::{collection_name}"
+        with cls._collections_lock:
+            store = None if drop_old else cls._collections.get(key)
+            if store is None:
+                store = cls(embeddings=embedding, collection_name=collection_name, connection_args=connection_args, **kw)
+                cls._collections[key] = store
+        if documents:
+            store.add_documents(documents, ids=ids)
+        return store
+
+    # ---- helpers ----------------------------------------------------------------------------------------
+    _index_factory = None   # tests may inject a fake; the product path always builds the HIP index
+
+    def _ensure_index(self, dim: int):
+        if self._index is None:
+            self._dim = dim
+            factory = type(self)._index_factory or (lambda d: FlatIndex(d, N.METRIC_IP, device=self._device))
+            self._index = factory(dim)
+        elif dim != self._dim:
+            raise ValueError(f"embedding dimension changed: {self._dim} -> {dim}")
+
+    def _embed_docs(self, texts: list[str]) -> np.ndarray:
+        if hasattr(self.embeddings, "embed_documents_array"):     # our Embeddings: no Python float lists
+            return np.asarray(self.embeddings.embed_documents_array(texts), dtype=np.float32)
+        return np.asarray(self.embeddings.embed_documents(texts), dtype=np.float32)
+
+    def _embed_query(self, text: str) -> np.ndarray:
+        return np.asarray(self.embeddings.embed_query(text), dtype=np.float32)
+
+    def _doc(self, row: int) -> Document:
+        md = dict(self._metas[row])
+        md["pk"] = self._pks[row]
+        return Document(page_content=self._texts[row], metadata=md)
+
+    def _convert(self, ip: float) -> float:
+        if self.score_mode == "l2":
+            return float(2.0 - 2.0 * ip)
+        if self.score_mode == "cosine_distance":
+            return float(1.0 - ip)
+        return float(ip)
+
+    def __len__(self) -> int:
+        return sum(self._alive)
+
+    # ---- insert (RAGHelper.py:431, :525) ------------------------------------------------------------------
+    def add_texts(self, texts: Iterable[str], metadatas: Optional[list[dict]] = None, ids: Optional[list[str]] = None,
+                  **kw) -> list[str]:
+        texts = list(texts)
+        if not texts:
+            return []
+        metadatas = metadatas or [{} for _ in texts]
+        if ids is None:
+            import uuid
+            ids = [str(uuid.uuid4()) for _ in texts]
+        if len(ids) != len(texts) or len(metadatas) != len(texts):
+            raise ValueError("texts, metadatas and ids must have equal lengths")
+        vecs = self._embed_docs(texts)
+        with self._lock:
+            self._ensure_index(int(vecs.shape[1]))
+            # upsert semantics of the replaced stores: an existing pk is replaced
+            stale = [self._pk_to_row[i] for i in ids if i in self._pk_to_row and self._alive[self._pk_to_row[i]]]
+            if stale:
+                self._index.remove_rows(stale)
+                for r in stale:
+                    self._alive[r] = False
+            first = self._index.add(vecs)
+            for off, (t, m, i) in enumerate(zip(texts, metadatas, ids)):
+                self._texts.append(t)
+                self._metas.append(dict(m))
+                self._pks.append(str(i))
+                self._alive.append(True)
+                self._pk_to_row[str(i)] = first + off
+        return list(ids)
+
+    def add_documents(self, documents: list[Document], ids: Optional[list[str]] = None, **kw) -> list[str]:
+        return self.add_texts([d.page_content for d in documents], [d.metadata for d in documents], ids=ids, **kw)
+
+    # ---- delete (server.py:373-377) -----------------------------------------------------------------------
+    _EXPR = re.compile(r"""^\s*(\w+)\s*==\s*(['"])(.*)\2\s*$""")
+
+    def delete(self, ids: Optional[list[str]] = None, expr: Optional[str] = None, filter: Optional[dict] = None, **kw):
+        """Delete by pk list, by a Milvus-style `field == "value"` expression, or by a metadata dict.
+        Returns an object with ``delete_count`` (what server.py:385 reads) that is also truthy/int-like."""
+        with self._lock:
+            rows: list[int] = []
+            if ids:
+                rows += [self._pk_to_row[i] for i in ids if i in self._pk_to_row]
+            cond = dict(filter or {})
+            if expr:
+                m = self._EXPR.match(expr)
+                if not m:
+                    raise ValueError(f"unsupported delete expression: {expr!r}")
+                cond[m.group(1)] = m.group(3)
+            if cond:
+                for r, md in enumerate(self._metas):
+                    if self._alive[r] and all(
+                            (self._pks[r] if k == "pk" else md.get(k)) == v for k, v in cond.items()):
+                        rows.append(r)
+            rows = sorted({r for r in rows if self._alive[r]})
+            if rows and self._index is not None:
+                self._index.remove_rows(rows)
+            for r in rows:
+                self._alive[r] = False
+        return _DeleteResult(len(rows))
+
+    # ---- search ---------------------------------------------------------------------------------------------
+    def _search_vecs(self, qvecs: np.ndarray, k: int):
+        if self._index is None or len(self._index) == 0:
+            return np.full((qvecs.shape[0], 0), -np.inf, np.float32), np.full((qvecs.shape[0], 0), -1, np.int64)
+        kk = max(1, min(int(k), N.MAX_K))
+        return self._index.search(qvecs, kk)
+
+    def similarity_search_with_score_by_vector(self, embedding, k: int = 4, **kw) -> list[tuple[Document, float]]:
+        s, r = self._search_vecs(np.asarray(embedding, dtype=np.float32)[None], k)
+        return [(self._doc(int(row)), self._convert(float(sc))) for sc, row in zip(s[0], r[0]) if row >= 0]
+
+    def similarity_search_with_score(self, query: str, k: int = 4, **kw) -> list[tuple[Document, float]]:
+        return self.similarity_search_with_score_by_vector(self._embed_query(query), k, **kw)
+
+    def similarity_search(self, query: str, k: int = 4, **kw) -> list[Document]:
+        return [d for d, _ in self.similarity_search_with_score(query, k, **kw)]
+
+    def similarity_search_with_relevance_scores(self, query: str, k: int = 4, **kw) -> list[tuple[Document, float]]:
+        s, r = self._search_vecs(self._embed_query(query)[None], k)
+        return [(self._doc(int(row)), float(sc)) for sc, row in zip(s[0], r[0]) if row >= 0]
+
+    def similarity_search_with_score_batch(self, queries: list[str], k: int = 4) -> list[list[tuple[Document, float]]]:
+        qv = self._embed_docs(list(queries))
+        s, r = self._search_vecs(qv, k)
+        return [[(self._doc(int(row)), self._convert(float(sc))) for sc, row in zip(ss, rr) if row >= 0]
+                for ss, rr in zip(s, r)]
+
+    def max_marginal_relevance_search_by_vector(self, embedding, k: int = 4, fetch_k: int = 20,
+                                                lambda_mult: float = 0.5, **kw) -> list[Document]:
+        q = np.asarray(embedding, dtype=np.float32)
+        s, r = self._search_vecs(q[None], fetch_k)
+        rows = [int(x) for x in r[0] if x >= 0]
+        if not rows:
+            return []
+        cand = self._index.get_rows(rows)      # the `pk in [...]` vector re-fetch of the replaced store
+        picked = maximal_marginal_relevance(q, cand, k=k, lambda_mult=lambda_mult)
+        return [self._doc(rows[i]) for i in picked]
+
+    def max_marginal_relevance_search(self, query: str, k: int = 4, fetch_k: int = 20, lambda_mult: float = 0.5,
+                                      **kw) -> list[Document]:
+        return self.max_marginal_relevance_search_by_vector(self._embed_query(query), k, fetch_k, lambda_mult)
+
+    def max_marginal_relevance_search_batch(self, queries: list[str], k: int = 4, fetch_k: int = 20,
+                                            lambda_mult: float = 0.5, **kw) -> list[list[Document]]:
+        qv = self._embed_docs(list(queries))
+        s, r = self._search_vecs(qv, fetch_k)
+        out = []
+        for qi in range(qv.shape[0]):
+            rows = [int(x) for x in r[qi] if x >= 0]
+            if not rows:
+                out.append([])
+                continue
+            cand = self._index.get_rows(rows)
+            out.append([self._doc(rows[i]) for i in maximal_marginal_relevance(qv[qi], cand, k, lambda_mult)])
+        return out
+
+    def as_retriever(self, search_type: str = "similarity", search_kwargs: dict | None = None, **kw) -> MI355XRetriever:
+        return MI355XRetriever(self, search_type=search_type, search_kwargs=search_kwargs)
+
+
+class _DeleteResult(int):
+    """int subclass carrying ``delete_count`` (pymilvus MutationResult field read at server.py:385)."""
+
+    def __new__(cls, n: int):
+        obj = super().__new__(cls, n)
+        obj.delete_count = n
+        return obj

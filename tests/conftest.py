@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def librmu():
+    """Builds (if stale) and loads librmu.so -- hipcc cross-compiles without a GPU."""
+    from ragmeup_amd import build as b
+    b.build()
+    from ragmeup_amd import _native
+    return _native.lib()

@@ -1,0 +1,183 @@
+"""CPU: host-side mirror of the reference's plug-in surface (no GPU: the index is an oracle-backed fake
+injected through MI355XVectorStore._index_factory; the product path always builds the HIP index)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from ragmeup_amd.documents import Document
+from ragmeup_amd.reranker import ScoredCrossEncoderReranker
+from ragmeup_amd.vectorstore import MI355XVectorStore, maximal_marginal_relevance
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class FakeIndex:
+    """Same interface as ragmeup_amd.index.FlatIndex, computed by the oracle."""
+
+    def __init__(self, dim):
+        self.dim, self.x, self.alive = dim, np.zeros((0, dim), np.float32), np.zeros(0, bool)
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def add(self, v):
+        first = self.x.shape[0]
+        self.x = np.concatenate([self.x, np.asarray(v, np.float32)])
+        self.alive = np.concatenate([self.alive, np.ones(len(v), bool)])
+        return first
+
+    def remove_rows(self, rows):
+        n = int(self.alive[list(rows)].sum()); self.alive[list(rows)] = False; return n
+
+    def get_rows(self, rows):
+        return self.x[list(rows)]
+
+    def search(self, q, k, row_base=0):
+        s, r = O.flat_search(np.asarray(q, np.float32).reshape(-1, self.dim), self.x, k, alive=self.alive)
+        return s.astype(np.float32), r
+
+
+class HashEmbeddings:
+    """Deterministic unit-norm embeddings from text (stands in for the encoder in host-logic tests)."""
+
+    def embed_documents(self, texts):
+        out = []
+        for t in texts:
+            seed = int(hashlib.md5(t.replace("\n", " ").encode()).hexdigest()[:8], 16)
+            v = np.random.default_rng(seed).standard_normal(384)
+            out.append((v / np.linalg.norm(v)).tolist())
+        return out
+
+    def embed_query(self, t):
+        return self.embed_documents([t])[0]
+
+
+@pytest.fixture()
+def store():
+    MI355XVectorStore._index_factory = FakeIndex
+    MI355XVectorStore._collections.clear()
+    yield MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=True,
+                                           connection_args={"uri": "data.db"}, collection_name="ragmeup_documents")
+    MI355XVectorStore._index_factory = None
+
+
+def _chunks(n, source="a.pdf"):
+    docs = []
+    for i in range(n):
+        text = f"chunk number {i} of {source}"
+        docs.append(Document(page_content=text, metadata={"source": source, "id": hashlib.md5(text.encode()).hexdigest()}))
+    return docs
+
+
+def test_reranker_matches_reference_golden():
+    g = json.load(open(os.path.join(HERE, "golden", "rerank_golden.json")))
+    for case in g["cases"]:
+        class M:
+            def score(self, pairs, _s=case["scores"]):
+                assert all(p[0] == "the query" for p in pairs)
+                return list(_s)
+        docs = [Document(f"passage {i}", {"source": f"f{i % 3}.pdf", "id": f"id{i}", "pk": f"id{i}"})
+                for i in range(len(case["scores"]))]
+        kw = {} if case["top_n"] is None else {"top_n": case["top_n"]}
+        out = ScoredCrossEncoderReranker(model=M(), **kw).compress_documents(docs, "the query")
+        assert [{"page_content": d.page_content, "metadata": d.metadata} for d in out] == case["result"], case["name"]
+        assert all("relevance_score" not in d.metadata for d in docs)        # inputs are copied, not mutated
+
+
+def test_reranker_config_semantics():
+    class M:
+        def score(self, p): return [0.0] * len(p)
+    assert ScoredCrossEncoderReranker(model=M()).top_n == 3                    # reference default
+    with pytest.raises(TypeError):
+        ScoredCrossEncoderReranker(model=M(), bogus=1)                          # extra = "forbid"
+    with pytest.raises(TypeError):
+        ScoredCrossEncoderReranker(model=object())
+
+
+def test_mmr_matches_oracle():
+    rng = np.random.default_rng(5)
+    for _ in range(25):
+        c = rng.standard_normal((20, 384)).astype(np.float32)
+        c[7] = c[3]                                         # exact duplicate -> tie handling
+        q = rng.standard_normal(384).astype(np.float32)
+        for lam in (0.0, 0.5, 1.0):
+            assert maximal_marginal_relevance(q, c, 10, lam) == O.mmr(q, c, 10, lam)
+    assert maximal_marginal_relevance(q, c[:0], 4) == []
+
+
+def test_indexing_loop_as_reference(store):
+    """RAGHelper.py:423-434: batches of 1000, ids = md5 of the chunk text."""
+    docs = _chunks(2500)
+    for i in range(0, len(docs), 1000):
+        batch = docs[i:i + 1000]
+        ids = store.add_documents(batch, ids=[d.metadata["id"] for d in batch])
+        assert ids == [d.metadata["id"] for d in batch]
+    assert len(store) == 2500
+    hit = store.similarity_search("chunk number 1234 of a.pdf", k=1)[0]
+    assert hit.page_content == "chunk number 1234 of a.pdf"
+    assert set(hit.metadata) >= {"source", "id", "pk"} and hit.metadata["pk"] == hit.metadata["id"]   # server.py:279-281
+
+
+def test_retriever_mmr_and_composition(store):
+    store.add_documents(_chunks(300), ids=[d.metadata["id"] for d in _chunks(300)])
+    r = store.as_retriever(search_type="mmr", search_kwargs={"k": 10})           # RAGHelper.py:497-499
+    docs = r.invoke("chunk number 17 of a.pdf")
+    assert len(docs) == 10 and docs[0].page_content == "chunk number 17 of a.pdf"
+    # same as the oracle pipeline: top-20 by IP -> MMR(k=10, lambda 0.5)
+    emb = HashEmbeddings()
+    q = np.asarray(emb.embed_query("chunk number 17 of a.pdf"), np.float32)
+    x = np.asarray(emb.embed_documents([d.page_content for d in _chunks(300)]), np.float32)
+    _, rows = O.flat_search(q[None], x, 20)
+    want = [int(rows[0][i]) for i in O.mmr(q, x[rows[0]], 10, 0.5)]
+    assert [d.page_content for d in docs] == [f"chunk number {i} of a.pdf" for i in want]
+    chain = r | (lambda ds: "|".join(d.metadata["pk"] for d in ds))              # RAGHelper_local.py:158
+    assert chain.invoke("chunk number 17 of a.pdf").count("|") == 9
+    with pytest.raises(ValueError):
+        store.as_retriever(search_type="bogus")
+
+
+def test_scores_as_replaced_stores(store):
+    store.add_documents(_chunks(50), ids=[d.metadata["id"] for d in _chunks(50)])
+    (d, l2), = store.similarity_search_with_score("chunk number 3 of a.pdf", k=1)
+    assert abs(l2) < 1e-5                                     # Milvus "L2": 2 - 2*ip = 0 for the identical text
+    store.score_mode = "cosine_distance"
+    assert abs(store.similarity_search_with_score("chunk number 3 of a.pdf", k=1)[0][1]) < 1e-5
+    store.score_mode = "ip"
+    assert abs(store.similarity_search_with_score("chunk number 3 of a.pdf", k=1)[0][1] - 1.0) < 1e-5
+
+
+def test_delete_by_source_expression_and_upsert(store):
+    store.add_documents(_chunks(40, "a.pdf"), ids=[d.metadata["id"] for d in _chunks(40, "a.pdf")])
+    store.add_documents(_chunks(30, "b.pdf"), ids=[d.metadata["id"] for d in _chunks(30, "b.pdf")])
+    res = store.delete(expr='source == "a.pdf"')              # server.py:373-377
+    assert res.delete_count == 40 and len(store) == 30
+    assert all(d.metadata["source"] == "b.pdf" for d in store.similarity_search("chunk number 3 of a.pdf", k=5))
+    assert store.delete(expr='source == "a.pdf"').delete_count == 0
+    # re-adding an existing pk replaces it (upsert), it does not duplicate
+    again = _chunks(30, "b.pdf")[:5]
+    store.add_documents(again, ids=[d.metadata["id"] for d in again])
+    assert len(store) == 30
+    with pytest.raises(ValueError):
+        store.delete(expr="source LIKE 'x'")
+
+
+def test_from_documents_reattaches_unless_drop_old():
+    MI355XVectorStore._index_factory = FakeIndex
+    try:
+        MI355XVectorStore._collections.clear()
+        a = MI355XVectorStore.from_documents(_chunks(5), HashEmbeddings(), drop_old=True,
+                                             connection_args={"uri": "u"}, collection_name="c")
+        b = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False,
+                                             connection_args={"uri": "u"}, collection_name="c")
+        assert a is b and len(b) == 5                         # vector_store_initial_load=True path (RAGHelper.py:391)
+        c = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=True,
+                                             connection_args={"uri": "u"}, collection_name="c")
+        assert c is not a and len(c) == 0
+        pg = MI355XVectorStore(embeddings=HashEmbeddings(), collection_name="c", connection="postgres://x", use_jsonb=True)
+        assert pg.connection == "postgres://x"                # PGVector-style ctor (RAGHelper.py:399-404)
+    finally:
+        MI355XVectorStore._index_factory = None

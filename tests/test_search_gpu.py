@@ -1,0 +1,274 @@
+"""GPU parity tests of the dense search path, through the C-ABI (librmu.so), against the CPU oracle.
+
+Bar (north_star): identical top-k row ids (bit-exact integer result; a swap is tolerated only between
+entries whose fp64 oracle scores differ by < 1e-6), scores within 1e-4.
+At BASELINE.json's full sizes the oracle cannot run in seconds, so size-independent properties are checked.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import assert_topk_parity
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def rmu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import ragmeup_amd
+    from ragmeup_amd import _native
+    _native.lib()                       # fails loudly if librmu.so is missing: there is no fallback
+    return ragmeup_amd
+
+
+@pytest.fixture(scope="module")
+def corpus50k():
+    x = O.make_corpus(50_000)
+    q, planted = O.make_queries(x, 256)
+    return x, q, planted
+
+
+# geometry coverage: WQ=1 (nq<=32), WQ=2 (<=64), WQ=4; k classes <=32 and <=112; ragged last tiles
+@pytest.mark.parametrize("nq,k", [(1, 10), (7, 10), (32, 20), (33, 10), (64, 32), (65, 10), (200, 10),
+                                  (256, 1), (130, 100), (40, 112), (5, 33)])
+def test_parity_vs_oracle(rmu, corpus50k, nq, k):
+    x, q, planted = corpus50k
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    s, r = idx.search(q[:nq], k)
+    os_, or_ = O.flat_search(q[:nq], x, k)
+    assert_topk_parity(s, r, os_, or_)
+    assert (r[:, 0] == planted[:nq]).all()
+    assert (np.diff(s, axis=1) <= 0).all()                       # best first
+    idx.close()
+
+
+@pytest.mark.parametrize("n", [1, 7, 31, 32, 33, 127, 128, 129, 4097])
+def test_tiny_and_ragged_corpora(rmu, n):
+    x = O.make_corpus(n)
+    q, _ = O.make_queries(x, 5)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    for k in (1, 10, 40):
+        s, r = idx.search(q, k)
+        os_, or_ = O.flat_search(q, x, k)
+        assert_topk_parity(s, r, os_, or_)
+        if n < k:                                                # fewer live rows than k: (-inf, -1) padding
+            assert (r[:, n:] == -1).all() and np.isneginf(s[:, n:]).all()
+    idx.close()
+
+
+def test_empty_index(rmu):
+    idx = rmu.FlatIndex(384)
+    s, r = idx.search(np.ones((3, 384), np.float32), 10)
+    assert (r == -1).all() and np.isneginf(s).all()
+    idx.close()
+
+
+def test_committed_golden_fixture(rmu):
+    g = np.load(os.path.join(HERE, "golden", "search_golden.npz"))
+    x = O.make_corpus(int(g["n"]), int(g["d"]), int(g["seed_x"]))
+    q, _ = O.make_queries(x, int(g["nq"]), int(g["seed_q"]))
+    idx = rmu.FlatIndex(int(g["d"]))
+    idx.add(x)
+    s, r = idx.search(q, int(g["k"]))
+    assert_topk_parity(s, r, g["scores"], g["rows"])
+    idx.close()
+
+
+def test_duplicates_resolve_to_lower_row(rmu):
+    x = O.make_corpus(3000)
+    xd = np.concatenate([x, x[100:110], x[100:110]])            # each of rows 100..109 exists three times
+    idx = rmu.FlatIndex(384)
+    idx.add(xd)
+    s, r = idx.search(x[100:110], 3)
+    for i in range(10):
+        assert list(r[i]) == [100 + i, 3000 + i, 3010 + i]       # exact ties: ascending row id
+    os_, or_ = O.flat_search(x[100:110], xd, 3)
+    assert np.array_equal(r, or_)
+    idx.close()
+
+
+def test_incremental_add_growth_and_row_ids(rmu):
+    x = O.make_corpus(30_000)
+    q, _ = O.make_queries(x, 16)
+    idx = rmu.FlatIndex(384, capacity_hint=16)                   # forces several reallocations
+    firsts = [idx.add(x[lo:lo + 1000]) for lo in range(0, 30_000, 1000)]   # RAGHelper._batch_size = 1000
+    assert firsts == list(range(0, 30_000, 1000)) and len(idx) == 30_000
+    s, r = idx.search(q, 10)
+    assert_topk_parity(s, r, *O.flat_search(q, x, 10))
+    got = idx.get_rows([0, 999, 1000, 29_999])
+    assert np.array_equal(got, x[[0, 999, 1000, 29_999]])       # MMR re-fetch is bit-exact
+    idx.close()
+
+
+def test_tombstones(rmu):
+    x = O.make_corpus(20_000)
+    q, planted = O.make_queries(x, 64)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    dead = np.unique(np.concatenate([planted[:32], np.arange(5000, 5100)]))
+    assert idx.remove_rows(dead) == dead.size
+    assert idx.remove_rows(dead[:5]) == 0                        # already gone
+    alive = np.ones(20_000, bool); alive[dead] = False
+    s, r = idx.search(q, 10)
+    assert_topk_parity(s, r, *O.flat_search(q, x, 10, alive=alive))
+    assert not np.isin(r, dead).any()
+    idx.close()
+
+
+@pytest.mark.parametrize("d", [64, 192, 256, 384, 512, 768])
+def test_other_dimensions(rmu, d):
+    x = O.make_corpus(6000, d, seed=5)
+    q, _ = O.make_queries(x, 40, seed=6)
+    idx = rmu.FlatIndex(d)
+    idx.add(x)
+    s, r = idx.search(q, 10)
+    assert_topk_parity(s, r, *O.flat_search(q, x, 10))
+    assert np.array_equal(idx.get_rows([17]), x[[17]])
+    idx.close()
+
+
+def test_cosine_metric_on_unnormalised_rows(rmu):
+    from ragmeup_amd import _native as N
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((8000, 384)) * rng.uniform(0.2, 5.0, (8000, 1))).astype(np.float32)
+    q = (rng.standard_normal((20, 384)) * 3.0).astype(np.float32)
+    idx = rmu.FlatIndex(384, metric=N.METRIC_COSINE)
+    idx.add(x)
+    s, r = idx.search(q, 10)
+    assert_topk_parity(s, r, *O.flat_search(q, x, 10, O.METRIC_COSINE))
+    idx.close()
+
+
+def test_device_pointers_and_row_base(rmu, corpus50k):
+    import torch
+    x, q, _ = corpus50k
+    idx = rmu.FlatIndex(384)
+    idx.add(torch.from_numpy(x).cuda())                          # device -> device append
+    s, r = idx.search(torch.from_numpy(q[:100]).cuda(), 10, row_base=1_000_000)
+    assert s.is_cuda and r.dtype == torch.int64
+    os_, or_ = O.flat_search(q[:100], x, 10)
+    assert_topk_parity(s.cpu().numpy(), r.cpu().numpy(), os_, or_ + 1_000_000)
+    idx.close()
+
+
+def test_topk_merge_abi(rmu):
+    x = O.make_corpus(12_000)
+    q, _ = O.make_queries(x, 70)
+    ps, pr = [], []
+    for lo in range(0, 12_000, 1500):                            # 8 shards, as on an 8-GPU node
+        s, r = O.flat_search(q, x[lo:lo + 1500], 10)
+        ps.append(s.astype(np.float32)); pr.append(r + lo)
+    ms, mr = rmu.topk_merge(np.stack(ps), np.stack(pr))
+    gs, gr = O.flat_search(q, x, 10)
+    assert_topk_parity(ms, mr, gs, gr)
+    # short lists (-1 padded) and k > 64
+    s, r = O.flat_search(q[:3], x[:5], 100)
+    ms, mr = rmu.topk_merge(np.stack([s.astype(np.float32)] * 2), np.stack([r, np.where(r >= 0, r + 5, -1)]))
+    assert (mr[:, 10:] == -1).all() and (np.sort(mr[:, :10], axis=1) == np.arange(10)).all()
+
+
+def test_emulated_shards_equal_global(rmu, corpus50k):
+    """8 row shards on one GPU + rmu_topk_merge == one global search (the N>1 data path minus the all-gather)."""
+    from ragmeup_amd.shard import shard_bounds
+    x, q, _ = corpus50k
+    parts_s, parts_r = [], []
+    for rank in range(8):
+        lo, hi = shard_bounds(x.shape[0], 8, rank)
+        idx = rmu.FlatIndex(384)
+        idx.add(x[lo:hi])
+        s, r = idx.search(q, 10, row_base=lo)
+        parts_s.append(s); parts_r.append(r)
+        idx.close()
+    ms, mr = rmu.topk_merge(np.stack(parts_s), np.stack(parts_r))
+    assert_topk_parity(ms, mr, *O.flat_search(q, x, 10))
+
+
+def test_concurrent_searches_and_writer(rmu, corpus50k):
+    """Flask's threaded server + LCEL RunnableParallel call search from several threads while /add_document
+    may append: searches are re-entrant, add takes the writer lock."""
+    x, q, _ = corpus50k
+    idx = rmu.FlatIndex(384)
+    idx.add(x[:40_000])
+    want_s, want_r = O.flat_search(q[:48], x[:40_000], 10)
+    errs = []
+
+    def reader(i):
+        try:
+            for _ in range(5):
+                s, r = idx.search(q[i * 8:(i + 1) * 8], 10)
+                # rows >= 40000 may legitimately appear once the writer has appended them
+                m = r < 40_000
+                if m.all():
+                    assert_topk_parity(s, r, want_s[i * 8:(i + 1) * 8], want_r[i * 8:(i + 1) * 8])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def writer():
+        try:
+            idx.add(x[40_000:])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=reader, args=(i,)) for i in range(6)] + [threading.Thread(target=writer)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    s, r = idx.search(q[:48], 10)
+    assert_topk_parity(s, r, *O.flat_search(q[:48], x, 10))
+    idx.close()
+
+
+def test_invalid_requests_raise(rmu):
+    from ragmeup_amd._native import RmuError
+    idx = rmu.FlatIndex(384)
+    idx.add(O.make_corpus(100))
+    with pytest.raises(RmuError):
+        idx.search(np.ones((1, 384), np.float32), 0)
+    with pytest.raises(RmuError):
+        idx.search(np.ones((1, 384), np.float32), 113)
+    with pytest.raises(ValueError):
+        idx.search(np.ones((1, 100), np.float32), 10)
+    with pytest.raises(RmuError):
+        idx.get_rows([100])
+    with pytest.raises(RmuError):
+        rmu.FlatIndex(4096)
+    idx.close()
+
+
+def test_full_size_properties_1m(rmu):
+    """BASELINE config 2 (1M x 384, B=1024, top-10): properties that need no O(N*B) oracle pass, plus an
+    oracle check of a 32-query subset."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn((1_000_000, 384), generator=g, device="cuda")
+    x /= x.norm(dim=1, keepdim=True)
+    pick = torch.randperm(1_000_000, generator=g, device="cuda")[:1024]
+    q = x[pick] + 0.1 * torch.randn((1024, 384), generator=g, device="cuda")
+    q /= q.norm(dim=1, keepdim=True)
+    idx = rmu.FlatIndex(384, capacity_hint=1_000_000)
+    idx.add(x)
+    s, r = idx.search(q, 10)
+    assert (r[:, 0] == pick).all()                                         # planted neighbour found
+    assert (s[:, :-1] >= s[:, 1:]).all()                                   # sorted
+    assert (r.sort(dim=1).values.diff(dim=1) > 0).all()                    # ids unique per query
+    # re-score the returned ids independently (fp64 gather-dot) and check nothing better was missed:
+    rescored = torch.einsum("qkd,qd->qk", x[r].double(), q.double())
+    assert (rescored - s.double()).abs().max() < 1e-4
+    full = (q[:64].double() @ x.double().T)                                # 64 x 1M fp64 on the device (checker only)
+    kth = torch.topk(full, 10, dim=1).values[:, -1]
+    assert (s[:64, -1].double() - kth).abs().max() < 1e-6
+    # oracle parity on a subset
+    xs = x.cpu().numpy(); qs = q[:32].cpu().numpy()
+    assert_topk_parity(s[:32].cpu().numpy(), r[:32].cpu().numpy(), *O.flat_search(qs, xs, 10))
+    # idempotence
+    s2, r2 = idx.search(q, 10)
+    assert torch.equal(r, r2) and torch.equal(s, s2)
+    idx.close()
