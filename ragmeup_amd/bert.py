@@ -1,0 +1,138 @@
+"""BertEncoder -- Python handle on the hand-written BERT-6x384 forward in librmu.so (rmu_bert_*).
+
+Serves the two transformer forwards on the reference's hot path:
+  * sentence-transformers bi-encoder: BertModel -> masked mean pool -> L2 normalise   (mode 0)
+  * CrossEncoder: BertForSequenceClassification(num_labels=1) logit                    (mode 1)
+PyTorch is used only to hold the weight / id tensors on the device; every FLOP runs in our kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Mapping
+
+import numpy as np
+
+from . import _native as N
+
+
+class BertCfg(ctypes.Structure):
+    _fields_ = [("vocab_size", ctypes.c_int), ("hidden", ctypes.c_int), ("layers", ctypes.c_int),
+                ("heads", ctypes.c_int), ("ffn", ctypes.c_int), ("max_pos", ctypes.c_int),
+                ("type_vocab", ctypes.c_int), ("ln_eps", ctypes.c_float), ("has_head", ctypes.c_int)]
+
+
+def weight_order(layers: int, has_head: bool) -> list[str]:
+    """Order of the fp32 tensors rmu_bert_create expects (HF parameter names, 'bert.' prefix stripped)."""
+    names = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight",
+             "embeddings.token_type_embeddings.weight", "embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+    for l in range(layers):
+        p = f"encoder.layer.{l}."
+        names += [p + "attention.self.query.weight", p + "attention.self.query.bias",
+                  p + "attention.self.key.weight", p + "attention.self.key.bias",
+                  p + "attention.self.value.weight", p + "attention.self.value.bias",
+                  p + "attention.output.dense.weight", p + "attention.output.dense.bias",
+                  p + "attention.output.LayerNorm.weight", p + "attention.output.LayerNorm.bias",
+                  p + "intermediate.dense.weight", p + "intermediate.dense.bias",
+                  p + "output.dense.weight", p + "output.dense.bias",
+                  p + "output.LayerNorm.weight", p + "output.LayerNorm.bias"]
+    if has_head:
+        names += ["pooler.dense.weight", "pooler.dense.bias", "classifier.weight", "classifier.bias"]
+    return names
+
+
+def _strip(state: Mapping) -> dict:
+    out = {}
+    for k, v in state.items():
+        for pre in ("bert.", "0.auto_model.", "auto_model.", "model."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        out[k] = v
+    return out
+
+
+class BertEncoder:
+    """weights: mapping HF-name -> array/tensor (fp32).  Use `from_pretrained_dir` for a checkpoint directory."""
+
+    HIDDEN = 384
+
+    def __init__(self, weights: Mapping, layers: int = 6, heads: int = 12, ffn: int = 1536, ln_eps: float = 1e-12,
+                 has_head: bool | None = None, device: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("BertEncoder needs an MI355X: the encoder has no CPU fallback")
+        self._torch = torch
+        self.device = torch.device("cuda", device)
+        self._lib = N.lib()
+        N.check(self._lib.rmu_init(device), "rmu_init")
+        w = _strip(weights)
+        if has_head is None:
+            has_head = "classifier.weight" in w
+        self.has_head = bool(has_head)
+        names = weight_order(layers, self.has_head)
+        missing = [n for n in names if n not in w]
+        if missing:
+            raise KeyError(f"checkpoint lacks {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        tens = [torch.as_tensor(np.asarray(w[n], dtype=np.float32) if not torch.is_tensor(w[n]) else w[n])
+                .to(self.device, torch.float32).contiguous() for n in names]
+        hid = tens[0].shape[1]
+        cfg = BertCfg(int(tens[0].shape[0]), int(hid), int(layers), int(heads), int(ffn), int(tens[1].shape[0]),
+                      int(tens[2].shape[0]), float(ln_eps), int(self.has_head))
+        ptrs = (ctypes.c_void_p * len(tens))(*[t.data_ptr() for t in tens])
+        torch.cuda.synchronize(self.device)
+        h = ctypes.c_void_p()
+        N.check(self._lib.rmu_bert_create(ctypes.byref(h), ctypes.byref(cfg), ptrs, len(tens)), "rmu_bert_create")
+        self._h = h
+        self.max_pos = int(tens[1].shape[0])
+        self.vocab_size = int(tens[0].shape[0])
+        del tens                                   # the library keeps its own (bf16 / fp32) copies
+
+    @classmethod
+    def from_transformers(cls, model, device: int = 0) -> "BertEncoder":
+        c = model.config
+        return cls(model.state_dict(), layers=c.num_hidden_layers, heads=c.num_attention_heads,
+                   ffn=c.intermediate_size, ln_eps=c.layer_norm_eps, device=device)
+
+    @classmethod
+    def from_pretrained_dir(cls, path: str, device: int = 0) -> "BertEncoder":
+        """HF checkpoint directory (config.json + model.safetensors | pytorch_model.bin)."""
+        import json
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.numpy import load_file
+            state = load_file(st)
+        else:
+            import torch
+            state = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        return cls(state, layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"],
+                   ffn=cfg["intermediate_size"], ln_eps=cfg.get("layer_norm_eps", 1e-12), device=device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rmu_bert_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- forward ------------------------------------------------------------------------------------------
+    def encode_ids(self, ids, lens, type_ids=None, mode: int = 0, out=None):
+        """ids [B, L] int (numpy or torch, padded), lens [B].  mode 0 -> [B, 384] unit-norm fp32 (torch CUDA);
+        mode 1 -> [B] fp32 logits.  `out` may be a pre-allocated CUDA tensor (e.g. a slice of a corpus matrix)."""
+        torch = self._torch
+        ids_t = torch.as_tensor(ids).to(self.device, torch.int32).contiguous()
+        lens_t = torch.as_tensor(lens).to(self.device, torch.int32).contiguous()
+        tt_t = None if type_ids is None else torch.as_tensor(type_ids).to(self.device, torch.int32).contiguous()
+        B, L = ids_t.shape
+        if out is None:
+            out = torch.empty((B, self.HIDDEN) if mode == 0 else (B,), dtype=torch.float32, device=self.device)
+        stride = out.stride(0) if mode == 0 else 1
+        torch.cuda.current_stream(self.device).synchronize()
+        N.check(self._lib.rmu_bert_encode(self._h, ids_t.data_ptr(), tt_t.data_ptr() if tt_t is not None else None,
+                                          lens_t.data_ptr(), int(B), int(L), int(mode), out.data_ptr(), int(stride), 0),
+                "rmu_bert_encode")
+        return out

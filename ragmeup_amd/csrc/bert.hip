@@ -1,0 +1,621 @@
+// bert.hip -- BERT-6x384 encoder forward (bi-encoder pooling / cross-encoder head) for gfx950 (MI355X only).
+//
+// Replaces the transformer forwards the reference reaches through
+//   HuggingFaceEmbeddings.embed_documents / embed_query   (server/RAGHelper_local.py:107-117, called from the
+//       indexing loop server/RAGHelper.py:423-434 and every retriever query, :497-499)          SURVEY 8(a2,a3)
+//   HuggingFaceCrossEncoder.score                          (server/RAGHelper.py:483-486 ->
+//       server/ScoredCrossEncoderReranker.py:42)                                                 SURVEY 8(a7)
+// i.e. transformers' BertModel / BertForSequenceClassification (6 layers, hidden 384, 12 heads x 32, FFN 1536,
+// GELU(erf), LayerNorm eps 1e-12) + sentence-transformers pooling (masked mean, L2 normalise) or the
+// pooler-tanh + Linear(384,1) head.
+//
+// Layout: tokens are PACKED (no padding rows): sequence b owns rows [cu[b], cu[b+1]) of every [T, *] activation.
+// Activations are bf16 in HBM, every accumulation / LayerNorm / softmax is fp32.  GEMMs are
+// v_mfma_f32_16x16x32_bf16 on 128x128x64 tiles staged through LDS by LDS-DMA (global_load_lds_dwordx4) with the
+// XOR swizzle applied to the per-lane SOURCE address (the DMA writes lane-linear).  Operands are swapped
+// (D^T = W . A^T) so a lane ends up with 4 consecutive output features of one token: 8-byte bf16 stores.
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rmu_common.h"
+#include "../../include/rmu.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __bf16 bf16;
+
+namespace {
+
+constexpr int H = 384, NH = 12, DH = 32, FF = 1536;
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+
+// ------------------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_f32_to_bf16(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (bf16)(src[i] * scale);
+}
+__global__ void k_scale_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] * scale;
+}
+
+// cu[0] = 0, cu[b+1] = cu[b] + clamp(lens[b], 0, max_len); one block
+__global__ void k_cu_seqlens(const int* __restrict__ lens, int batch, int max_len, int* __restrict__ cu) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int per = (batch + nt - 1) / nt;
+    const int lo = tid * per, hi = min(batch, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += min(max(lens[i], 0), max_len);
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < nt; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        cu[0] = 0;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = lo; i < hi; ++i) { run += min(max(lens[i], 0), max_len); cu[i + 1] = run; }
+}
+
+// wave-wide LayerNorm of 384 values held 6 per lane
+__device__ __forceinline__ void ln_row(float (&v)[6], const float* __restrict__ g, const float* __restrict__ b, int c0,
+                                       float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const float d = v[i] - mu; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rs = rsqrtf(q * (1.0f / H) + eps);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = (v[i] - mu) * rs * g[c0 + i] + b[c0 + i];
+}
+
+// embeddings + LayerNorm: one wave per (sequence, position); packed output row cu[b] + pos
+__global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, const int* __restrict__ type_ids,
+                                                  const int* __restrict__ cu, int batch, int max_len,
+                                                  const float* __restrict__ wemb, const float* __restrict__ pemb,
+                                                  const float* __restrict__ temb, const float* __restrict__ g,
+                                                  const float* __restrict__ bta, float eps, int vocab, int type_vocab,
+                                                  bf16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= (int64_t)batch * max_len) return;
+    const int b = (int)(slot / max_len), pos = (int)(slot % max_len);
+    const int len = cu[b + 1] - cu[b];
+    if (pos >= len) return;
+    int id = ids[slot];
+    id = min(max(id, 0), vocab - 1);
+    int tt = type_ids ? type_ids[slot] : 0;
+    tt = min(max(tt, 0), type_vocab - 1);
+    const int c0 = lane * 6;
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        v[i] = wemb[(int64_t)id * H + c0 + i] + pemb[(int64_t)pos * H + c0 + i] + temb[(int64_t)tt * H + c0 + i];
+    ln_row(v, g, bta, c0, eps);
+    bf16* o = out + ((int64_t)cu[b] + pos) * H + c0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = (bf16)v[i];
+}
+
+// out = LayerNorm(y) (y already holds GEMM + bias + residual); one wave per token
+__global__ __launch_bounds__(256) void k_layernorm(const bf16* __restrict__ y, const int* __restrict__ cu, int batch,
+                                                   const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                   bf16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= cu[batch]) return;
+    const int c0 = lane * 6;
+    float v[6];
+    const bf16* r = y + t * H + c0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = bf2f(r[i]);
+    ln_row(v, g, bta, c0, eps);
+    bf16* o = out + t * H + c0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = (bf16)v[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GEMM: out[m, n] = epi( sum_k A[m, k] * W[n, k] + bias[n] )     A [M, K] bf16, W [N, K] bf16 (HF Linear layout)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+extern __shared__ __attribute__((aligned(16))) char gsm[];
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                              const float* __restrict__ bias, const bf16* __restrict__ resid,
+                                              bf16* __restrict__ out, const int* __restrict__ cu, int batch, int N, int K) {
+    const int M = cu[batch];                       // real token count (device side: no host sync)
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;             // wave -> 64 tokens x 64 features
+    char* As = gsm;                                // [2][128 rows][8 units of 16 B]   (tokens x k)
+    char* Ws = gsm + 2 * BM * BK * 2;              // [2][128 rows][8 units]           (features x k)
+
+    // DMA source map: LDS unit f = (it*4 + w)*64 + lane  ->  row f/8, physical unit f%8, logical unit p ^ (row&7)
+    int arow[4], wrow[4], ucol[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = (it * 4 + w) * 64 + lane;
+        const int row = f >> 3, p = f & 7;
+        ucol[it] = (p ^ (row & 7)) * 8;            // element offset inside the BK slab
+        arow[it] = min(m0 + row, M - 1);           // clamp: rows >= M are never stored
+        wrow[it] = n0 + row;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)arow[it] * K + k0 + ucol[it]),
+                                             (__attribute__((address_space(3))) void*)(As + buf * (BM * BK * 2) + (it * 4 + w) * 1024),
+                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (int64_t)wrow[it] * K + k0 + ucol[it]),
+                                             (__attribute__((address_space(3))) void*)(Ws + buf * (BN * BK * 2) + (it * 4 + w) * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];                               // [feature tile][token tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, kg = lane >> 4;
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                            // tile kt landed everywhere; everyone left buffer cur^1
+        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+        const char* as = As + cur * (BM * BK * 2);
+        const char* ws = Ws + cur * (BN * BK * 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + fr;
+                wf[i] = *(const bf16x8*)(ws + (row * 8 + ((ks * 4 + kg) ^ (row & 7))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 64 + j * 16 + fr;
+                af[j] = *(const bf16x8*)(as + (row * 8 + ((ks * 4 + kg) ^ (row & 7))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: lane holds features n..n+3 (rows of D^T) of token m (column of D^T)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + kg * 4;
+            const f32x4 bv = *(const f32x4*)(bias + n);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
+            if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            }
+            if (EPI == EPI_RESID) {
+                const bf16x4 rv = *(const bf16x4*)(resid + (int64_t)m * N + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+            *(bf16x4*)(out + (int64_t)m * N + n) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// attention: one workgroup = (sequence, head, 64 queries); K rows and V^T of the whole sequence in LDS; each wave
+// owns 16 queries and keeps its full score strip S^T[keys, 16] in registers (<= 32 key tiles), exact softmax.
+// ------------------------------------------------------------------------------------------------------------
+template <int MAXT>   // max key tiles of 16 (sequence length <= 16*MAXT)
+__global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv, const int* __restrict__ cu,
+                                                   bf16* __restrict__ ctx) {
+    constexpr int KSTR = 80;                       // bytes per K row in LDS (64 + 16 pad: conflict-free b128 reads)
+    constexpr int LP = MAXT * 16;
+    constexpr int VSTR = LP * 2 + 8;               // bytes per V^T row
+    char* ks = gsm;                                // [LP][KSTR]
+    char* vt = gsm + LP * KSTR;                    // [DH][VSTR]
+    const int b = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    if (qb * 64 >= L) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = (L + 15) >> 4;                  // key tiles in use
+    const int npair = (nt + 1) >> 1;               // 32-key blocks for P.V
+    const int rows_fill = npair * 32;              // rows touched by the MFMAs (<= LP)
+    const int64_t rs = 3 * H;                      // qkv row stride (elements)
+
+    // ---- K rows (16-B pieces) and V transposed into LDS; rows >= L are zero -------------------------------
+    for (int p = tid; p < rows_fill * 4; p += 256) {
+        const int r = p >> 2, u = p & 3;
+        uint4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (r < L) {
+            const bf16* base = qkv + (int64_t)(t0 + r) * rs + head * DH + u * 8;
+            kv = *(const uint4*)(base + H);
+            vv = *(const uint4*)(base + 2 * H);
+        }
+        *(uint4*)(ks + r * KSTR + u * 16) = kv;
+        const unsigned short* ve = (const unsigned short*)&vv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *(unsigned short*)(vt + (u * 8 + e) * VSTR + r * 2) = ve[e];
+    }
+    __syncthreads();
+
+    const int q0 = qb * 64 + w * 16;
+    if (q0 >= L) return;                           // no barriers below
+    const int fr = lane & 15, kg = lane >> 4;
+    // Q fragment (B operand): query q0+fr, dims 8*kg..  (1/sqrt(32) is folded into Wq at load time)
+    bf16x8 qf = {};
+    if (q0 + fr < L) qf = *(const bf16x8*)(qkv + (int64_t)(t0 + q0 + fr) * rs + head * DH + kg * 8);
+
+    // ---- S^T tiles: lane holds query fr, keys 16*kt + 4*kg + i ------------------------------------------------
+    f32x4 st[MAXT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < MAXT; ++kt) {
+        st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (kt < nt) {
+            const bf16x8 kf = *(const bf16x8*)(ks + (kt * 16 + fr) * KSTR + kg * 16);
+            f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (kt * 16 + kg * 4 + i >= L) s[i] = -INFINITY;
+                mx = fmaxf(mx, s[i]);
+            }
+            st[kt] = s;
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < MAXT; ++kt) {
+        if (kt < nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = __expf(st[kt][i] - mx);   // exp(-inf) = 0 for masked keys
+                st[kt][i] = p;
+                sum += p;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+
+    // ---- O = P . V : k-slot (kg, i, half) of block pb <-> key 32*pb + 16*half + 4*kg + i on BOTH operands ------
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int pb = 0; pb < MAXT / 2; ++pb) {
+        if (pb < npair) {
+            bf16x8 pf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pf[i] = (bf16)st[2 * pb][i];
+                pf[4 + i] = (2 * pb + 1 < nt) ? (bf16)st[2 * pb + 1][i] : (bf16)0.f;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const char* vrow = vt + (dt * 16 + fr) * VSTR + (32 * pb + 4 * kg) * 2;
+                const bf16x4 v0 = *(const bf16x4*)(vrow);
+                const bf16x4 v1 = *(const bf16x4*)(vrow + 32);
+                bf16x8 vf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { vf[i] = v0[i]; vf[4 + i] = v1[i]; }
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: row = query 4*kg + i, col = dim fr (+16*dt).  Row sums live in lanes whose fr == that query.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qi = kg * 4 + i;
+        const float den = __shfl(sum, qi);
+        if (q0 + qi < L) {
+            bf16* dst = ctx + (int64_t)(t0 + q0 + qi) * H + head * DH + fr;
+            dst[0] = (bf16)(o[0][i] / den);
+            dst[16] = (bf16)(o[1][i] / den);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pooling heads
+// ------------------------------------------------------------------------------------------------------------
+// sentence-transformers Pooling(mean) + Normalize: one wave per sequence
+__global__ __launch_bounds__(64) void k_meanpool_l2(const bf16* __restrict__ h, const int* __restrict__ cu,
+                                                    float* __restrict__ out, int64_t out_stride) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    const int c0 = lane * 6;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < L; ++t) {
+        const bf16* r = h + (int64_t)(t0 + t) * H + c0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] += bf2f(r[i]);
+    }
+    const float inv = 1.0f / fmaxf((float)L, 1e-9f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s[i] *= inv; q = fmaf(s[i], s[i], q); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rn = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+    float* dst = out + (int64_t)b * out_stride + c0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i] = s[i] * rn;
+}
+
+// BertForSequenceClassification(num_labels=1): logit = wc . tanh(Wp h_cls + bp) + bc ; one block per sequence
+__global__ __launch_bounds__(128) void k_cls_head(const bf16* __restrict__ h, const int* __restrict__ cu,
+                                                  const float* __restrict__ wp, const float* __restrict__ bp,
+                                                  const float* __restrict__ wc, const float* __restrict__ bc,
+                                                  float* __restrict__ out) {
+    __shared__ float hc[H];
+    __shared__ float red[128];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    for (int c = tid; c < H; c += 128) hc[c] = L > 0 ? bf2f(h[(int64_t)t0 * H + c]) : 0.f;
+    __syncthreads();
+    float part = 0.f;
+    for (int o = tid; o < H; o += 128) {
+        const float* wr = wp + (int64_t)o * H;
+        float a = bp[o];
+        for (int c = 0; c < H; ++c) a = fmaf(wr[c], hc[c], a);
+        part = fmaf(wc[o], tanhf(a), part);
+    }
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) out[b] = red[0] + bc[0];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// model object + C-ABI
+// ------------------------------------------------------------------------------------------------------------
+struct BertLayer {
+    bf16 *wqkv, *wo, *w1, *w2;
+    float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
+};
+struct rmu_bert {
+    rmu_bert_cfg cfg;
+    float *wemb = nullptr, *pemb = nullptr, *temb = nullptr, *elng = nullptr, *elnb = nullptr;
+    std::vector<BertLayer> layers;
+    float *wp = nullptr, *bp = nullptr, *wc = nullptr, *bc = nullptr;
+    std::vector<void*> owned;
+    // workspace (guarded: one encode at a time per model)
+    std::mutex mu;
+    int64_t ws_tokens = 0;
+    int ws_batch = 0;
+    bf16 *h = nullptr, *h1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr;
+    int* cu = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+extern "C" void rmu_set_error_(const char* msg);   // rmu_api.hip: thread-local message behind rmu_last_error()
+static int bfail(int code, const std::string& m) { rmu_set_error_(m.c_str()); return code; }
+
+#define B_TRY(expr)                                                                                      \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return bfail(e_ == hipErrorOutOfMemory ? RMU_E_OOM : RMU_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+static int dev_alloc(rmu_bert* m, T** p, size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) return RMU_E_OOM;
+    m->owned.push_back(q);
+    *p = (T*)q;
+    return RMU_OK;
+}
+
+static int copy_f32(rmu_bert* m, float** dst, const void* src, size_t n, float scale, hipStream_t s) {
+    if (dev_alloc(m, dst, n)) return RMU_E_OOM;
+    hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)src, *dst, (int64_t)n, scale);
+    return RMU_OK;
+}
+static int conv_bf16(bf16* dst, const void* src, size_t n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)src, dst, (int64_t)n, scale);
+    return RMU_OK;
+}
+
+extern "C" int rmu_bert_free(rmu_bert_t* m) {
+    if (!m) return RMU_OK;
+    (void)hipDeviceSynchronize();
+    for (void* p : m->owned) (void)hipFree(p);
+    for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->cu})
+        if (p) (void)hipFree(p);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return RMU_OK;
+}
+
+extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const void* const* wptr, int n_weights) {
+    if (!out || !cfg || !wptr) return bfail(RMU_E_INVALID, "rmu_bert_create: null argument");
+    if (cfg->hidden != H || cfg->heads != NH || cfg->ffn != FF || cfg->layers < 1 || cfg->layers > 48)
+        return bfail(RMU_E_INVALID, "rmu_bert_create: this build supports hidden 384, 12 heads, ffn 1536");
+    if (cfg->max_pos < 1 || cfg->max_pos > 512 || cfg->vocab_size < 1 || cfg->type_vocab < 1)
+        return bfail(RMU_E_INVALID, "rmu_bert_create: max_pos must be in [1, 512]");
+    const int need = 5 + 16 * cfg->layers + (cfg->has_head ? 4 : 0);
+    if (n_weights != need) return bfail(RMU_E_INVALID, "rmu_bert_create: wrong number of weight tensors");
+    for (int i = 0; i < need; ++i)
+        if (!wptr[i]) return bfail(RMU_E_INVALID, "rmu_bert_create: null weight pointer");
+    auto* m = new (std::nothrow) rmu_bert();
+    if (!m) return bfail(RMU_E_OOM, "rmu_bert_create: host alloc");
+    m->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return bfail(RMU_E_HIP, "stream"); }
+    hipStream_t s = m->stream;
+    int rc = RMU_OK;
+    int wi = 0;
+    rc |= copy_f32(m, &m->wemb, wptr[wi++], (size_t)cfg->vocab_size * H, 1.f, s);
+    rc |= copy_f32(m, &m->pemb, wptr[wi++], (size_t)cfg->max_pos * H, 1.f, s);
+    rc |= copy_f32(m, &m->temb, wptr[wi++], (size_t)cfg->type_vocab * H, 1.f, s);
+    rc |= copy_f32(m, &m->elng, wptr[wi++], H, 1.f, s);
+    rc |= copy_f32(m, &m->elnb, wptr[wi++], H, 1.f, s);
+    const float qs = 1.0f / sqrtf((float)DH);       // softmax scale folded into the query projection
+    m->layers.resize(cfg->layers);
+    for (int l = 0; l < cfg->layers && !rc; ++l) {
+        BertLayer& L = m->layers[l];
+        const void *qw = wptr[wi++], *qb = wptr[wi++], *kw = wptr[wi++], *kb = wptr[wi++], *vw = wptr[wi++], *vb = wptr[wi++];
+        rc |= dev_alloc(m, &L.wqkv, (size_t)3 * H * H);
+        rc |= dev_alloc(m, &L.bqkv, (size_t)3 * H);
+        if (rc) break;
+        conv_bf16(L.wqkv, qw, (size_t)H * H, qs, s);
+        conv_bf16(L.wqkv + H * H, kw, (size_t)H * H, 1.f, s);
+        conv_bf16(L.wqkv + 2 * H * H, vw, (size_t)H * H, 1.f, s);
+        hipLaunchKernelGGL(k_scale_copy, dim3(2), dim3(256), 0, s, (const float*)qb, L.bqkv, (int64_t)H, qs);
+        hipLaunchKernelGGL(k_scale_copy, dim3(2), dim3(256), 0, s, (const float*)kb, L.bqkv + H, (int64_t)H, 1.f);
+        hipLaunchKernelGGL(k_scale_copy, dim3(2), dim3(256), 0, s, (const float*)vb, L.bqkv + 2 * H, (int64_t)H, 1.f);
+        rc |= dev_alloc(m, &L.wo, (size_t)H * H);
+        if (!rc) conv_bf16(L.wo, wptr[wi], (size_t)H * H, 1.f, s);
+        wi++;
+        rc |= copy_f32(m, &L.bo, wptr[wi++], H, 1.f, s);
+        rc |= copy_f32(m, &L.ln1g, wptr[wi++], H, 1.f, s);
+        rc |= copy_f32(m, &L.ln1b, wptr[wi++], H, 1.f, s);
+        rc |= dev_alloc(m, &L.w1, (size_t)FF * H);
+        if (!rc) conv_bf16(L.w1, wptr[wi], (size_t)FF * H, 1.f, s);
+        wi++;
+        rc |= copy_f32(m, &L.b1, wptr[wi++], FF, 1.f, s);
+        rc |= dev_alloc(m, &L.w2, (size_t)H * FF);
+        if (!rc) conv_bf16(L.w2, wptr[wi], (size_t)H * FF, 1.f, s);
+        wi++;
+        rc |= copy_f32(m, &L.b2, wptr[wi++], H, 1.f, s);
+        rc |= copy_f32(m, &L.ln2g, wptr[wi++], H, 1.f, s);
+        rc |= copy_f32(m, &L.ln2b, wptr[wi++], H, 1.f, s);
+    }
+    if (!rc && cfg->has_head) {
+        rc |= copy_f32(m, &m->wp, wptr[wi++], (size_t)H * H, 1.f, s);
+        rc |= copy_f32(m, &m->bp, wptr[wi++], H, 1.f, s);
+        rc |= copy_f32(m, &m->wc, wptr[wi++], H, 1.f, s);
+        rc |= copy_f32(m, &m->bc, wptr[wi++], 1, 1.f, s);
+    }
+    if (rc || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+        rmu_bert_free(m);
+        return bfail(rc ? rc : RMU_E_HIP, "rmu_bert_create: weight upload failed");
+    }
+    *out = m;
+    return RMU_OK;
+}
+
+static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
+    if (tokens > m->ws_tokens) {
+        (void)hipDeviceSynchronize();
+        for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid})
+            if (p) (void)hipFree(p);
+        m->h = m->h1 = m->y = m->qkv = m->ctx = m->mid = nullptr;
+        m->ws_tokens = 0;
+        const int64_t t = tokens + tokens / 8 + 128;
+        if (hipMalloc((void**)&m->h, t * H * 2) != hipSuccess || hipMalloc((void**)&m->h1, t * H * 2) != hipSuccess ||
+            hipMalloc((void**)&m->y, t * H * 2) != hipSuccess || hipMalloc((void**)&m->qkv, t * 3 * H * 2) != hipSuccess ||
+            hipMalloc((void**)&m->ctx, t * H * 2) != hipSuccess || hipMalloc((void**)&m->mid, t * FF * 2) != hipSuccess)
+            return RMU_E_OOM;
+        m->ws_tokens = t;
+    }
+    if (batch + 1 > m->ws_batch) {
+        (void)hipDeviceSynchronize();
+        if (m->cu) (void)hipFree(m->cu);
+        m->cu = nullptr; m->ws_batch = 0;
+        const int nb = batch + batch / 8 + 64;
+        if (hipMalloc((void**)&m->cu, (size_t)nb * sizeof(int)) != hipSuccess) return RMU_E_OOM;
+        m->ws_batch = nb;
+    }
+    return RMU_OK;
+}
+
+template <int EPI>
+static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
+                        int batch, int64_t m_cap, int N, int K, hipStream_t s) {
+    static bool attr = false;
+    const int lds = 2 * (BM * BK * 2) + 2 * (BN * BK * 2);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    const dim3 grid((unsigned)(N / BN), (unsigned)((m_cap + BM - 1) / BM));
+    hipLaunchKernelGGL(k_gemm<EPI>, grid, dim3(256), lds, s, A, W, bias, resid, out, cu, batch, N, K);
+}
+
+template <int MAXT>
+static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
+    static bool attr = false;
+    const int lds = MAXT * 16 * 80 + DH * (MAXT * 16 * 2 + 8);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_attention<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL(k_attention<MAXT>, grid, dim3(256), lds, s, qkv, cu, ctx);
+}
+
+extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
+                               int max_len, int mode, float* out_dev, int64_t out_stride, uint64_t hip_stream) {
+    if (!m || !ids || !lens || !out_dev) return bfail(RMU_E_INVALID, "rmu_bert_encode: null argument");
+    if (batch < 1 || batch > 65535 || max_len < 1 || max_len > m->cfg.max_pos)
+        return bfail(RMU_E_INVALID, "rmu_bert_encode: 1 <= batch <= 65535, 1 <= max_len <= max_pos");
+    if (mode != 0 && mode != 1) return bfail(RMU_E_INVALID, "rmu_bert_encode: mode must be 0 or 1");
+    if (mode == 1 && !m->cfg.has_head) return bfail(RMU_E_INVALID, "rmu_bert_encode: model has no classification head");
+    if (mode == 0 && out_stride < H) return bfail(RMU_E_INVALID, "rmu_bert_encode: out_stride < hidden");
+    std::lock_guard<std::mutex> lk(m->mu);
+    const int64_t cap = (int64_t)batch * max_len;
+    int rc = ensure_ws(m, cap, batch);
+    if (rc) return bfail(rc, "rmu_bert_encode: workspace");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
+    const float eps = m->cfg.ln_eps;
+
+    hipLaunchKernelGGL(k_cu_seqlens, dim3(1), dim3(1024), 0, s, (const int*)lens, batch, max_len, m->cu);
+    hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, (const int*)ids, (const int*)type_ids,
+                       (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
+                       m->cfg.type_vocab, m->h);
+    const dim3 ln_grid((unsigned)((cap + 3) / 4));
+    const dim3 at_grid((unsigned)((max_len + 63) / 64), NH, (unsigned)batch);
+    for (const BertLayer& L : m->layers) {
+        launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
+        if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
+        else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
+        else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
+        launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
+        hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
+        launch_gemm<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, cap, FF, H, s);
+        launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
+        hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
+    }
+    if (mode == 0)
+        hipLaunchKernelGGL(k_meanpool_l2, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)m->h, (const int*)m->cu, out_dev, out_stride);
+    else
+        hipLaunchKernelGGL(k_cls_head, dim3((unsigned)batch), dim3(128), 0, s, (const bf16*)m->h, (const int*)m->cu, m->wp, m->bp, m->wc, m->bc, out_dev);
+    B_TRY(hipGetLastError());
+    if (!hip_stream) B_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}

@@ -38,6 +38,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 extern "C" const char* rmu_last_error(void) { return g_err.c_str(); }
+extern "C" void rmu_set_error_(const char* msg) { g_err = msg ? msg : ""; }   // used by bert.hip
 extern "C" const char* rmu_version(void) { return "librmu 0.1 gfx950"; }
 
 static int g_device = -1;

@@ -1,0 +1,104 @@
+"""GPU parity of the BERT-6x384 forwards against the fp64 oracle (itself pinned on transformers' BertModel in
+tests/test_oracle_cpu.py).  Weights are architecture-exact and synthetic (no checkpoints exist offline).
+
+Tolerance (bf16 MFMA vs fp32/fp64 reference): cosine(embedding, oracle) >= 0.999;
+cross-encoder logit within 2e-2 * (1 + |logit|)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import bert_weights_numpy, make_bert, synth_tokens
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bi():
+    import torch
+    assert torch.cuda.is_available()
+    from ragmeup_amd.bert import BertEncoder
+    m = make_bert(seed=0, layers=6)
+    w = bert_weights_numpy(m)
+    return BertEncoder(w, layers=6), w
+
+
+@pytest.fixture(scope="module")
+def cross():
+    from ragmeup_amd.bert import BertEncoder
+    m = make_bert(seed=1, layers=6, head=True)
+    w = bert_weights_numpy(m)
+    return BertEncoder(w, layers=6), w
+
+
+@pytest.mark.parametrize("n,lmax,mean", [(1, 16, 8), (9, 40, 24), (33, 128, 90), (5, 256, 200), (3, 512, 400)])
+def test_embeddings_vs_oracle(bi, n, lmax, mean):
+    enc, w = bi
+    ids, tt, lens = synth_tokens(n, seed=3 + n, lmin=2, lmax=lmax, mean=mean, std=max(2, mean // 3))
+    got = enc.encode_ids(ids, lens, None, mode=0).cpu().numpy()
+    ref = O.embed_pool(O.bert_hidden(w, ids, np.zeros_like(ids), lens), lens)
+    cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
+    assert cos.min() >= 0.999, cos
+    assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)          # unit norm (ST Normalize)
+
+
+def test_padding_and_batch_composition_do_not_matter(bi):
+    enc, _ = bi
+    ids, tt, lens = synth_tokens(12, seed=21, lmax=60, mean=30, std=12)
+    a = enc.encode_ids(ids, lens, None, mode=0).cpu().numpy()
+    wide = np.concatenate([ids, np.full((12, 37), 7, np.int32)], axis=1)       # garbage in the padding
+    b = enc.encode_ids(wide, lens, None, mode=0).cpu().numpy()
+    assert np.array_equal(a, b)
+    one = np.stack([enc.encode_ids(ids[i:i + 1, :lens[i]], lens[i:i + 1], None, mode=0).cpu().numpy()[0] for i in range(12)])
+    assert np.abs(one - a).max() < 1e-6                                         # a sequence's result ignores its batch
+
+
+def test_cross_encoder_logits_vs_oracle(cross):
+    enc, w = cross
+    ids, tt, lens = synth_tokens(14, seed=5, lmax=160, mean=120, std=25, pair=True)
+    got = enc.encode_ids(ids, lens, tt, mode=1).cpu().numpy()
+    ref = O.cross_encoder_logit(w, O.bert_hidden(w, ids, tt, lens))
+    assert np.all(np.abs(got - ref) <= 2e-2 * (1 + np.abs(ref))), (got, ref)
+    # rerank order identical up to near-ties
+    order_g, order_r = np.argsort(-got, kind="stable"), np.argsort(-ref, kind="stable")
+    for a, b in zip(order_g, order_r):
+        assert a == b or abs(ref[a] - ref[b]) < 1e-2
+
+
+def test_embeddings_object_and_reranker_pipeline(bi, cross):
+    """embed_ids -> store -> dense top-k -> cross-encoder -> ScoredCrossEncoderReranker, all on the GPU paths."""
+    from ragmeup_amd import FlatIndex, ScoredCrossEncoderReranker
+    from ragmeup_amd.documents import Document
+    from ragmeup_amd.embeddings import MI355XCrossEncoder, MI355XEmbeddings
+    emb = MI355XEmbeddings(encoder=bi[0])
+    ids, _, lens = synth_tokens(300, seed=31, lmax=64, mean=40, std=10)
+    seqs = [ids[i, :lens[i]].tolist() for i in range(300)]
+    vecs = emb.embed_ids(seqs)
+    idx = FlatIndex(384)
+    idx.add(vecs)
+    s, r = idx.search(vecs[:20], 5)
+    assert (r[:, 0].cpu().numpy() == np.arange(20)).all()                    # each chunk retrieves itself first
+    ref = O.embed_pool(O.bert_hidden(bi[1], ids[:20], np.zeros_like(ids[:20]), lens[:20]), lens[:20])
+    osc, oracle_rows = O.flat_search(ref.astype(np.float32), vecs.cpu().numpy(), 6)
+    got_rows = r.cpu().numpy()
+    # downstream recall.  Random-init BERT maps random sequences to nearly identical vectors, so a miss
+    # is accepted only when it is a near-tie at the bf16 noise level (oracle scores within 2e-3 of the cut).
+    for i in range(20):
+        for pos, row in enumerate(oracle_rows[i][:5]):
+            if row not in got_rows[i]:
+                assert osc[i, pos] - osc[i, 5] < 2e-3, (i, pos, osc[i])
+
+    class TokCE(MI355XCrossEncoder):                                          # token-level stand-in for a tokenizer
+        def score(self, pairs):
+            seqs, types = [], []
+            for q, p in pairs:
+                qa, pa = [int(t) for t in q.split()], [int(t) for t in p.split()]
+                seqs.append([101] + qa + [102] + pa + [102]); types.append([0] * (len(qa) + 2) + [1] * (len(pa) + 1))
+            return self.score_ids(seqs, types).cpu().numpy().astype(float).tolist()
+
+    ce = TokCE(encoder=cross[0])
+    docs = [Document(" ".join(map(str, seqs[i][1:-1])), {"source": "s", "id": str(i)}) for i in range(14)]
+    out = ScoredCrossEncoderReranker(model=ce, top_n=3).compress_documents(docs, " ".join(map(str, seqs[50][1:9])))
+    assert len(out) == 3 and all("relevance_score" in d.metadata for d in out)
+    sc = [d.metadata["relevance_score"] for d in out]
+    assert sc == sorted(sc, reverse=True)
+    idx.close()
