@@ -157,16 +157,25 @@ def main():
     bytes_alg = n_local * D * 4 + B * D * 4 + B * K * 12
     ach_tf = flops / (scan_avg_ms * 1e-3) / 1e12
     ach_gbs = bytes_alg / (scan_avg_ms * 1e-3) / 1e9
-    roofline = {
-        "kernel": "scan_topk_kernel<D=384,WQ=4,CK=96,RING=4,CAP=64>",
-        "bound": "mfma",
-        "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach_tf / PEAK_F32_MFMA_TFLOPS, 4),
-        "traffic": None,
-        "kernel_ms": round(scan_avg_ms, 4),
-        "hbm_algorithmic_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(ach_gbs / PEAK_HBM_GBS, 4),
-        "launch": geom,
-    }
+    f_mfma, f_hbm = ach_tf / PEAK_F32_MFMA_TFLOPS, ach_gbs / PEAK_HBM_GBS
+    wq = 1 if B <= 32 else (2 if B <= 64 else 4)
+    kname = {4: "scan_topk_kernel<D=384,WQ=4,CK=96,RING=4,CAP=64>", 2: "scan_topk_kernel<D=384,WQ=2,CK=96,RING=3,CAP=64>",
+             1: "scan_topk_kernel<D=384,WQ=1,CK=48,RING=3,CAP=64>"}[wq]
+    # HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE), measured on this
+    # exact configuration and committed under profiles/; null for any other configuration.
+    traffic = None
+    if world == 1 and N == 10_000_000 and D == 384 and K == 10 and B in (1024, 1):
+        traffic = {1024: 2 * 7.865e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
+    if f_mfma >= f_hbm:
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
+    else:
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(f_hbm, 4)}
+    roofline.update({"traffic": traffic, "traffic_source": "profiles/r01_summary.md" if traffic else None,
+                     "kernel_ms": round(scan_avg_ms, 4), "algorithmic_bytes": bytes_alg, "algorithmic_flops": flops,
+                     "mfma_TFLOPs": round(ach_tf, 2), "mfma_frac_of_157.3": round(f_mfma, 4),
+                     "hbm_algorithmic_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(f_hbm, 4), "launch": geom})
 
     # ---- CPU baseline + recall on a bounded sample (rank 0, N=1 only) -------------------------------
     cpu = None
