@@ -105,7 +105,7 @@ def main():
         dist.broadcast(planted, 0)
     sample_host = None
     if rank == 0 and not args.no_cpu_baseline:
-        sample_rows = min(n_local, 1_000_000)
+        sample_rows = min(n_local, 2_000_000)
         sample_host = shard[:sample_rows].cpu().numpy()
     del shard
     torch.cuda.empty_cache()
@@ -182,7 +182,7 @@ def main():
     recall = None
     if world == 1 and sample_host is not None:
         from oracle import oracle as O
-        nq_s = 128
+        nq_s = min(B, 1024)          # ~10-20 s of CPU work on the GPU box's host cores
         qh = q[:nq_s].cpu().numpy()
         threads = os.cpu_count() or 1
         t1 = time.perf_counter()

@@ -26,7 +26,7 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> tuple[int, int]:
 
 class ShardedSearcher:
     def __init__(self, index=None, row_base: int = 0, group=None,
-                 local_search: Callable | None = None, merge: Callable | None = None):
+                 local_search: Callable | None = None, merge: Callable | None = None, force_collective: bool = False):
         self.index = index
         self.row_base = int(row_base)
         self.group = group
@@ -39,6 +39,7 @@ class ShardedSearcher:
             merge = topk_merge
         self._search = local_search
         self._merge = merge
+        self.force_collective = bool(force_collective)   # run the all-gather + merge even at world size 1 (tests)
 
     @property
     def world(self) -> int:
@@ -49,7 +50,7 @@ class ShardedSearcher:
         Returns (scores [B,k] f32, rows [B,k] i64) -- identical on every rank."""
         s, r = self._search(q, k)
         w = self.world
-        if w == 1:
+        if w == 1 and not (self.force_collective and dist.is_initialized()):
             return s, r
         s = torch.as_tensor(s).contiguous()
         r = torch.as_tensor(r).contiguous()

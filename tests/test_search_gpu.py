@@ -272,3 +272,28 @@ def test_full_size_properties_1m(rmu):
     s2, r2 = idx.search(q, 10)
     assert torch.equal(r, r2) and torch.equal(s, s2)
     idx.close()
+
+
+def test_rccl_allgather_path_world1(rmu, corpus50k):
+    """The collective leg (pack -> RCCL all_gather_into_tensor -> unpack -> rmu_topk_merge) at world_size 1 --
+    the only size a 1-GPU box allows (SURVEY.md 8e iii); world_size 2 is covered on CPU with gloo."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from ragmeup_amd.shard import ShardedSearcher
+    x, q, _ = corpus50k
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        idx = rmu.FlatIndex(384)
+        idx.add(x)
+        ss = ShardedSearcher(idx, row_base=0, force_collective=True)
+        s, r = ss.search(torch.from_numpy(q[:96]).cuda(), 10)
+        assert_topk_parity(s.cpu().numpy(), r.cpu().numpy(), *O.flat_search(q[:96], x, 10))
+        idx.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
