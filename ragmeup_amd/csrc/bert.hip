@@ -14,6 +14,7 @@
 // v_mfma_f32_16x16x32_bf16 on 128x128x64 tiles staged through LDS by LDS-DMA (global_load_lds_dwordx4) with the
 // XOR swizzle applied to the per-lane SOURCE address (the DMA writes lane-linear).  Operands are swapped
 // (D^T = W . A^T) so a lane ends up with 4 consecutive output features of one token: 8-byte bf16 stores.
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
@@ -31,6 +32,19 @@ namespace {
 constexpr int H = 384, NH = 12, DH = 32, FF = 1536;
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, two orders below the bf16 resolution of the output):
+// one rcp + one exp + 6 fma instead of libm's ~40-instruction erff
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // small kernels
@@ -132,44 +146,67 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16* __restrict__ y, c
 // ------------------------------------------------------------------------------------------------------------
 // GEMM: out[m, n] = epi( sum_k A[m, k] * W[n, k] + bias[n] )     A [M, K] bf16, W [N, K] bf16 (HF Linear layout)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128;
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
 extern __shared__ __attribute__((aligned(16))) char gsm[];
 
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm(const bf16* __restrict__ A, const bf16* __restrict__ W,
-                                              const float* __restrict__ bias, const bf16* __restrict__ resid,
-                                              bf16* __restrict__ out, const int* __restrict__ cu, int batch, int N, int K) {
+// Tile = (64*WM tokens) x 128 features, 2*WM waves (each 64 x 64), BK = K-slab per stage, ST = ring stages.
+// The kernel is bound by the L2->LDS operand fill rate (measured ~6-7 TB/s chip-wide), not by MFMA issue:
+// flop per staged byte is what matters (128x128: 64, 256x128: 87), and more resident workgroups beat deeper rings.
+template <int EPI, int WM, int BK, int ST>
+__global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                   const float* __restrict__ bias, const bf16* __restrict__ resid,
+                                                   bf16* __restrict__ out, const int* __restrict__ cu, int batch, int N, int K, int dbg) {
+    constexpr int BM = 64 * WM, NWV = 2 * WM, NTH = 64 * NWV;
+    constexpr int UPR = BK / 8;                    // 16-B units per row of a slab
+    constexpr int NITA = BM * UPR / NTH;           // DMA wave-instructions per wave per slab (tokens)
+    constexpr int NITW = BN * UPR / NTH;           // ... (features)
+    constexpr int SLABA = BM * BK * 2, SLABW = BN * BK * 2;
+    constexpr int KS = BK / 32;                    // MFMA k-substeps per slab
+    static_assert(NITA >= 1 && NITW >= 1, "tile too small for the thread count");
     const int M = cu[batch];                       // real token count (device side: no host sync)
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // block -> (token tile, feature tile): the N/BN feature tiles that re-read one token tile run on ONE XCD
+    // (dispatch places block b on XCD b % 8) so the tile comes through one L2 instead of eight
+    const int ntn = N / BN;
+    const int xcd = blockIdx.x & 7, mloc = blockIdx.x >> 3;
+    const int m0 = ((mloc / ntn) * 8 + xcd) * BM, n0 = (mloc % ntn) * BN;
     if (m0 >= M) return;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w >> 1, wn = w & 1;             // wave -> 64 tokens x 64 features
-    char* As = gsm;                                // [2][128 rows][8 units of 16 B]   (tokens x k)
-    char* Ws = gsm + 2 * BM * BK * 2;              // [2][128 rows][8 units]           (features x k)
+    char* As = gsm;                                // [ST][BM rows][UPR units]   (tokens x k)
+    char* Ws = gsm + ST * SLABA;                   // [ST][128 rows][UPR units]  (features x k)
+    auto swz = [](int row) { return UPR == 8 ? (row & 7) : ((row >> 2) & 3); };
 
-    // DMA source map: LDS unit f = (it*4 + w)*64 + lane  ->  row f/8, physical unit f%8, logical unit p ^ (row&7)
-    int arow[4], wrow[4], ucol[4];
+    // DMA source map: LDS unit f = (it*NWV + w)*64 + lane  ->  row f/UPR, physical unit f%UPR, logical unit p ^ swz(row)
+    int arow[NITA], acol[NITA], wrow[NITW], wcol[NITW];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int f = (it * 4 + w) * 64 + lane;
-        const int row = f >> 3, p = f & 7;
-        ucol[it] = (p ^ (row & 7)) * 8;            // element offset inside the BK slab
+    for (int it = 0; it < NITA; ++it) {
+        const int f = (it * NWV + w) * 64 + lane;
+        const int row = f / UPR, p = f % UPR;
+        acol[it] = (p ^ swz(row)) * 8;             // element offset inside the slab
         arow[it] = min(m0 + row, M - 1);           // clamp: rows >= M are never stored
+    }
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+        const int f = (it * NWV + w) * 64 + lane;
+        const int row = f / UPR, p = f % UPR;
+        wcol[it] = (p ^ swz(row)) * 8;
         wrow[it] = n0 + row;
     }
-    auto stage = [&](int buf, int k0) {
+    const int nk = K / BK;
+    auto stage = [&](int kt) {                     // kt may run past nk: harmless reloads keep vmcnt uniform
+        const int buf = kt % ST;
+        const int k0 = (kt < nk ? kt : nk - 1) * BK;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)arow[it] * K + k0 + ucol[it]),
-                                             (__attribute__((address_space(3))) void*)(As + buf * (BM * BK * 2) + (it * 4 + w) * 1024),
-                                             16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (int64_t)wrow[it] * K + k0 + ucol[it]),
-                                             (__attribute__((address_space(3))) void*)(Ws + buf * (BN * BK * 2) + (it * 4 + w) * 1024),
-                                             16, 0, 0);
-        }
+        for (int it = 0; it < NITA; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)arow[it] * K + k0 + acol[it]),
+                                             (__attribute__((address_space(3))) void*)(As + buf * SLABA + (it * NWV + w) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < NITW; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (int64_t)wrow[it] * K + k0 + wcol[it]),
+                                             (__attribute__((address_space(3))) void*)(Ws + buf * SLABW + (it * NWV + w) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[4][4];                               // [feature tile][token tile]
@@ -179,27 +216,27 @@ __global__ __launch_bounds__(256) void k_gemm(const bf16* __restrict__ A, const 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, kg = lane >> 4;
-    const int nk = K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                            // tile kt landed everywhere; everyone left buffer cur^1
-        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-        const char* as = As + cur * (BM * BK * 2);
-        const char* ws = Ws + cur * (BN * BK * 2);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+    for (int p = 0; p < ST - 1; ++p) stage(p);
+    for (int kt = 0; kt < ((dbg & 2) ? 0 : nk); ++kt) {
+        // slab kt landed (own DMA) once at most ST-2 younger groups are outstanding; own LDS reads returned
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NITA + NITW) * (ST - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(kt + ST - 1);                         // refills the slot everyone finished reading last round
+        const char* as = As + (kt % ST) * SLABA;
+        const char* ws = Ws + (kt % ST) * SLABW;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8 wf[4], af[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wn * 64 + i * 16 + fr;
-                wf[i] = *(const bf16x8*)(ws + (row * 8 + ((ks * 4 + kg) ^ (row & 7))) * 16);
+                wf[i] = *(const bf16x8*)(ws + (row * UPR + ((ks * 4 + kg) ^ swz(row))) * 16);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = wm * 64 + j * 16 + fr;
-                af[j] = *(const bf16x8*)(as + (row * 8 + ((ks * 4 + kg) ^ (row & 7))) * 16);
+                af[j] = *(const bf16x8*)(as + (row * UPR + ((ks * 4 + kg) ^ swz(row))) * 16);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -208,38 +245,204 @@ __global__ __launch_bounds__(256) void k_gemm(const bf16* __restrict__ A, const 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
     }
-    // epilogue: lane holds features n..n+3 (rows of D^T) of token m (column of D^T)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail reloads: the ring is reused below
+    __syncthreads();
+    // epilogue.  A lane holds features n..n+3 (rows of D^T) of token m (column of D^T): written straight to HBM
+    // that is 16 rows x 32 B per store instruction.  Instead each wave parks its 64 x 64 bf16 tile in LDS
+    // (rows of 128 B + 16 B pad) and writes it back out as FULL 128-B lines, 8 lanes x 16 B per token row.
+    // (Measured on FFN1: the 3.2 GB intermediate written as 32-B pieces cost more than the whole MFMA loop.)
+    constexpr int TSTR = 144;                       // bytes per token row of the staging tile
+    char* tile = gsm + w * (64 * TSTR);             // 9 KiB per wave, inside the (now idle) ring
+    // (the launcher sizes dynamic LDS as max(ring, 2*WM*64*TSTR))
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + fr;
-        if (m >= M) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + kg * 4;
-            const f32x4 bv = *(const f32x4*)(bias + n);
+            const int nl = i * 16 + kg * 4;         // feature inside the wave tile
+            const f32x4 bv = *(const f32x4*)(bias + n0 + wn * 64 + nl);
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
             if (EPI == EPI_GELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
-            }
-            if (EPI == EPI_RESID) {
-                const bf16x4 rv = *(const bf16x4*)(resid + (int64_t)m * N + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bf2f(rv[e]);
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + fast_erf(v[e] * 0.70710678118654752f));
             }
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-            *(bf16x4*)(out + (int64_t)m * N + n) = o;
+            *(bf16x4*)(tile + (j * 16 + fr) * TSTR + nl * 2) = o;
+        }
+    }
+    // wave-private tile: no barrier needed, only the wave's own LDS writes must have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+        const int row = r8 * 8 + (lane >> 3), u = lane & 7;      // 8 token rows x 8 units of 16 B per instruction
+        const int m = m0 + wm * 64 + row;
+        if (m < M && !(dbg & 1)) {
+            bf16x8 o = *(const bf16x8*)(tile + row * TSTR + u * 16);
+            const int64_t off = (int64_t)m * N + n0 + wn * 64 + u * 8;
+            if (EPI == EPI_RESID) {
+                const bf16x8 rv = *(const bf16x8*)(resid + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)(bf2f(o[e]) + bf2f(rv[e]));
+            }
+            *(bf16x8*)(out + off) = o;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// attention: one workgroup = (sequence, head, 64 queries); K rows and V^T of the whole sequence in LDS; each wave
-// owns 16 queries and keeps its full score strip S^T[keys, 16] in registers (<= 32 key tiles), exact softmax.
+// GEMM + bias + residual + LayerNorm for N = 384 (out-proj, FFN2): out = LN(A . W^T + bias + resid) * g + b.
+// Tile = 128 tokens x ALL 384 features (8 waves: 4 token groups x 2 feature halves, each 32 x 192), so a
+// workgroup owns whole rows: the pre-LN sum is parked in LDS as bf16 (the same rounding the unfused path applied
+// when it wrote y to HBM) and normalised from there -- no y round trip through HBM, no separate LN launch.
+// ------------------------------------------------------------------------------------------------------------
+template <int BK, int ST>
+__global__ __launch_bounds__(512) void k_gemm_ln(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                 const float* __restrict__ bias, const bf16* __restrict__ resid,
+                                                 const float* __restrict__ g, const float* __restrict__ bta, float eps,
+                                                 bf16* __restrict__ out, const int* __restrict__ cu, int batch, int K) {
+    constexpr int BM = 128, BNF = H, NWV = 8, NTH = 512;
+    constexpr int UPR = BK / 8;
+    constexpr int NITA = BM * UPR / NTH, NITW = BNF * UPR / NTH;
+    constexpr int SLABA = BM * BK * 2, SLABW = BNF * BK * 2;
+    constexpr int KS = BK / 32;
+    constexpr int TSTR = H * 2 + 16;               // bytes per token row of the pre-LN tile in LDS
+    static_assert(NITA >= 1, "tile/thread mismatch");
+    const int M = cu[batch];
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;             // wave -> tokens [32wm, +32) x features [192wn, +192)
+    char* As = gsm;
+    char* Ws = gsm + ST * SLABA;
+    auto swz = [](int row) { return UPR == 8 ? (row & 7) : ((row >> 2) & 3); };
+    int arow[NITA], acol[NITA], wrow[NITW], wcol[NITW];
+#pragma unroll
+    for (int it = 0; it < NITA; ++it) {
+        const int f = (it * NWV + w) * 64 + lane;
+        const int row = f / UPR, p = f % UPR;
+        acol[it] = (p ^ swz(row)) * 8;
+        arow[it] = min(m0 + row, M - 1);
+    }
+#pragma unroll
+    for (int it = 0; it < NITW; ++it) {
+        const int f = (it * NWV + w) * 64 + lane;
+        const int row = f / UPR, p = f % UPR;
+        wcol[it] = (p ^ swz(row)) * 8;
+        wrow[it] = row;
+    }
+    const int nk = K / BK;
+    auto stage = [&](int kt) {
+        const int buf = kt % ST;
+        const int k0 = (kt < nk ? kt : nk - 1) * BK;
+#pragma unroll
+        for (int it = 0; it < NITA; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)arow[it] * K + k0 + acol[it]),
+                                             (__attribute__((address_space(3))) void*)(As + buf * SLABA + (it * NWV + w) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int it = 0; it < NITW; ++it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (int64_t)wrow[it] * K + k0 + wcol[it]),
+                                             (__attribute__((address_space(3))) void*)(Ws + buf * SLABW + (it * NWV + w) * 1024), 16, 0, 0);
+    };
+    f32x4 acc[12][2];                              // [feature tile][token tile]
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < ST - 1; ++p) stage(p);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NITA + NITW) * (ST - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(kt + ST - 1);
+        const char* as = As + (kt % ST) * SLABA;
+        const char* ws = Ws + (kt % ST) * SLABW;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wm * 32 + j * 16 + fr;
+                af[j] = *(const bf16x8*)(as + (row * UPR + ((ks * 4 + kg) ^ swz(row))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int row = wn * 192 + i * 16 + fr;
+                const bf16x8 wf = *(const bf16x8*)(ws + (row * UPR + ((ks * 4 + kg) ^ swz(row))) * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // ring is dead: reuse LDS for the [128][384] pre-LN tile
+    char* tile = gsm;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tr = wm * 32 + j * 16 + fr;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int n = wn * 192 + i * 16 + kg * 4;
+            const f32x4 bv = *(const f32x4*)(bias + n);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][j][e] + bv[e]);
+            *(bf16x4*)(tile + tr * TSTR + n * 2) = o;
+        }
+    }
+    __syncthreads();
+    // each wave normalises 16 token rows; lane owns columns {2l, 2l+1} + 128*jj (coalesced 4-B accesses)
+    float gg[6], bb[6];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        gg[2 * jj] = g[128 * jj + 2 * lane]; gg[2 * jj + 1] = g[128 * jj + 2 * lane + 1];
+        bb[2 * jj] = bta[128 * jj + 2 * lane]; bb[2 * jj + 1] = bta[128 * jj + 2 * lane + 1];
+    }
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    for (int r = 0; r < 16; ++r) {
+        const int tr = w * 16 + r;
+        const int m = m0 + tr;
+        if (m >= M) break;                         // uniform per wave
+        float v[6];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const bf16x2 a2 = *(const bf16x2*)(tile + tr * TSTR + (128 * jj + 2 * lane) * 2);
+            const bf16x2 r2 = *(const bf16x2*)(resid + (int64_t)m * H + 128 * jj + 2 * lane);
+            // y = bf16(gemm + bias + resid): same rounding point as the unfused y tensor
+            v[2 * jj] = bf2f((bf16)(bf2f(a2[0]) + bf2f(r2[0])));
+            v[2 * jj + 1] = bf2f((bf16)(bf2f(a2[1]) + bf2f(r2[1])));
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sm += v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        const float mu = sm * (1.0f / H);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const float d = v[i] - mu; q = fmaf(d, d, q); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rs = rsqrtf(q * (1.0f / H) + eps);
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            bf16x2 o2;
+            o2[0] = (bf16)((v[2 * jj] - mu) * rs * gg[2 * jj] + bb[2 * jj]);
+            o2[1] = (bf16)((v[2 * jj + 1] - mu) * rs * gg[2 * jj + 1] + bb[2 * jj + 1]);
+            *(bf16x2*)(out + (int64_t)m * H + 128 * jj + 2 * lane) = o2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// attention: one workgroup = (sequence, head); K rows and V^T of the whole sequence staged in LDS once; each wave
+// takes 16 queries per round (rounds of 64) and keeps its full score strip S^T[keys, 16] in registers
+// (<= 32 key tiles): exact softmax, no online rescaling.
 // ------------------------------------------------------------------------------------------------------------
 template <int MAXT>   // max key tiles of 16 (sequence length <= 16*MAXT)
 __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv, const int* __restrict__ cu,
@@ -249,105 +452,124 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
     constexpr int VSTR = LP * 2 + 8;               // bytes per V^T row
     char* ks = gsm;                                // [LP][KSTR]
     char* vt = gsm + LP * KSTR;                    // [DH][VSTR]
-    const int b = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    const int b = blockIdx.y, head = blockIdx.x;
     const int t0 = cu[b], L = cu[b + 1] - t0;
-    if (qb * 64 >= L) return;
+    if (L <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, kg = lane >> 4;
     const int nt = (L + 15) >> 4;                  // key tiles in use
     const int npair = (nt + 1) >> 1;               // 32-key blocks for P.V
     const int rows_fill = npair * 32;              // rows touched by the MFMAs (<= LP)
     const int64_t rs = 3 * H;                      // qkv row stride (elements)
 
-    // ---- K rows (16-B pieces) and V transposed into LDS; rows >= L are zero -------------------------------
-    for (int p = tid; p < rows_fill * 4; p += 256) {
-        const int r = p >> 2, u = p & 3;
-        uint4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (r < L) {
-            const bf16* base = qkv + (int64_t)(t0 + r) * rs + head * DH + u * 8;
-            kv = *(const uint4*)(base + H);
-            vv = *(const uint4*)(base + 2 * H);
-        }
-        *(uint4*)(ks + r * KSTR + u * 16) = kv;
-        const unsigned short* ve = (const unsigned short*)&vv;
+    // Q fragment of the first query block: issued BEFORE the K/V staging so its latency overlaps it
+    // (B operand: query q0+fr, dims 8*kg..; 1/sqrt(32) is folded into Wq at load time)
+    bf16x8 qf = {};
+    if (w * 16 + fr < L) qf = *(const bf16x8*)(qkv + (int64_t)(t0 + w * 16 + fr) * rs + head * DH + kg * 8);
+
+    // ---- K rows (16-B pieces) and V transposed into LDS, once per (sequence, head); rows >= L are zero -------
+    for (int p0 = 0; p0 < rows_fill * 4; p0 += 512) {
+        uint4 kv[2], vv[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *(unsigned short*)(vt + (u * 8 + e) * VSTR + r * 2) = ve[e];
+        for (int u2 = 0; u2 < 2; ++u2) {           // both loads in flight before either is used
+            const int p = p0 + u2 * 256 + tid;
+            const int r = p >> 2, u = p & 3;
+            kv[u2] = uint4{0u, 0u, 0u, 0u};
+            vv[u2] = uint4{0u, 0u, 0u, 0u};
+            if (p < rows_fill * 4 && r < L) {
+                const bf16* base = qkv + (int64_t)(t0 + r) * rs + head * DH + u * 8;
+                kv[u2] = *(const uint4*)(base + H);
+                vv[u2] = *(const uint4*)(base + 2 * H);
+            }
+        }
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+            const int p = p0 + u2 * 256 + tid;
+            if (p < rows_fill * 4) {
+                const int r = p >> 2, u = p & 3;
+                *(uint4*)(ks + r * KSTR + u * 16) = kv[u2];
+                const unsigned short* ve = (const unsigned short*)&vv[u2];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *(unsigned short*)(vt + (u * 8 + e) * VSTR + r * 2) = ve[e];
+            }
+        }
     }
     __syncthreads();
 
-    const int q0 = qb * 64 + w * 16;
-    if (q0 >= L) return;                           // no barriers below
-    const int fr = lane & 15, kg = lane >> 4;
-    // Q fragment (B operand): query q0+fr, dims 8*kg..  (1/sqrt(32) is folded into Wq at load time)
-    bf16x8 qf = {};
-    if (q0 + fr < L) qf = *(const bf16x8*)(qkv + (int64_t)(t0 + q0 + fr) * rs + head * DH + kg * 8);
+    for (int q0 = w * 16; q0 < L; q0 += 64) {      // each wave: 16 queries per round; no barriers below
+        // prefetch the next round's Q fragment while this round computes
+        bf16x8 qn = {};
+        if (q0 + 64 + fr < L) qn = *(const bf16x8*)(qkv + (int64_t)(t0 + q0 + 64 + fr) * rs + head * DH + kg * 8);
 
-    // ---- S^T tiles: lane holds query fr, keys 16*kt + 4*kg + i ------------------------------------------------
-    f32x4 st[MAXT];
-    float mx = -INFINITY;
+        // ---- S^T tiles: lane holds query fr, keys 16*kt + 4*kg + i --------------------------------------------
+        f32x4 st[MAXT];
+        float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < MAXT; ++kt) {
-        st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (kt < nt) {
-            const bf16x8 kf = *(const bf16x8*)(ks + (kt * 16 + fr) * KSTR + kg * 16);
-            f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        for (int kt = 0; kt < MAXT; ++kt) {
+            st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (kt < nt) {
+                const bf16x8 kf = *(const bf16x8*)(ks + (kt * 16 + fr) * KSTR + kg * 16);
+                f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (kt * 16 + kg * 4 + i >= L) s[i] = -INFINITY;
-                mx = fmaxf(mx, s[i]);
-            }
-            st[kt] = s;
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MAXT; ++kt) {
-        if (kt < nt) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p = __expf(st[kt][i] - mx);   // exp(-inf) = 0 for masked keys
-                st[kt][i] = p;
-                sum += p;
+                for (int i = 0; i < 4; ++i) {
+                    if (kt * 16 + kg * 4 + i >= L) sc[i] = -INFINITY;
+                    mx = fmaxf(mx, sc[i]);
+                }
+                st[kt] = sc;
             }
         }
-    }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __expf(st[kt][i] - mx);   // exp(-inf) = 0 for masked keys
+                    st[kt][i] = p;
+                    sum += p;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
 
-    // ---- O = P . V : k-slot (kg, i, half) of block pb <-> key 32*pb + 16*half + 4*kg + i on BOTH operands ------
-    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // ---- O = P . V : k-slot (kg, i, half) of block pb <-> key 32*pb + 16*half + 4*kg + i on BOTH operands --
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int pb = 0; pb < MAXT / 2; ++pb) {
-        if (pb < npair) {
-            bf16x8 pf;
+        for (int pb = 0; pb < MAXT / 2; ++pb) {
+            if (pb < npair) {
+                bf16x8 pf;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pf[i] = (bf16)st[2 * pb][i];
-                pf[4 + i] = (2 * pb + 1 < nt) ? (bf16)st[2 * pb + 1][i] : (bf16)0.f;
-            }
+                for (int i = 0; i < 4; ++i) {
+                    pf[i] = (bf16)st[2 * pb][i];
+                    pf[4 + i] = (2 * pb + 1 < nt) ? (bf16)st[2 * pb + 1][i] : (bf16)0.f;
+                }
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const char* vrow = vt + (dt * 16 + fr) * VSTR + (32 * pb + 4 * kg) * 2;
-                const bf16x4 v0 = *(const bf16x4*)(vrow);
-                const bf16x4 v1 = *(const bf16x4*)(vrow + 32);
-                bf16x8 vf;
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vrow = vt + (dt * 16 + fr) * VSTR + (32 * pb + 4 * kg) * 2;
+                    const bf16x4 v0 = *(const bf16x4*)(vrow);
+                    const bf16x4 v1 = *(const bf16x4*)(vrow + 32);
+                    bf16x8 vf;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { vf[i] = v0[i]; vf[4 + i] = v1[i]; }
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) { vf[i] = v0[i]; vf[4 + i] = v1[i]; }
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+                }
             }
         }
-    }
-    // D layout: row = query 4*kg + i, col = dim fr (+16*dt).  Row sums live in lanes whose fr == that query.
+        // D layout: row = query 4*kg + i, col = dim fr (+16*dt).  Row sums live in lanes whose fr == that query.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int qi = kg * 4 + i;
-        const float den = __shfl(sum, qi);
-        if (q0 + qi < L) {
-            bf16* dst = ctx + (int64_t)(t0 + q0 + qi) * H + head * DH + fr;
-            dst[0] = (bf16)(o[0][i] / den);
-            dst[16] = (bf16)(o[1][i] / den);
+        for (int i = 0; i < 4; ++i) {
+            const int qi = kg * 4 + i;
+            const float den = __shfl(sum, qi);
+            if (q0 + qi < L) {
+                bf16* dst = ctx + (int64_t)(t0 + q0 + qi) * H + head * DH + fr;
+                dst[0] = (bf16)(o[0][i] / den);
+                dst[16] = (bf16)(o[1][i] / den);
+            }
         }
+        qf = qn;
     }
 }
 
@@ -561,14 +783,44 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
     return RMU_OK;
 }
 
+template <int EPI, int WM, int BK, int ST>
+static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
+                            int batch, int64_t m_cap, int N, int K, hipStream_t s) {
+    static bool attr = false;
+    constexpr int BM = 64 * WM;
+    const int ring = ST * (BM * BK * 2 + BN * BK * 2), stagebuf = 2 * WM * 64 * 144;
+    const int lds = ring > stagebuf ? ring : stagebuf;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm<EPI, WM, BK, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    const int64_t mt = ((m_cap + BM - 1) / BM + 7) / 8 * 8;     // token tiles, padded to a multiple of 8 (XCD map)
+    const dim3 grid((unsigned)(mt * (N / BN)));
+    static const int dbg = getenv("RMU_GEMM_DBG") ? atoi(getenv("RMU_GEMM_DBG")) : 0;
+    hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg);
+}
 template <int EPI>
 static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
                         int batch, int64_t m_cap, int N, int K, hipStream_t s) {
+    static const int cfg = getenv("RMU_GEMM_CFG") ? atoi(getenv("RMU_GEMM_CFG")) : 0;
+    switch (cfg) {
+        case 1: return launch_gemm_cfg<EPI, 2, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        case 2: return launch_gemm_cfg<EPI, 4, 64, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        case 3: return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        case 4: return launch_gemm_cfg<EPI, 4, 32, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        case 5: return launch_gemm_cfg<EPI, 2, 32, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        case 6: return launch_gemm_cfg<EPI, 2, 64, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        case 7: return launch_gemm_cfg<EPI, 4, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        default: return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);   // best measured
+    }
+}
+
+static void launch_gemm_ln(const bf16* A, const bf16* W, const float* bias, const bf16* resid, const float* g, const float* b,
+                           float eps, bf16* out, const int* cu, int batch, int64_t m_cap, int K, hipStream_t s) {
     static bool attr = false;
-    const int lds = 2 * (BM * BK * 2) + 2 * (BN * BK * 2);
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    const dim3 grid((unsigned)(N / BN), (unsigned)((m_cap + BM - 1) / BM));
-    hipLaunchKernelGGL(k_gemm<EPI>, grid, dim3(256), lds, s, A, W, bias, resid, out, cu, batch, N, K);
+    constexpr int BK = 32, ST = 2;
+    const int ring = ST * (128 * BK * 2 + H * BK * 2), tile = 128 * (H * 2 + 16);
+    const int lds = ring > tile ? ring : tile;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_ln<BK, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    hipLaunchKernelGGL((k_gemm_ln<BK, ST>), dim3((unsigned)((m_cap + 127) / 128)), dim3(512), lds, s, A, W, bias, resid, g, b, eps, out,
+                       cu, batch, K);
 }
 
 template <int MAXT>
@@ -599,17 +851,27 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
                        (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
                        m->cfg.type_vocab, m->h);
     const dim3 ln_grid((unsigned)((cap + 3) / 4));
-    const dim3 at_grid((unsigned)((max_len + 63) / 64), NH, (unsigned)batch);
+    const dim3 at_grid(NH, (unsigned)batch);   // one workgroup per (head, sequence)
     for (const BertLayer& L : m->layers) {
         launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
-        launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
-        hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
+        // measured: the fused 128x384 kernel (one workgroup per CU, serial LN pass) is 12% slower than GEMM + LN launches
+        static const bool fuse_ln = getenv("RMU_FUSED_LN") != nullptr;
+        if (fuse_ln) {
+            launch_gemm_ln(m->ctx, L.wo, L.bo, m->h, L.ln1g, L.ln1b, eps, m->h1, m->cu, batch, cap, H, s);
+        } else {
+            launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
+            hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
+        }
         launch_gemm<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, cap, FF, H, s);
-        launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
-        hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
+        if (fuse_ln) {
+            launch_gemm_ln(m->mid, L.w2, L.b2, m->h1, L.ln2g, L.ln2b, eps, m->h, m->cu, batch, cap, FF, s);
+        } else {
+            launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
+            hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
+        }
     }
     if (mode == 0)
         hipLaunchKernelGGL(k_meanpool_l2, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)m->h, (const int*)m->cu, out_dev, out_stride);
