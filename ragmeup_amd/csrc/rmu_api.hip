@@ -70,7 +70,7 @@ struct Buf {
 struct Tls {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr;
+    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch;
     bool timing = false;
     float scan_ms = -1.f, search_ms = -1.f;
     int grid = 0, block = 0, lds = 0, passes = 0;
@@ -382,7 +382,9 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         } else {
             HIP_TRY(hipMemsetAsync(L.partial, 0, pbytes, s));
         }
-        rc = rmu_merge_keys_launch(L.partial, L.parts, nb, k, row_base, 0, nullptr, d_s, d_r, s);
+        const int64_t skeys = (int64_t)32 * nb * k;
+        u64* scratch = (L.parts >= 64 && nb <= 1024 && !t.mscratch.ensure((size_t)skeys * sizeof(u64))) ? (u64*)t.mscratch.p : nullptr;
+        rc = rmu_merge_keys_launch2(L.partial, L.parts, nb, k, row_base, 0, nullptr, d_s, d_r, scratch, skeys, s);
         if (rc) return fail(rc, "rmu_index_search: merge launch");
         if (!out_dev) {
             HIP_TRY(hipMemcpyAsync(out_scores + q0 * k, d_s, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -112,5 +112,8 @@ int rmu_scan_launch(const ScanLaunch* p, hipStream_t s); // launches the fused s
 int rmu_merge_keys_launch(const u64* partial, int parts, int64_t nq, int k, int64_t row_base,
                           int l2_out, const float* qnorm2, float* out_scores, int64_t* out_rows,
                           hipStream_t s);
+int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out,
+                           const float* qnorm2, float* out_scores, int64_t* out_rows, u64* scratch, int64_t scratch_keys,
+                           hipStream_t s);
 int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
                            float* out_scores, int64_t* out_rows, u64* scratch_keys, hipStream_t s);

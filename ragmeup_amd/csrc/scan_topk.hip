@@ -32,8 +32,9 @@
 
 namespace {
 
-template <int D_, int WQ_, int CKF_, int RING_, int CAP_, int NCHECK_, int EXP_ = 0>
+template <int D_, int WQ_, int CKF_, int RING_, int CAP_, int NCHECK_, int EXP_ = 0, int LA_ = 1>
 struct Cfg {
+    static constexpr bool LA_ON = LA_ != 0;    // one-chunk look-ahead (costs one ring slot of in-flight data)
     static constexpr int EXP = EXP_;        // 0 = product; 1..3 = timing ablations (wrong results)
     static constexpr int D = D_;            // padded row length (floats)
     static constexpr int WQ = WQ_;          // query groups per workgroup
@@ -47,7 +48,7 @@ struct Cfg {
     static constexpr int SLOT_BYTES = RT * CKF_ * 4;
     static constexpr int NI = RT * U16 / 256;  // DMA wave-instructions per wave per chunk
     static constexpr int CAP = CAP_;
-    static constexpr int NPL = CAP_ / 64;
+    static constexpr int NPL = (CAP_ + 63) / 64;
     static constexpr int NCHECK = NCHECK_;
     static constexpr int A = 32 / NCHECK_;  // max appends per slot between overflow checks
     static constexpr int SWB = (U16 % 16 == 8) ? 8 : 4;  // swizzle block (units)
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
     };
     // LA (look-ahead): chunk cc+1 has landed when barrier cc is passed, so the first fragment of the
     // next chunk is read BEFORE its barrier and the MFMA pipe never waits on an LDS round trip.
-    constexpr bool LA = C::RING >= 3;
+    constexpr bool LA = C::RING >= 3 && C::LA_ON;
     constexpr int WAITN = LA ? C::NI * (C::RING - 3) : C::NI * (C::RING - 2);
 
     // ---- threshold filter of the PREVIOUS tile, hidden behind this tile's MFMAs ------------------------
@@ -492,9 +493,9 @@ int launch_cfg(const ScanLaunch* p, hipStream_t s) {
 //                                 D    WQ CKF RING CAP NCHECK
 template <int D> using C_w4_k0 = Cfg<D, 4, 96, 4, 64, 1>;    // 48 KiB ring + 64 KiB candidates
 template <int D> using C_w4_k1 = Cfg<D, 4, 96, 2, 128, 2>;   // 24 KiB ring + 128 KiB candidates
-template <int D> using C_w2_k0 = Cfg<D, 2, 96, 3, 64, 1>;    // 72 KiB ring
+template <int D> using C_w2_k0 = Cfg<D, 2, 96, 3, 64, 1, 0, 0>;   // 72 KiB ring, no look-ahead (2 chunks in flight)
 template <int D> using C_w2_k1 = Cfg<D, 2, 48, 2, 128, 2>;   // 24 KiB ring
-template <int D> using C_w1_k0 = Cfg<D, 1, 48, 3, 64, 1>;    // 72 KiB ring
+template <int D> using C_w1_k0 = Cfg<D, 1, 48, 3, 64, 1, 0, 0>;   // 72 KiB ring; HBM-bound: no look-ahead -> 2 chunks in flight (5.0 -> 5.8 TB/s)
 
 template <int D>
 int launch_d(const ScanLaunch* p, hipStream_t s) {
