@@ -90,6 +90,10 @@ float rmu_last_scan_ms(void);
 /* Same for the whole search (scan + merge), and the launch geometry of the last scan. */
 float rmu_last_search_ms(void);
 int rmu_last_scan_geometry(int* grid, int* block, int* lds_bytes, int* passes);
+/* How the calling thread's last rmu_index_search was answered: >0 by the fp16 hi/lo screening pass + exact fp32
+ * re-score (results identical to the exact scan), 0 by the exact fp32 scan, <0 = that many queries failed the
+ * screening sufficiency test and the batch was re-run on the exact scan. */
+int rmu_last_screened(void);
 /* Enable (1) / disable (0) the event timing above for the calling thread (off by default). */
 int rmu_set_timing(int on);
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "rmu_init", "rmu_last_error", "rmu_version",
     "rmu_index_create", "rmu_index_free", "rmu_index_size", "rmu_index_dim", "rmu_index_add",
     "rmu_index_remove_rows", "rmu_index_get_rows", "rmu_index_search", "rmu_topk_merge",
-    "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing",
+    "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing", "rmu_last_screened",
     "rmu_bert_create", "rmu_bert_free", "rmu_bert_encode",
 ]
 

@@ -70,10 +70,10 @@ struct Buf {
 struct Tls {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch;
+    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm;
     bool timing = false;
     float scan_ms = -1.f, search_ms = -1.f;
-    int grid = 0, block = 0, lds = 0, passes = 0;
+    int grid = 0, block = 0, lds = 0, passes = 0, screened = 0;
     int device = -1;
     int ensure_stream() {
         if (g_device >= 0 && device != g_device) { (void)hipSetDevice(g_device); device = g_device; }
@@ -87,6 +87,7 @@ struct Tls {
 };
 static thread_local Tls g_tls;
 
+extern "C" int rmu_last_screened(void) { return g_tls.screened; }
 extern "C" int rmu_set_timing(int on) { g_tls.timing = on != 0; return RMU_OK; }
 extern "C" float rmu_last_scan_ms(void) { return g_tls.scan_ms; }
 extern "C" float rmu_last_search_ms(void) { return g_tls.search_ms; }
@@ -126,6 +127,16 @@ __global__ void k_row_norm(float* x, int dpad, int64_t n, int normalise, float* 
     }
 }
 
+// max over rows of |x|^2 (non-negative floats order like their bit patterns)
+__global__ void k_max_norm2(const float* __restrict__ norm2, int64_t n, unsigned* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float v = i < n ? norm2[i] : 0.f;
+    if (!(v == v)) v = 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(v));
+}
+
 __global__ void k_gather_rows(const float* x, int dpad, int dim, const int64_t* rows, int64_t n, float* out) {
     const int64_t r = blockIdx.x;
     if (r >= n) return;
@@ -140,6 +151,8 @@ struct rmu_index {
     int dim = 0, dpad = 0, metric = 0;
     int64_t n = 0, cap = 0, n_live = 0;
     float* x = nullptr;
+    char* split = nullptr;          // fp16 hi/lo image of x (screening pass), same byte geometry; nullptr = disabled
+    float xnorm_max = 0.f;          // max row norm (bounds the screening error)
     std::vector<uint8_t> alive;
     std::shared_mutex mu;
 };
@@ -173,6 +186,17 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
         return fail(RMU_E_HIP, "rmu_index_create: zero fill");
     }
     idx->cap = cap;
+    // screening image (2x corpus memory): 384-wide rows only; RMU_SCREEN=0 disables
+    static const bool screen_on = !(getenv("RMU_SCREEN") && atoi(getenv("RMU_SCREEN")) == 0);
+    if (screen_on && idx->dpad == 384) {
+        if (hipMalloc((void**)&idx->split, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float)) != hipSuccess) {
+            idx->split = nullptr;   // not fatal: exact path only
+            (void)hipGetLastError();
+        } else {
+            (void)hipMemsetAsync(idx->split, 0, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float), g_tls.stream);
+            (void)hipStreamSynchronize(g_tls.stream);
+        }
+    }
     *out = idx;
     return RMU_OK;
 }
@@ -183,7 +207,9 @@ extern "C" int rmu_index_free(rmu_index_t* idx) {
         std::unique_lock<std::shared_mutex> lk(idx->mu);
         (void)hipDeviceSynchronize();
         if (idx->x) (void)hipFree(idx->x);
+        if (idx->split) (void)hipFree(idx->split);
         idx->x = nullptr;
+        idx->split = nullptr;
     }
     delete idx;
     return RMU_OK;
@@ -217,6 +243,21 @@ static int grow(rmu_index* idx, int64_t need) {
     if (idx->n)
         HIP_TRY(hipMemcpyAsync(nx, idx->x, (size_t)idx->n * idx->dpad * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (idx->split) {
+        char* ns = nullptr;
+        const size_t rowb = (size_t)idx->dpad * sizeof(float);
+        if (hipMalloc((void**)&ns, (size_t)(cap + kSlackRows) * rowb) == hipSuccess) {
+            HIP_TRY(hipMemsetAsync(ns + idx->n * rowb, 0, (size_t)(cap + kSlackRows - idx->n) * rowb, s));
+            if (idx->n) HIP_TRY(hipMemcpyAsync(ns, idx->split, (size_t)idx->n * rowb, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            (void)hipFree(idx->split);
+            idx->split = ns;
+        } else {
+            (void)hipGetLastError();
+            (void)hipFree(idx->split);   // no room for the screening image: exact path only from now on
+            idx->split = nullptr;
+        }
+    }
     (void)hipFree(idx->x);
     idx->x = nx;
     idx->cap = cap;
@@ -247,6 +288,26 @@ extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int
                            (float*)nullptr);
         HIP_TRY(hipGetLastError());
     }
+    if (idx->split) {
+        rc = rmu_split_launch(dst, idx->split + (size_t)idx->n * idx->dpad * sizeof(float), n, s);
+        if (rc) return fail(rc, "rmu_index_add: split image");
+        if (idx->metric == RMU_METRIC_COSINE) {
+            idx->xnorm_max = 1.0f;
+        } else {
+            Buf& nb = g_tls.nrm;
+            if (nb.ensure((size_t)n * sizeof(float) + 16)) return fail(RMU_E_OOM, "rmu_index_add: norm workspace");
+            unsigned* mx = (unsigned*)((char*)nb.p + (size_t)n * sizeof(float));
+            HIP_TRY(hipMemsetAsync(mx, 0, sizeof(unsigned), s));
+            hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dst, idx->dpad, n, 0, (float*)nb.p);
+            hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
+            unsigned hmx = 0;
+            HIP_TRY(hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            float f; memcpy(&f, &hmx, 4);
+            f = sqrtf(f);
+            if (f > idx->xnorm_max) idx->xnorm_max = f;
+        }
+    }
     HIP_TRY(hipStreamSynchronize(s));
     idx->alive.resize((size_t)(idx->n + n), 1);
     idx->n += n;
@@ -274,6 +335,9 @@ extern "C" int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int6
     HIP_TRY(hipMemcpyAsync(b.p, todo.data(), todo.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, idx->x, idx->dpad,
                        (const int64_t*)b.p, (int64_t)todo.size());
+    if (idx->split)   // fp32 NaN pattern = one fp16 NaN per pair: every screening score of the row is NaN as well
+        hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, (float*)idx->split, idx->dpad,
+                           (const int64_t*)b.p, (int64_t)todo.size());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     idx->n_live -= (int64_t)todo.size();
@@ -322,7 +386,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
 
     std::shared_lock<std::shared_mutex> lk(idx->mu);
     const int dpad = idx->dpad, dim = idx->dim;
-    t.scan_ms = -1.f; t.search_ms = -1.f; t.passes = 0;
+    t.scan_ms = -1.f; t.search_ms = -1.f; t.passes = 0; t.screened = 0;
     float scan_total = 0.f;
     if (timed) HIP_TRY(hipEventRecord(t.ev[0], s));
 
@@ -372,8 +436,51 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             d_s = (float*)t.out_s.p;
             d_r = (int64_t*)t.out_r.p;
         }
+        // ---- screened path: fp16 hi/lo scan proposes K' = 24 candidates, exact fp32 re-score decides -------------
+        bool done = false;
+        static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 128;
+        if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && k <= 16 && idx->n > 0 &&
+            idx->xnorm_max > 0.f && idx->xnorm_max < 1.0e4f) {
+            const int kp = 24;
+            ScanLaunch S{};
+            S.x = (const float*)idx->split; S.n_rows = idx->n; S.dpad = dpad; S.nq = (int)nb; S.k = kp;
+            rc = rmu_scan_plan(&S);
+            if (!rc && S.wq == 4 && S.kv == 0) {
+                const size_t sp = (size_t)S.parts * nb * kp * sizeof(u64);
+                if (t.partial.ensure(sp) || t.qsplit.ensure((size_t)nb * dpad * sizeof(float)) ||
+                    t.ckeys.ensure((size_t)nb * kp * sizeof(u64)) || t.flag.ensure(16))
+                    return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
+                L.partial = (u64*)t.partial.p;   // ensure() may have moved the buffer; the exact fallback uses it too
+                S.partial = (u64*)t.partial.p; S.gthr = (u32*)t.gthr.p; S.share_thr = L.share_thr | ((getenv("RMU_SCREEN_NOFILTER") != nullptr) ? 2 : 0); S.dbg = nullptr;
+                S.q = (const float*)t.qsplit.p;
+                HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
+                rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
+                if (rc) return fail(rc, "rmu_index_search: query split");
+                if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
+                rc = rmu_screen_launch(&S, s);
+                if (rc) return fail(rc, "rmu_index_search: screening launch");
+                if (timed) HIP_TRY(hipEventRecord(t.ev[3], s));
+                rc = rmu_merge_to_keys_launch(S.partial, S.parts, nb, kp, (u64*)t.ckeys.p, s);
+                if (rc) return fail(rc, "rmu_index_search: screening merge");
+                // |s~ - s_fp32| <= 1e-4 * |x|max * |q| (derivation in scan_screen.hip)
+                rc = rmu_rescore_launch((const u64*)t.ckeys.p, kp, idx->x, qdev, nb, k, 1.0e-4f * idx->xnorm_max, row_base, d_s, d_r,
+                                        (int*)t.flag.p, s);
+                if (rc) return fail(rc, "rmu_index_search: re-score launch");
+                int hflag = 0;
+                HIP_TRY(hipMemcpyAsync(&hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                t.grid = S.grid; t.block = 256; t.lds = 0; t.passes += 1;
+                t.screened = hflag == 0 ? 1 : -hflag;   // >0: answered by the screen; <0: that many queries fell back
+                if (timed) { float ms = 0.f; if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms; }
+                done = hflag == 0;
+                if (done) HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));   // (kept tidy for the next block)
+                else HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));        // exact scan below restarts the thresholds
+            }
+        }
         // ---- fused scan ------------------------------------------------------------------------------
-        if (idx->n > 0) {
+        if (done) {
+            // outputs are already in d_s / d_r
+        } else if (idx->n > 0) {
             if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
             rc = rmu_scan_launch(&L, s);
             if (rc) return fail(rc, std::string("rmu_index_search: scan launch: ") + hipGetErrorString(hipGetLastError()));
@@ -382,10 +489,12 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         } else {
             HIP_TRY(hipMemsetAsync(L.partial, 0, pbytes, s));
         }
+        if (!done) {
         const int64_t skeys = (int64_t)32 * nb * k;
         u64* scratch = (L.parts >= 64 && nb <= 1024 && !t.mscratch.ensure((size_t)skeys * sizeof(u64))) ? (u64*)t.mscratch.p : nullptr;
         rc = rmu_merge_keys_launch2(L.partial, L.parts, nb, k, row_base, 0, nullptr, d_s, d_r, scratch, skeys, s);
         if (rc) return fail(rc, "rmu_index_search: merge launch");
+        }
         if (!out_dev) {
             HIP_TRY(hipMemcpyAsync(out_scores + q0 * k, d_s, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_rows + q0 * k, d_r, (size_t)nb * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
@@ -393,7 +502,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // workspace is reused by the next query block (and host outputs must land): drain per block
         if (!hip_stream || q0 + nb < nq || !out_dev) HIP_TRY(hipStreamSynchronize(s));
         if (g_dbg) { u64 h[16]; (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg] slow_tiles=%llu compactions=%llu appends=%llu tiles=%llu slow_clk=%llu compact_clk=%llu addwait_clk=%llu endwait_clk=%llu check_clk=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]); }
-        if (timed && idx->n > 0) {
+        if (timed && idx->n > 0 && !done) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms;
         }

@@ -164,6 +164,14 @@ int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
+int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, hipStream_t s) {
+    if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
+    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
+    if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys);
+    else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+
 int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
                            float* out_scores, int64_t* out_rows, u64* /*scratch_keys*/, hipStream_t s) {
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;

@@ -116,6 +116,10 @@ class FlatIndex:
     def last_search_ms(self) -> float:
         return float(self._lib.rmu_last_search_ms())
 
+    def last_screened(self) -> int:
+        """>0: answered by the fp16 screening pass + exact re-score; 0: exact scan; <0: fell back to the exact scan."""
+        return int(self._lib.rmu_last_screened())
+
     def last_geometry(self) -> dict:
         g, b, l, p = (ctypes.c_int() for _ in range(4))
         self._lib.rmu_last_scan_geometry(ctypes.byref(g), ctypes.byref(b), ctypes.byref(l), ctypes.byref(p))

@@ -297,3 +297,67 @@ def test_rccl_allgather_path_world1(rmu, corpus50k):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---- fp16 hi/lo screening pass + exact fp32 re-score (nq >= 128, k <= 16, dim 384) ------------------------------------
+@pytest.mark.parametrize("nq,k", [(128, 10), (200, 1), (256, 16), (1024, 10)])
+def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
+    x = O.make_corpus(60_000)
+    q, planted = O.make_queries(x, nq)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    s, r = idx.search(q, k)
+    assert idx.last_screened() > 0, "expected the screening path to answer this batch"
+    assert_topk_parity(s, r, *O.flat_search(q, x, k + 4))      # oracle a few ranks deeper: boundary near-ties
+    assert (r[:, 0] == planted).all()
+    # bit-identical to the exact fp32 scan (same summation order in the re-score)
+    s2, r2 = idx.search(q, 17 if k <= 16 else k)     # k > 16 always takes the exact scan
+    assert idx.last_screened() == 0
+    assert np.array_equal(r2[:, :k], r) and np.array_equal(s2[:, :k], s)
+    idx.close()
+
+
+def test_screened_search_falls_back_on_dense_ties(rmu):
+    """More than K' = 24 exact duplicates of the best row: the sufficiency test must flag the query and the exact scan
+    must answer -- ids still in ascending-row order among the ties."""
+    x = O.make_corpus(20_000)
+    xd = np.concatenate([x, np.repeat(x[77:78], 40, axis=0)])            # row 77 exists 41 times
+    q = np.concatenate([x[77:78], O.make_queries(x, 199)[0]])
+    idx = rmu.FlatIndex(384)
+    idx.add(xd)
+    s, r = idx.search(q, 10)
+    assert idx.last_screened() < 0                                            # fell back
+    assert_topk_parity(s, r, *O.flat_search(q, xd, 10))
+    assert list(r[0]) == [77] + list(range(20_000, 20_009))
+    idx.close()
+
+
+def test_screened_search_with_tombstones_and_growth(rmu):
+    x = O.make_corpus(40_000)
+    q, planted = O.make_queries(x, 160)
+    idx = rmu.FlatIndex(384, capacity_hint=64)
+    for lo in range(0, 40_000, 8000):
+        idx.add(x[lo:lo + 8000])
+    dead = np.unique(planted[:50])
+    idx.remove_rows(dead)
+    alive = np.ones(40_000, bool); alive[dead] = False
+    s, r = idx.search(q, 10)
+    assert idx.last_screened() > 0
+    assert_topk_parity(s, r, *O.flat_search(q, x, 10, alive=alive))
+    assert not np.isin(r, dead).any()
+    idx.close()
+
+
+def test_screened_search_unnormalised_rows(rmu):
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((30_000, 384)) * rng.uniform(0.1, 3.0, (30_000, 1))).astype(np.float32)
+    q = rng.standard_normal((130, 384)).astype(np.float32)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    s, r = idx.search(q, 10)
+    os_, or_ = O.flat_search(q, x, 10)
+    # scores are O(50) here: the 1e-4 bar is relative to unit-norm scores; scale it by the score magnitude
+    assert np.array_equal(r, or_) or idx.last_screened() != 0
+    assert np.abs(s - os_).max() <= 1e-4 * max(1.0, np.abs(os_).max())
+    assert (r == or_).mean() > 0.999
+    idx.close()
