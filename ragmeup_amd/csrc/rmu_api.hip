@@ -440,7 +440,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         bool done = false;
         static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 128;
         if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && k <= 16 && idx->n > 0 &&
-            idx->xnorm_max > 0.f && idx->xnorm_max < 1.0e4f) {
+            idx->xnorm_max > 0.f && idx->xnorm_max < 500.f) {   // fp16(64*x) must not overflow
             const int kp = 24;
             ScanLaunch S{};
             S.x = (const float*)idx->split; S.n_rows = idx->n; S.dpad = dpad; S.nq = (int)nb; S.k = kp;

@@ -5,8 +5,9 @@
 // exact kernel's own summation order, guarded by a sufficiency test with fallback to the exact scan.
 //
 // Split image (built at add time, same byte geometry as the fp32 matrix: 1536 B per 384-d row): for every 8
-// consecutive k, [h0..h7 | l0..l7] with h = fp16(x), l = fp16((x - h) * 2^11).  Queries are split the same way.
-//   s~ = sum h.qh  +  2^-11 * sum (h.ql + l.qh)          (3 x v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulate)
+// consecutive k, [h0..h7 | l0..l7] with y = 64*x, h = fp16(y), l = fp16(y - h) (the 2^6 scale keeps l out of the fp16
+// subnormal range for |x| >= ~1e-3; |x| must stay below ~1000).  Queries are split the same way.
+//   4096 * s~ = sum (h.qh + h.ql + l.qh)                  (3 x v_mfma_f32_32x32x16_f16 per 16 k, ONE fp32 accumulator)
 // Error vs the true dot product (unit scale): dropped l.ql and the residual of the 22-bit split are < 1e-6, the
 // fp32 accumulation of 3*384 products is bounded by 1152 * 2^-24 * sum|x_i q_i| <= 6.9e-5; the exact fp32 kernel is
 // itself within 384 * 2^-24 = 2.3e-5 of the truth.  EPS = 1e-4 * |x|max * |q| bounds |s~ - s_fp32| with margin.
@@ -15,6 +16,7 @@
 // of the set, so the exact top-k is inside it.  Otherwise the query is flagged and the caller re-runs the batch on
 // the exact scan.
 #include <cstdlib>
+#include <type_traits>
 #include "rmu_common.h"
 #include "scan_common.h"
 #include "../../include/rmu.h"
@@ -56,16 +58,16 @@ __global__ void k_split_rows(const float* __restrict__ src, char* __restrict__ d
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = s[e];
-        const _Float16 h = (_Float16)x;
+        const float y = s[e] * 64.0f;
+        const _Float16 h = (_Float16)y;
         hi[e] = h;
-        lo[e] = (_Float16)((x - (float)h) * 2048.0f);
+        lo[e] = (_Float16)(y - (float)h);
     }
     *(f16x8*)(dst + gidx * 32) = hi;
     *(f16x8*)(dst + gidx * 32 + 16) = lo;
 }
 
-template <bool LA>
+template <bool LA, int PF>   // PF = L2 prefetch distance in chunks (0 = off)
 __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     using C = ScreenCfg;
     const int lane = threadIdx.x & 63;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         thr_w[lane] = q_ok ? -INFINITY : INFINITY;
     }
     float thr = q_ok ? -INFINITY : INFINITY, thr_loc = thr, thr_g = -INFINITY;
+    float thr_s = thr;                                  // thr * 4096: filter threshold in the accumulator's scale (+-inf here)
     u32* gthr_w = a.gthr + (qt * 4 + w) * 32;
     const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
 
@@ -123,21 +126,38 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         const int i = f / S_U16, p = f % S_U16;
         dma_off[n] = (u32)(i * ROWB + (p ^ (i & 15)) * 16);
     }
+    // L2 prefetch: the 8 query-tile workgroups of an XCD stream the same rows in lock step, so every chunk's first touch
+    // is an HBM miss that all eight wait on.  Each wave therefore touches 48 of the 192 lines of the chunk PF chunks
+    // ahead (one dword per 128-B line, result discarded) so that the LDS-DMA finds its lines in L2.  The load is part
+    // of the chunk's VMEM group, i.e. it is covered by the same counted vmcnt; its destination is one dedicated VGPR.
+    u32 pf_dummy = 0;
+    const int pf_lane = (w * 64 + lane) < 192 ? (w * 64 + lane) : 191;
+    const u32 pf_off = (u32)((pf_lane / 6) * ROWB + (pf_lane % 6) * 128);
     auto issue_chunk = [&](int cc) {
         int tl = cc / S_NCH;
         const int c = cc % S_NCH;
         if (tl >= ntiles) tl = ntiles - 1;
         const char* sbase = (const char*)a.x + ((t0 + tl) * S_RT) * (int64_t)ROWB + c * S_CKB;
         char* slot = ring + (cc % S_RING) * S_SLOT;
+        if (PF > 0) {
+            int tp = (cc + PF) / S_NCH;
+            if (tp >= ntiles) tp = ntiles - 1;
+            const char* pbase = (const char*)a.x + ((t0 + tp) * S_RT) * (int64_t)ROWB + ((cc + PF) % S_NCH) * S_CKB + pf_off;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_dummy) : "v"(pbase));
+        }
 #pragma unroll
         for (int n = 0; n < S_NI; ++n)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
                                              (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
     };
     // A fragments: row j, step t of the chunk: hi unit 4t + 2h, lo unit +1 (physical = logical ^ (row & 15))
-    int abase[4];
+    // (lo unit = hi unit ^ 1, i.e. byte ^ 16: all other address terms have bit 4 clear, so it folds into the base)
+    int abase_hi[4], abase_lo[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) abase[m] = j * S_CKB + (((4 * m + 2 * h) ^ (j & 15)) * 16);
+    for (int m = 0; m < 4; ++m) {
+        abase_hi[m] = j * S_CKB + (((4 * m + 2 * h) ^ (j & 15)) * 16);
+        abase_lo[m] = abase_hi[m] ^ 16;
+    }
 
     const u32 cnt_addr = lds_addr(cnt_w + j);
     const u32 cand_addr = lds_addr(cand_w + j * C::CAP);
@@ -154,22 +174,24 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
             }
             thr_loc = thr_w[j];
             thr = fmaxf(thr_loc, thr_g);
+            thr_s = thr * 4096.0f;
         }
     };
     struct Frag { f16x8 hi, lo; };
+    // slot_off and t are compile-time at every call site: the address is a base VGPR + an immediate offset
     auto read_frag = [&](int slot_off, int t) -> Frag {
-        const int off = slot_off + abase[t & 3] + (t >> 2) * 256;
         Frag f;
-        f.hi = *(const f16x8*)(ring + off);
-        f.lo = *(const f16x8*)(ring + (off ^ 16));
+        f.hi = *(const f16x8*)(ring + abase_hi[t & 3] + (slot_off + (t >> 2) * 256));
+        f.lo = *(const f16x8*)(ring + abase_lo[t & 3] + (slot_off + (t >> 2) * 256));
         return f;
     };
-    constexpr int WAITN = LA ? S_NI * (S_RING - 3) : S_NI * (S_RING - 2);
+    constexpr int GRP = S_NI + (PF > 0 ? 1 : 0);   // VMEM ops per chunk group
+    constexpr int WAITN = LA ? GRP * (S_RING - 3) : GRP * (S_RING - 2);
 
-    struct Acc { f32x16 a, b; };                       // a: h.qh ; b: 2^11 * (h.ql + l.qh)
-    auto score = [](const Acc& p, int r) { return fmaf(p.b[r], 1.0f / 2048.0f, p.a[r]); };
+    struct Acc { f32x16 a; };                          // 4096 * s~  (rows and queries are both scaled by 2^6)
+    auto score = [](const Acc& p, int r) { return p.a[r] * (1.0f / 4096.0f); };
     u32 pmask = 0, wr_addr = 0, res_pos = 0;
-    auto mask_slot = [&](const Acc& prev, int r) { pmask |= (score(prev, r) > thr) ? (1u << r) : 0u; };
+    auto mask_slot = [&](const Acc& prev, int r) { pmask |= (prev.a[r] > thr_s) ? (1u << r) : 0u; };
     auto slow_begin = [&](u32 bits) {
         const u32 n = __builtin_popcount(pmask & bits);
         asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(res_pos) : "v"(cnt_addr), "v"(n) : "memory");
@@ -187,13 +209,15 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     };
 
     int cc = 0;
+    static_assert(LA && S_RING == 4 && S_NCH == 2, "static ring slots: tile parity p uses slots 2p, 2p+1");
     Frag a_cur;
     a_cur.hi = f16x8{}; a_cur.lo = f16x8{};
-    // one tile: 72 MFMAs into `acc`; the previous tile's scores are filtered in the first gaps (slot r behind MFMA r+1),
-    // then ONE branch (see scan_topk.hip for why)
-    auto tile_body = [&](Acc& acc, Acc& prev, int64_t prev_rbase) {
+    // one tile (PAR = tile parity = which half of the ring it lives in): 72 MFMAs into `acc`; the previous tile's scores
+    // are filtered in the first gaps (slot r behind MFMA r+1), then ONE branch (see scan_topk.hip for why)
+    auto tile_body = [&](auto par_c, Acc& acc, Acc& prev, int64_t prev_rbase) {
+        constexpr int PAR = decltype(par_c)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc.a[r] = 0.f; acc.b[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc.a[r] = 0.f;
         pmask = 0;
 #pragma unroll
         for (int c = 0; c < S_NCH; ++c, ++cc) {
@@ -201,22 +225,21 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
             __builtin_amdgcn_s_barrier();
             if (c == 0) {
                 const u32 go = gt_lds[j];
-                thr_g = (go && a.share_thr) ? rmu_ord2f(go - 1u) : -INFINITY;
+                thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
                 thr = fmaxf(thr_loc, thr_g);
+                thr_s = thr * 4096.0f;
             }
             if (c == S_NCH - 1)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gthr_w + j),
                                                  (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
             issue_chunk(cc + S_RING - 1);
-            const int slot_off = (cc % S_RING) * S_SLOT;
-            const int next_off = ((cc + 1) % S_RING) * S_SLOT;
-            if (!LA) a_cur = read_frag(slot_off, 0);
+            constexpr int SL0 = 2 * PAR;                       // ring slot of chunk 0 of this tile
+            const int slot_off = (SL0 + c) * S_SLOT;            // compile-time after unrolling
+            const int next_off = ((SL0 + c + 1) % S_RING) * S_SLOT;
 #pragma unroll
             for (int t = 0; t < S_TS; ++t) {
                 const int gs = c * S_TS + t;
-                Frag a_nxt = a_cur;
-                if (t + 1 < S_TS) a_nxt = read_frag(slot_off, t + 1);
-                else if (LA) a_nxt = read_frag(next_off, 0);
+                const Frag a_nxt = (t + 1 < S_TS) ? read_frag(slot_off, t + 1) : read_frag(next_off, 0);
                 if (gs == 6 && __builtin_expect(__any(pmask != 0), 0) && !(a.share_thr & 2)) {
 #pragma unroll
                     for (int g2 = 0; g2 < 2; ++g2) {
@@ -229,48 +252,50 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
                 const f16x8 bh = qh[gs], bl = ql[gs];
                 acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.hi, bh, acc.a, 0, 0, 0);
                 if (gs < 6 && 3 * gs >= 1 && 3 * gs <= 16) mask_slot(prev, 3 * gs - 1);
-                acc.b = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.hi, bl, acc.b, 0, 0, 0);
+                acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.hi, bl, acc.a, 0, 0, 0);
                 if (gs < 6 && 3 * gs + 1 <= 16) mask_slot(prev, 3 * gs);
-                acc.b = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.lo, bh, acc.b, 0, 0, 0);
+                acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.lo, bh, acc.a, 0, 0, 0);
                 if (gs < 6 && 3 * gs + 2 <= 16) mask_slot(prev, 3 * gs + 1);
                 a_cur = a_nxt;
                 if (gs >= 6) {
-                    if (t + 1 < S_TS || LA) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
                 }
             }
         }
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
 
     if (ntiles > 0) {
 #pragma unroll
         for (int c0 = 0; c0 < S_RING - 1; ++c0) issue_chunk(c0);
         if (LA) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_NI * (S_RING - 2)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP * (S_RING - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
             a_cur = read_frag(0, 0);
         }
         Acc accA, accB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { accB.a[r] = -INFINITY; accB.b[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) accB.a[r] = -INFINITY;
         const int64_t lane_r0 = t0 * S_RT + 4 * h;
         auto rb = [&](int t) { return lane_r0 + (int64_t)t * S_RT; };
-        tile_body(accA, accB, rb(-1));
+        tile_body(P0{}, accA, accB, rb(-1));              // tile 0 -> ring slots 0,1
         int tl = 1;
         for (; tl + 1 < ntiles; tl += 2) {
-            tile_body(accB, accA, rb(tl - 1));
-            tile_body(accA, accB, rb(tl));
+            tile_body(P1{}, accB, accA, rb(tl - 1));       // odd tile -> slots 2,3
+            tile_body(P0{}, accA, accB, rb(tl));           // even tile -> slots 0,1
         }
         bool last_in_a = true;
         if (tl < ntiles) {
-            tile_body(accB, accA, rb(tl - 1));
+            tile_body(P1{}, accB, accA, rb(tl - 1));
             last_in_a = false;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) : : "memory");
         {
             Acc last;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { last.a[r] = last_in_a ? accA.a[r] : accB.a[r]; last.b[r] = last_in_a ? accA.b[r] : accB.b[r]; }
+            for (int r = 0; r < 16; ++r) last.a[r] = last_in_a ? accA.a[r] : accB.a[r];
             const int64_t rbl = rb(ntiles - 1);
             pmask = 0;
 #pragma unroll
@@ -368,18 +393,23 @@ int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s)
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
+template <bool LA, int PF>
+static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
     static bool attr = false;
-    static const bool la = getenv("RMU_SCREEN_LA") != nullptr;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)scan_screen_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ScreenCfg::LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)scan_screen_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ScreenCfg::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)scan_screen_kernel<LA, PF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ScreenCfg::LDS_BYTES) != hipSuccess)
             return RMU_E_HIP;
         attr = true;
     }
-    if (la) hipLaunchKernelGGL(scan_screen_kernel<true>, dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
-    else hipLaunchKernelGGL(scan_screen_kernel<false>, dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
+    hipLaunchKernelGGL((scan_screen_kernel<LA, PF>), dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+
+int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
+    // L2 software prefetch measured neutral-to-negative (26.3 -> 27.2 ms): off by default, RMU_SCREEN_PF=8 enables it
+    static const int pf = getenv("RMU_SCREEN_PF") ? atoi(getenv("RMU_SCREEN_PF")) : 0;
+    return pf > 0 ? screen_launch_cfg<true, 8>(p, s) : screen_launch_cfg<true, 0>(p, s);
 }
 
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float eps_unit,
