@@ -70,6 +70,12 @@ int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, int6
  * `col.query(expr="pk in [...]", output_fields=[vector])` round trip (RAGHelper.py:497-499). */
 int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, float* out_host);
 
+/* Persist / restore the corpus matrix (flat file: 64-byte header, liveness bytes, fp32 rows; restart = one H2D copy).
+ * Serves: the Milvus-Lite `data.db` the reference re-opens when vector_store_initial_load is False
+ * (RAGHelper.py:391, :417; .env.template:33,36).  Tombstones survive (poisoned rows are stored as they are). */
+int rmu_index_save(rmu_index_t* idx, const char* path);
+int rmu_index_load(rmu_index_t** out, const char* path);
+
 /* Exact top-k of every query against all live rows.
  *   q [nq, dim] fp32; out_scores [nq, k] fp32, out_rows [nq, k] int64, best first,
  *   order (score, then lower row id); slots beyond the live row count hold (-inf | +inf for L2SQ, -1).
@@ -123,6 +129,20 @@ int rmu_bert_free(rmu_bert_t* m);
 int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens,
                     int batch, int max_len, int mode, float* out_dev, int64_t out_stride,
                     uint64_t hip_stream);
+
+/* ---- WordPiece tokenizer (host C++; the step in front of both encoder forwards) --------------------
+ * Restates transformers' BertTokenizer (BasicTokenizer + WordPiece) as used by sentence-transformers `tokenize`
+ * (HuggingFaceEmbeddings.embed_documents, RAGHelper.py:423-434) and CrossEncoder pair tokenisation
+ * (HuggingFaceCrossEncoder.score, RAGHelper.py:483-486).  vocab_path: one token per line (vocab.txt). */
+typedef struct rmu_tok rmu_tok_t;
+int rmu_tok_create(rmu_tok_t** out, const char* vocab_path, int do_lower_case);
+int rmu_tok_free(rmu_tok_t* tk);
+int rmu_tok_vocab_size(rmu_tok_t* tk);
+/* n UTF-8 strings (texts_b may be NULL, or hold NULL entries, for single sentences).  Host outputs: ids/type_ids
+ * [n, max_len] int32 ([CLS] a [SEP] (b [SEP]), [PAD]-filled; type_ids may be NULL), lens [n].  Single sequences keep
+ * their first max_len-2 tokens; pairs use "longest_first" truncation. */
+int rmu_tok_encode(rmu_tok_t* tk, const char* const* texts_a, const char* const* texts_b, int n, int max_len,
+                   int32_t* ids, int32_t* type_ids, int32_t* lens);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@
 #include <vector>
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 
@@ -364,6 +365,78 @@ extern "C" int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, bo.p, (size_t)n * idx->dim * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// persistence
+// ------------------------------------------------------------------------------------------------
+struct RmuFileHeader {
+    char magic[8];          // "RMUIDX01"
+    int32_t dim, dpad, metric, reserved;
+    int64_t n, n_live;
+    float xnorm_max;
+    char pad[64 - 8 - 16 - 16 - 4];
+};
+static_assert(sizeof(RmuFileHeader) == 64, "header");
+
+extern "C" int rmu_index_save(rmu_index_t* idx, const char* path) {
+    if (!idx || !path) return fail(RMU_E_INVALID, "rmu_index_save: null argument");
+    int rc = g_tls.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_save: stream");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(RMU_E_INVALID, std::string("rmu_index_save: cannot open ") + path);
+    RmuFileHeader h{};
+    memcpy(h.magic, "RMUIDX01", 8);
+    h.dim = idx->dim; h.dpad = idx->dpad; h.metric = idx->metric; h.n = idx->n; h.n_live = idx->n_live; h.xnorm_max = idx->xnorm_max;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    if (idx->n) ok = ok && fwrite(idx->alive.data(), 1, (size_t)idx->n, f) == (size_t)idx->n;
+    const size_t rowb = (size_t)idx->dpad * sizeof(float);
+    const int64_t chunk = 65536;                       // rows per staging copy (<= 192 MiB)
+    std::vector<char> host(ok ? (size_t)std::min<int64_t>(chunk, std::max<int64_t>(idx->n, 1)) * rowb : 0);
+    for (int64_t r0 = 0; ok && r0 < idx->n; r0 += chunk) {
+        const int64_t nr = std::min<int64_t>(chunk, idx->n - r0);
+        if (hipMemcpy(host.data(), (const char*)idx->x + r0 * rowb, (size_t)nr * rowb, hipMemcpyDeviceToHost) != hipSuccess) {
+            fclose(f);
+            return fail(RMU_E_HIP, "rmu_index_save: device read");
+        }
+        ok = fwrite(host.data(), rowb, (size_t)nr, f) == (size_t)nr;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RMU_OK : fail(RMU_E_INVALID, std::string("rmu_index_save: write failed: ") + path);
+}
+
+extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
+    if (!out || !path) return fail(RMU_E_INVALID, "rmu_index_load: null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(RMU_E_INVALID, std::string("rmu_index_load: cannot open ") + path);
+    RmuFileHeader h{};
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RMUIDX01", 8) != 0 || h.n < 0 || h.dim < 1 ||
+        h.dpad != pad_dim(h.dim)) {
+        fclose(f);
+        return fail(RMU_E_INVALID, std::string("rmu_index_load: not an RMUIDX01 file: ") + path);
+    }
+    rmu_index_t* idx = nullptr;
+    int rc = rmu_index_create(&idx, h.dim, h.metric, h.n > 0 ? h.n : 4096);
+    if (rc) { fclose(f); return rc; }
+    idx->alive.assign((size_t)h.n, 1);
+    bool ok = h.n == 0 || fread(idx->alive.data(), 1, (size_t)h.n, f) == (size_t)h.n;
+    const size_t rowb = (size_t)h.dpad * sizeof(float);
+    const int64_t chunk = 65536;
+    std::vector<char> host(ok ? (size_t)std::min<int64_t>(chunk, std::max<int64_t>(h.n, 1)) * rowb : 0);
+    hipStream_t s = g_tls.stream;
+    for (int64_t r0 = 0; ok && r0 < h.n; r0 += chunk) {
+        const int64_t nr = std::min<int64_t>(chunk, h.n - r0);
+        ok = fread(host.data(), rowb, (size_t)nr, f) == (size_t)nr;
+        if (ok && hipMemcpy((char*)idx->x + r0 * rowb, host.data(), (size_t)nr * rowb, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        if (ok && idx->split) ok = rmu_split_launch((const float*)((const char*)idx->x + r0 * rowb), idx->split + r0 * rowb, nr, s) == RMU_OK;
+        if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
+    }
+    fclose(f);
+    if (!ok) { rmu_index_free(idx); return fail(RMU_E_INVALID, std::string("rmu_index_load: truncated or unreadable: ") + path); }
+    idx->n = h.n; idx->n_live = h.n_live; idx->xnorm_max = h.xnorm_max;
+    *out = idx;
     return RMU_OK;
 }
 

@@ -42,8 +42,19 @@ class _EncoderBase:
             encoder = BertEncoder.from_pretrained_dir(model_dir, device=device)
         self.encoder = encoder
         if tokenizer is None and model_dir is not None:
-            from transformers import AutoTokenizer
-            tokenizer = AutoTokenizer.from_pretrained(model_dir)
+            import os
+            vocab = os.path.join(model_dir, "vocab.txt")
+            if os.path.exists(vocab):       # BERT WordPiece checkpoints: the native host tokenizer (rmu_tok_*)
+                from .tokenizer import WordPieceTokenizer
+                lower = True
+                cfg = os.path.join(model_dir, "tokenizer_config.json")
+                if os.path.exists(cfg):
+                    import json
+                    lower = bool(json.load(open(cfg)).get("do_lower_case", True))
+                tokenizer = WordPieceTokenizer(vocab, do_lower_case=lower)
+            else:
+                from transformers import AutoTokenizer
+                tokenizer = AutoTokenizer.from_pretrained(model_dir)
         self.tokenizer = tokenizer
         self.max_seq_length = min(int(max_seq_length), encoder.max_pos)
         self.token_budget = int(token_budget)

@@ -30,6 +30,25 @@ class FlatIndex:
                 "rmu_index_create")
         self._h = h
 
+    # -- persistence ---------------------------------------------------------------------
+    def save(self, path: str):
+        N.check(self._lib.rmu_index_save(self._h, str(path).encode()), "rmu_index_save")
+
+    @classmethod
+    def load(cls, path: str, device: int | None = None) -> "FlatIndex":
+        self = cls.__new__(cls)
+        self._lib = N.lib()
+        if device is not None:
+            N.check(self._lib.rmu_init(int(device)), "rmu_init")
+        h = ctypes.c_void_p()
+        N.check(self._lib.rmu_index_load(ctypes.byref(h), str(path).encode()), "rmu_index_load")
+        self._h = h
+        d = ctypes.c_int()
+        N.check(self._lib.rmu_index_dim(h, ctypes.byref(d)), "rmu_index_dim")
+        self.dim = int(d.value)
+        self.metric = N.METRIC_IP
+        return self
+
     # -- lifecycle ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):

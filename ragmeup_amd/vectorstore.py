@@ -20,6 +20,8 @@ strict '>' so the lowest index wins ties) on the fetch_k vectors gathered from H
 """
 from __future__ import annotations
 
+import os
+import pickle
 import re
 import threading
 from typing import Any, Iterable, Optional
@@ -106,7 +108,8 @@ class MI355XVectorStore:
 
     def __init__(self, embeddings: Any = None, collection_name: str = "LangChainCollection", connection: Any = None,
                  use_jsonb: bool = True, *, embedding_function: Any = None, connection_args: dict | None = None,
-                 drop_old: bool = False, score_mode: str = "l2", dim: int | None = None, device: int | None = None):
+                 drop_old: bool = False, score_mode: str = "l2", dim: int | None = None, device: int | None = None,
+                 auto_persist: bool = False):
         self.embeddings = embeddings if embeddings is not None else embedding_function
         if self.embeddings is None:
             raise ValueError("an Embeddings object is required")
@@ -117,6 +120,7 @@ class MI355XVectorStore:
         self.score_mode = score_mode
         self._device = device
         self._dim = dim
+        self.auto_persist = bool(auto_persist)   # Milvus-Lite writes through to its file; opt in to the same
         self._index: FlatIndex | None = None
         self._lock = threading.RLock()       # writer lock (add/delete); searches take the C-side shared lock
         self._texts: list[str] = []
@@ -136,9 +140,44 @@ class MI355XVectorStore:
             if store is None:
                 store = cls(embeddings=embedding, collection_name=collection_name, connection_args=connection_args, **kw)
                 cls._collections[key] = store
+                # vector_store_initial_load=False: re-open what an earlier run persisted (RAGHelper.py:391, :417)
+                if not drop_old and store._persist_paths() and all(os.path.exists(p) for p in store._persist_paths()):
+                    store.load()
         if documents:
             store.add_documents(documents, ids=ids)
         return store
+
+    # ---- persistence: <uri>.<collection>.rmu (corpus matrix) + .meta.pkl (texts, metadata, pks) -------------
+    def _persist_paths(self) -> tuple[str, str] | None:
+        if not self.connection or not isinstance(self.connection, str) or "://" in self.connection:
+            return None
+        base = f"{self.connection}.{self.collection_name}"
+        return base + ".rmu", base + ".meta.pkl"
+
+    def persist(self) -> bool:
+        paths = self._persist_paths()
+        if paths is None or self._index is None:
+            return False
+        with self._lock:
+            self._index.save(paths[0])
+            with open(paths[1], "wb") as f:
+                pickle.dump({"texts": self._texts, "metas": self._metas, "pks": self._pks, "alive": self._alive,
+                             "dim": self._dim, "score_mode": self.score_mode}, f)
+        return True
+
+    def load(self) -> bool:
+        paths = self._persist_paths()
+        if paths is None:
+            return False
+        with self._lock:
+            with open(paths[1], "rb") as f:
+                m = pickle.load(f)
+            factory = type(self)._index_factory
+            self._index = factory.load(paths[0]) if factory is not None and hasattr(factory, "load") else FlatIndex.load(paths[0], device=self._device)
+            self._texts, self._metas, self._pks, self._alive = m["texts"], m["metas"], m["pks"], m["alive"]
+            self._dim = m["dim"]
+            self._pk_to_row = {pk: r for r, pk in enumerate(self._pks) if self._alive[r]}
+        return True
 
     # ---- helpers ----------------------------------------------------------------------------------------
     _index_factory = None   # tests may inject a fake; the product path always builds the HIP index
@@ -202,6 +241,8 @@ class MI355XVectorStore:
                 self._pks.append(str(i))
                 self._alive.append(True)
                 self._pk_to_row[str(i)] = first + off
+            if self.auto_persist:
+                self.persist()
         return list(ids)
 
     def add_documents(self, documents: list[Document], ids: Optional[list[str]] = None, **kw) -> list[str]:
@@ -233,6 +274,8 @@ class MI355XVectorStore:
                 self._index.remove_rows(rows)
             for r in rows:
                 self._alive[r] = False
+            if rows and self.auto_persist:
+                self.persist()
         return _DeleteResult(len(rows))
 
     # ---- search ---------------------------------------------------------------------------------------------

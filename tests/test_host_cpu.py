@@ -40,6 +40,16 @@ class FakeIndex:
         s, r = O.flat_search(np.asarray(q, np.float32).reshape(-1, self.dim), self.x, k, alive=self.alive)
         return s.astype(np.float32), r
 
+    def save(self, path):
+        np.savez(path + ".npz", x=self.x, alive=self.alive)
+        open(path, "wb").close()
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path + ".npz")
+        self = cls(z["x"].shape[1]); self.x, self.alive = z["x"], z["alive"]
+        return self
+
 
 class HashEmbeddings:
     """Deterministic unit-norm embeddings from text (stands in for the encoder in host-logic tests)."""
@@ -181,3 +191,47 @@ def test_from_documents_reattaches_unless_drop_old():
         assert pg.connection == "postgres://x"                # PGVector-style ctor (RAGHelper.py:399-404)
     finally:
         MI355XVectorStore._index_factory = None
+
+
+def test_persist_and_reopen(tmp_path):
+    """vector_store_initial_load=False re-opens the persisted collection (RAGHelper.py:391, :417)."""
+    MI355XVectorStore._index_factory = FakeIndex
+    try:
+        MI355XVectorStore._collections.clear()
+        uri = str(tmp_path / "data.db")
+        a = MI355XVectorStore.from_documents(_chunks(60), HashEmbeddings(), drop_old=True,
+                                             connection_args={"uri": uri}, collection_name="c",
+                                             ids=[d.metadata["id"] for d in _chunks(60)])
+        a.delete(ids=[_chunks(60)[7].metadata["id"]])
+        assert a.persist()
+        MI355XVectorStore._collections.clear()                      # "new process"
+        b = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False,
+                                             connection_args={"uri": uri}, collection_name="c")
+        assert len(b) == 59
+        hit = b.similarity_search("chunk number 33 of a.pdf", k=1)[0]
+        assert hit.page_content == "chunk number 33 of a.pdf" and hit.metadata["pk"] == _chunks(60)[33].metadata["id"]
+        assert all(d.page_content != "chunk number 7 of a.pdf" for d in b.similarity_search("chunk number 7 of a.pdf", k=5))
+        c = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=True,
+                                             connection_args={"uri": uri}, collection_name="c")
+        assert len(c) == 0                                          # drop_old ignores the files
+    finally:
+        MI355XVectorStore._index_factory = None
+
+
+def test_weighted_rrf_matches_oracle_and_dedupes():
+    from ragmeup_amd.ensemble import MI355XEnsembleRetriever, weighted_reciprocal_rank
+    mk = lambda names: [Document(n, {"src": "x"}) for n in names]
+    sparse, dense = mk(["a", "b", "c", "e"]), mk(["b", "d", "a", "f", "g"])
+    fused = weighted_reciprocal_rank([sparse, dense], [0.5, 0.5])
+    assert [d.page_content for d in fused] == O.weighted_rrf([[d.page_content for d in sparse],
+                                                              [d.page_content for d in dense]], [0.5, 0.5])
+    assert len({d.page_content for d in fused}) == len(fused) == 7
+    assert fused[0].page_content == "b"                              # ranks (2,1) beat (1,3)
+
+    class R:
+        def __init__(self, docs): self.docs = docs
+        def invoke(self, q): return self.docs
+    ens = MI355XEnsembleRetriever([R(sparse), R(dense)], weights=[0.5, 0.5])   # RAGHelper.py:501-503
+    assert [d.page_content for d in ens.invoke("q")] == [d.page_content for d in fused]
+    with pytest.raises(ValueError):
+        weighted_reciprocal_rank([sparse], [0.5, 0.5])

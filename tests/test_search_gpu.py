@@ -361,3 +361,27 @@ def test_screened_search_unnormalised_rows(rmu):
     assert np.abs(s - os_).max() <= 1e-4 * max(1.0, np.abs(os_).max())
     assert (r == or_).mean() > 0.999
     idx.close()
+
+
+def test_save_load_roundtrip(rmu, tmp_path):
+    x = O.make_corpus(25_000)
+    q, _ = O.make_queries(x, 140)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    idx.remove_rows([5, 6, 7])
+    s0, r0 = idx.search(q, 10)
+    path = str(tmp_path / "corpus.rmu")
+    idx.save(path)
+    idx.close()
+    assert os.path.getsize(path) == 64 + 25_000 + 25_000 * 1536
+    idx2 = rmu.FlatIndex.load(path)
+    assert len(idx2) == 25_000
+    s1, r1 = idx2.search(q, 10)                        # screened path on the reloaded (re-split) image
+    assert np.array_equal(r0, r1) and np.array_equal(s0, s1)
+    s2, r2 = idx2.search(q[:5], 10)                    # exact path
+    assert np.array_equal(r2, r0[:5])
+    assert not np.isin(r1, [5, 6, 7]).any()            # tombstones survive
+    assert idx2.add(x[:10]) == 25_000                  # and the index keeps growing
+    idx2.close()
+    with pytest.raises(Exception):
+        rmu.FlatIndex.load(str(tmp_path / "missing.rmu"))
