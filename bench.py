@@ -167,7 +167,7 @@ def main():
     # exact configuration and committed under profiles/; null for any other configuration.
     traffic = None
     if world == 1 and N == 10_000_000 and D == 384 and K == 10 and B in (1024, 1):
-        traffic = {1024: 2 * 7.865e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
+        traffic = {1024: 2 * 7.881e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
     path = "exact-f32"
     if all(v > 0 for v in screened):
         # answered by the fp16 hi/lo screening scan (3 f16 MFMAs per 16 k) + exact fp32 re-score of 24 candidates;
@@ -175,7 +175,7 @@ def main():
         path = "screen-f16x3+rescore-f32"
         kname = "scan_screen_kernel<LA,PF=0> (D=384, 128 queries/WG, ring 4 x 24 KiB)"
         f_mfma = ach_tf / PEAK_F16_MFMA_TFLOPS
-        traffic = 2 * 2.188e7 * 1024 + 1.708e4 * 1024 if (world == 1 and N == 10_000_000 and B == 1024) else None
+        traffic = 2 * 2.254e7 * 1024 + 1.708e4 * 1024 if (world == 1 and N == 10_000_000 and B == 1024) else None
         roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F16_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(f_mfma, 4), "executed_mfma_TFLOPs": round(3 * ach_tf, 2),
                     "executed_mfma_frac": round(3 * f_mfma, 4)}
@@ -185,7 +185,7 @@ def main():
     else:
         roofline = {"kernel": kname, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(f_hbm, 4)}
-    roofline.update({"traffic": traffic, "traffic_source": "profiles/r01_summary.md" if traffic else None,
+    roofline.update({"traffic": traffic, "traffic_source": "profiles/r01_pmc_means.csv (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024)" if traffic else None,
                      "kernel_ms": round(scan_avg_ms, 4), "algorithmic_bytes": bytes_alg, "algorithmic_flops": flops,
                      "path": path, "algorithmic_TFLOPs": round(ach_tf, 2),
                      "hbm_algorithmic_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(f_hbm, 4), "launch": geom})

@@ -542,7 +542,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                 int hflag = 0;
                 HIP_TRY(hipMemcpyAsync(&hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                t.grid = S.grid; t.block = 256; t.lds = 0; t.passes += 1;
+                t.grid = S.grid; t.block = 256; t.lds = rmu_screen_lds_bytes(); t.passes += 1;
                 t.screened = hflag == 0 ? 1 : -hflag;   // >0: answered by the screen; <0: that many queries fell back
                 if (timed) { float ms = 0.f; if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms; }
                 done = hflag == 0;

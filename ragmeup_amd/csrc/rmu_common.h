@@ -118,7 +118,8 @@ int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int
 int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, hipStream_t s);
 // fp16 hi/lo screening path (scan_screen.hip)
 int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> split image
-int rmu_screen_launch(const ScanLaunch* p, hipStream_t s);                              // x/q = split images, k = K'
+int rmu_screen_launch(const ScanLaunch* p, hipStream_t s);                             // x/q = split images, k = K'
+int rmu_screen_lds_bytes();
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float eps_unit,
                        int64_t row_base, float* out_s, int64_t* out_r, int* flagged, hipStream_t s);
 int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,

@@ -406,6 +406,8 @@ static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
+int rmu_screen_lds_bytes() { return ScreenCfg::LDS_BYTES; }
+
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     // L2 software prefetch measured neutral-to-negative (26.3 -> 27.2 ms): off by default, RMU_SCREEN_PF=8 enables it
     static const int pf = getenv("RMU_SCREEN_PF") ? atoi(getenv("RMU_SCREEN_PF")) : 0;
