@@ -70,8 +70,8 @@ struct Buf {
 };
 struct Tls {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm, fbq, fb_s, fb_r, fb_i;
     bool timing = false;
     float scan_ms = -1.f, search_ms = -1.f;
     int grid = 0, block = 0, lds = 0, passes = 0, screened = 0;
@@ -145,6 +145,15 @@ __global__ void k_gather_rows(const float* x, int dpad, int dim, const int64_t* 
     for (int c = threadIdx.x; c < dim; c += blockDim.x) out[r * dim + c] = row[c];
 }
 
+// results of the re-run queries back into the batch outputs: dst[(pos[i]) * k + c] = src[i * k + c]
+__global__ void k_scatter_results(const float* src_s, const int64_t* src_r, const int64_t* pos, int64_t n, int k,
+                                  float* dst_s, int64_t* dst_r) {
+    const int64_t i = blockIdx.x;
+    if (i >= n || (int)threadIdx.x >= k) return;
+    dst_s[pos[i] * k + threadIdx.x] = src_s[i * k + threadIdx.x];
+    dst_r[pos[i] * k + threadIdx.x] = src_r[i * k + threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------------
@@ -152,8 +161,9 @@ struct rmu_index {
     int dim = 0, dpad = 0, metric = 0;
     int64_t n = 0, cap = 0, n_live = 0;
     float* x = nullptr;
-    char* split = nullptr;          // fp16 hi/lo image of x (screening pass), same byte geometry; nullptr = disabled
+    char* split = nullptr;          // fp16(64 x) image of x (screening pass), 768 B per row; nullptr = disabled
     float xnorm_max = 0.f;          // max row norm (bounds the screening error)
+    float dx_max = 0.f;             // max row norm of (x - screening image): the measured rounding error
     std::vector<uint8_t> alive;
     std::shared_mutex mu;
 };
@@ -187,14 +197,14 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
         return fail(RMU_E_HIP, "rmu_index_create: zero fill");
     }
     idx->cap = cap;
-    // screening image (2x corpus memory): 384-wide rows only; RMU_SCREEN=0 disables
+    // screening image (+50% corpus memory): 384-wide rows only; RMU_SCREEN=0 disables
     static const bool screen_on = !(getenv("RMU_SCREEN") && atoi(getenv("RMU_SCREEN")) == 0);
     if (screen_on && idx->dpad == 384) {
-        if (hipMalloc((void**)&idx->split, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float)) != hipSuccess) {
+        if (hipMalloc((void**)&idx->split, (size_t)(cap + kSlackRows) * RMU_IMG_ROW_BYTES) != hipSuccess) {
             idx->split = nullptr;   // not fatal: exact path only
             (void)hipGetLastError();
         } else {
-            (void)hipMemsetAsync(idx->split, 0, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float), g_tls.stream);
+            (void)hipMemsetAsync(idx->split, 0, (size_t)(cap + kSlackRows) * RMU_IMG_ROW_BYTES, g_tls.stream);
             (void)hipStreamSynchronize(g_tls.stream);
         }
     }
@@ -246,7 +256,7 @@ static int grow(rmu_index* idx, int64_t need) {
     HIP_TRY(hipStreamSynchronize(s));
     if (idx->split) {
         char* ns = nullptr;
-        const size_t rowb = (size_t)idx->dpad * sizeof(float);
+        const size_t rowb = RMU_IMG_ROW_BYTES;
         if (hipMalloc((void**)&ns, (size_t)(cap + kSlackRows) * rowb) == hipSuccess) {
             HIP_TRY(hipMemsetAsync(ns + idx->n * rowb, 0, (size_t)(cap + kSlackRows - idx->n) * rowb, s));
             if (idx->n) HIP_TRY(hipMemcpyAsync(ns, idx->split, (size_t)idx->n * rowb, hipMemcpyDeviceToDevice, s));
@@ -262,6 +272,37 @@ static int grow(rmu_index* idx, int64_t need) {
     (void)hipFree(idx->x);
     idx->x = nx;
     idx->cap = cap;
+    return RMU_OK;
+}
+
+// after `n` rows at `dst` were converted into the screening image: refresh |x|max and the measured image error |dx|max
+static int update_image_stats(rmu_index_t* idx, const float* dst, int64_t n, hipStream_t s) {
+    Buf& nb = g_tls.nrm;
+    if (nb.ensure((size_t)n * sizeof(float) + 16)) return fail(RMU_E_OOM, "rmu_index_add: norm workspace");
+    unsigned* mx = (unsigned*)((char*)nb.p + (size_t)n * sizeof(float));
+    unsigned hmx = 0;
+    float f;
+    if (idx->metric == RMU_METRIC_COSINE) {
+        idx->xnorm_max = 1.0f;
+    } else {
+        HIP_TRY(hipMemsetAsync(mx, 0, sizeof(unsigned), s));
+        hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, const_cast<float*>(dst), idx->dpad, n, 0, (float*)nb.p);
+        hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
+        HIP_TRY(hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(&f, &hmx, 4);
+        f = sqrtf(f);
+        if (f > idx->xnorm_max) idx->xnorm_max = f;
+    }
+    HIP_TRY(hipMemsetAsync(mx, 0, sizeof(unsigned), s));
+    int rc = rmu_img_err_launch(dst, n, (float*)nb.p, s);
+    if (rc) return fail(rc, "rmu_index_add: image error");
+    hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
+    HIP_TRY(hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    memcpy(&f, &hmx, 4);
+    f = sqrtf(f) * 1.0001f;
+    if (f > idx->dx_max) idx->dx_max = f;
     return RMU_OK;
 }
 
@@ -290,24 +331,10 @@ extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int
         HIP_TRY(hipGetLastError());
     }
     if (idx->split) {
-        rc = rmu_split_launch(dst, idx->split + (size_t)idx->n * idx->dpad * sizeof(float), n, s);
+        rc = rmu_split_launch(dst, idx->split + (size_t)idx->n * RMU_IMG_ROW_BYTES, n, s);
         if (rc) return fail(rc, "rmu_index_add: split image");
-        if (idx->metric == RMU_METRIC_COSINE) {
-            idx->xnorm_max = 1.0f;
-        } else {
-            Buf& nb = g_tls.nrm;
-            if (nb.ensure((size_t)n * sizeof(float) + 16)) return fail(RMU_E_OOM, "rmu_index_add: norm workspace");
-            unsigned* mx = (unsigned*)((char*)nb.p + (size_t)n * sizeof(float));
-            HIP_TRY(hipMemsetAsync(mx, 0, sizeof(unsigned), s));
-            hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dst, idx->dpad, n, 0, (float*)nb.p);
-            hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
-            unsigned hmx = 0;
-            HIP_TRY(hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            float f; memcpy(&f, &hmx, 4);
-            f = sqrtf(f);
-            if (f > idx->xnorm_max) idx->xnorm_max = f;
-        }
+        rc = update_image_stats(idx, dst, n, s);
+        if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(s));
     idx->alive.resize((size_t)(idx->n + n), 1);
@@ -337,7 +364,7 @@ extern "C" int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int6
     hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, idx->x, idx->dpad,
                        (const int64_t*)b.p, (int64_t)todo.size());
     if (idx->split)   // fp32 NaN pattern = one fp16 NaN per pair: every screening score of the row is NaN as well
-        hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, (float*)idx->split, idx->dpad,
+        hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, (float*)idx->split, RMU_IMG_ROW_BYTES / 4,
                            (const int64_t*)b.p, (int64_t)todo.size());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -430,12 +457,14 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
         const int64_t nr = std::min<int64_t>(chunk, h.n - r0);
         ok = fread(host.data(), rowb, (size_t)nr, f) == (size_t)nr;
         if (ok && hipMemcpy((char*)idx->x + r0 * rowb, host.data(), (size_t)nr * rowb, hipMemcpyHostToDevice) != hipSuccess) ok = false;
-        if (ok && idx->split) ok = rmu_split_launch((const float*)((const char*)idx->x + r0 * rowb), idx->split + r0 * rowb, nr, s) == RMU_OK;
+        if (ok && idx->split) ok = rmu_split_launch((const float*)((const char*)idx->x + r0 * rowb), idx->split + r0 * RMU_IMG_ROW_BYTES, nr, s) == RMU_OK;
+        if (ok && idx->split) ok = update_image_stats(idx, (const float*)((const char*)idx->x + r0 * rowb), nr, s) == RMU_OK;
         if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
     }
     fclose(f);
     if (!ok) { rmu_index_free(idx); return fail(RMU_E_INVALID, std::string("rmu_index_load: truncated or unreadable: ") + path); }
-    idx->n = h.n; idx->n_live = h.n_live; idx->xnorm_max = h.xnorm_max;
+    idx->n = h.n; idx->n_live = h.n_live;
+    if (h.xnorm_max > idx->xnorm_max) idx->xnorm_max = h.xnorm_max;
     *out = idx;
     return RMU_OK;
 }
@@ -482,25 +511,6 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             }
             qdev = (const float*)t.q.p;
         }
-        // ---- plan + workspace ------------------------------------------------------------------------
-        ScanLaunch L{};
-        L.x = idx->x; L.n_rows = idx->n; L.dpad = dpad; L.q = qdev; L.nq = (int)nb; L.k = k;
-        static u64* g_dbg = nullptr;
-        if (getenv("RMU_SCAN_EXP") && atoi(getenv("RMU_SCAN_EXP")) == 7 && !g_dbg) { (void)hipMalloc((void**)&g_dbg, 128); }
-        if (g_dbg) (void)hipMemsetAsync(g_dbg, 0, 128, s);
-        L.dbg = g_dbg;
-        rc = rmu_scan_plan(&L);
-        if (rc) return fail(rc, "rmu_index_search: no scan geometry for this (dim, k)");
-        const size_t pbytes = (size_t)L.parts * nb * k * sizeof(u64);
-        if (t.partial.ensure(pbytes)) return fail(RMU_E_OOM, "rmu_index_search: partial workspace");
-        L.partial = (u64*)t.partial.p;
-        // shared per-query thresholds: padded to whole 128-query tiles, zero = no bound yet
-        const size_t gbytes = (size_t)((nb + 127) / 128 * 128 + 64) * sizeof(u32);
-        if (t.gthr.ensure(gbytes)) return fail(RMU_E_OOM, "rmu_index_search: threshold workspace");
-        HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
-        L.gthr = (u32*)t.gthr.p;
-        static const int share = getenv("RMU_NO_SHARED_THR") ? 0 : 1;
-        L.share_thr = share;
         float* d_s = out_scores + q0 * k;
         int64_t* d_r = out_rows + q0 * k;
         if (!out_dev) {
@@ -509,64 +519,131 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             d_s = (float*)t.out_s.p;
             d_r = (int64_t*)t.out_r.p;
         }
-        // ---- screened path: fp16 hi/lo scan proposes K' = 24 candidates, exact fp32 re-score decides -------------
+        static u64* g_dbg = nullptr;
+        if (getenv("RMU_SCAN_EXP") && atoi(getenv("RMU_SCAN_EXP")) == 7 && !g_dbg) { (void)hipMalloc((void**)&g_dbg, 128); }
+        if (g_dbg) (void)hipMemsetAsync(g_dbg, 0, 128, s);
+        static const int share = getenv("RMU_NO_SHARED_THR") ? 0 : 1;
+        bool exact_timed = false;
+        // ---- the exact fp32 fused scan + merge of `nqq` device queries into (os, orr) --------------------------------
+        auto exact_scan = [&](const float* qd, int64_t nqq, float* os, int64_t* orr) -> int {
+            ScanLaunch L{};
+            L.x = idx->x; L.n_rows = idx->n; L.dpad = dpad; L.q = qd; L.nq = (int)nqq; L.k = k; L.dbg = g_dbg;
+            int rc2 = rmu_scan_plan(&L);
+            if (rc2) return fail(rc2, "rmu_index_search: no scan geometry for this (dim, k)");
+            const size_t pbytes = (size_t)L.parts * nqq * k * sizeof(u64);
+            if (t.partial.ensure(pbytes)) return fail(RMU_E_OOM, "rmu_index_search: partial workspace");
+            L.partial = (u64*)t.partial.p;
+            // shared per-query thresholds: padded to whole 128-query tiles, zero = no bound yet
+            const size_t gbytes = (size_t)((nqq + 127) / 128 * 128 + 64) * sizeof(u32);
+            if (t.gthr.ensure(gbytes)) return fail(RMU_E_OOM, "rmu_index_search: threshold workspace");
+            HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
+            L.gthr = (u32*)t.gthr.p;
+            L.share_thr = share;
+            if (idx->n > 0) {
+                if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
+                rc2 = rmu_scan_launch(&L, s);
+                if (rc2) return fail(rc2, std::string("rmu_index_search: scan launch: ") + hipGetErrorString(hipGetLastError()));
+                if (timed) { HIP_TRY(hipEventRecord(t.ev[3], s)); exact_timed = true; }
+                t.grid = L.grid; t.block = 256; t.lds = L.lds_bytes; t.passes += 1;
+            } else {
+                HIP_TRY(hipMemsetAsync(L.partial, 0, pbytes, s));
+            }
+            const int64_t skeys = (int64_t)32 * nqq * k;
+            u64* scratch = (L.parts >= 64 && nqq <= 1024 && !t.mscratch.ensure((size_t)skeys * sizeof(u64))) ? (u64*)t.mscratch.p : nullptr;
+            rc2 = rmu_merge_keys_launch2(L.partial, L.parts, nqq, k, row_base, 0, nullptr, os, orr, scratch, skeys, s);
+            if (rc2) return fail(rc2, "rmu_index_search: merge launch");
+            return RMU_OK;
+        };
+        // ---- screened path: fp16 scan proposes K' = 32 candidates, exact fp32 re-score decides -------------------------
         bool done = false;
         static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 128;
+        static const int pre_den = getenv("RMU_SCREEN_PRE") ? atoi(getenv("RMU_SCREEN_PRE")) : 12;   // pre-pass = n / pre_den rows (0 = off)
         if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && k <= 16 && idx->n > 0 &&
             idx->xnorm_max > 0.f && idx->xnorm_max < 500.f) {   // fp16(64*x) must not overflow
-            const int kp = 24;
-            ScanLaunch S{};
-            S.x = (const float*)idx->split; S.n_rows = idx->n; S.dpad = dpad; S.nq = (int)nb; S.k = kp;
+            const int kp = 32;
+            // pre-pass over the first n/12 rows: its merged K'-th best seeds the shared thresholds of the main pass, which
+            // then starts with the bound a cold chunk would only reach after ~n/12 * (chunks) rows
+            const int64_t nA = (pre_den > 0 && idx->n >= (1 << 20)) ? (idx->n / pre_den) / 32 * 32 : 0;
+            ScanLaunch A{}, S{};
+            S.x = (const float*)idx->split; S.row0 = nA; S.n_rows = idx->n - nA; S.dpad = dpad; S.nq = (int)nb; S.k = kp;
             rc = rmu_scan_plan(&S);
-            if (!rc && S.wq == 4 && S.kv == 0) {
-                const size_t sp = (size_t)S.parts * nb * kp * sizeof(u64);
-                if (t.partial.ensure(sp) || t.qsplit.ensure((size_t)nb * dpad * sizeof(float)) ||
-                    t.ckeys.ensure((size_t)nb * kp * sizeof(u64)) || t.flag.ensure(16))
+            if (!rc && nA > 0) {
+                A = S; A.row0 = 0; A.n_rows = nA;
+                rc = rmu_scan_plan(&A);
+            }
+            if (!rc && S.wq == 4 && S.kv == 0 && (nA == 0 || (A.wq == 4 && A.kv == 0))) {
+                const int parts_total = S.parts + (nA > 0 ? A.parts : 0);
+                const size_t sp = (size_t)parts_total * nb * kp * sizeof(u64);
+                const size_t gbytes = (size_t)((nb + 127) / 128 * 128 + 64) * sizeof(u32);
+                if (t.partial.ensure(sp) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) || t.gthr.ensure(gbytes) ||
+                    t.ckeys.ensure((size_t)nb * kp * sizeof(u64)) || t.flag.ensure((size_t)(nb + 1) * sizeof(int)))
                     return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
-                L.partial = (u64*)t.partial.p;   // ensure() may have moved the buffer; the exact fallback uses it too
-                S.partial = (u64*)t.partial.p; S.gthr = (u32*)t.gthr.p; S.share_thr = L.share_thr | ((getenv("RMU_SCREEN_NOFILTER") != nullptr) ? 2 : 0); S.dbg = nullptr;
-                S.q = (const float*)t.qsplit.p;
+                const int sflags = share | ((getenv("RMU_SCREEN_NOFILTER") != nullptr) ? 2 : 0);
+                u64* pA = (u64*)t.partial.p;
+                u64* pS = pA + (nA > 0 ? (size_t)A.parts * nb * kp : 0);
+                S.partial = pS; S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = nullptr; S.q = (const float*)t.qsplit.p;
+                HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
                 HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
                 rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
-                if (rc) return fail(rc, "rmu_index_search: query split");
+                if (rc) return fail(rc, "rmu_index_search: query conversion");
+                if (nA > 0) {
+                    A.partial = pA; A.gthr = S.gthr; A.share_thr = sflags; A.dbg = nullptr; A.q = S.q;
+                    if (timed) HIP_TRY(hipEventRecord(t.ev[4], s));
+                    rc = rmu_screen_launch(&A, s);
+                    if (rc) return fail(rc, "rmu_index_search: screening pre-pass launch");
+                    if (timed) HIP_TRY(hipEventRecord(t.ev[5], s));
+                    rc = rmu_merge_to_keys_launch(pA, A.parts, nb, kp, (u64*)t.ckeys.p, s);
+                    if (!rc) rc = rmu_seed_thr_launch((const u64*)t.ckeys.p, kp, nb, S.gthr, s);
+                    if (rc) return fail(rc, "rmu_index_search: threshold seeding");
+                }
                 if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
                 rc = rmu_screen_launch(&S, s);
                 if (rc) return fail(rc, "rmu_index_search: screening launch");
                 if (timed) HIP_TRY(hipEventRecord(t.ev[3], s));
-                rc = rmu_merge_to_keys_launch(S.partial, S.parts, nb, kp, (u64*)t.ckeys.p, s);
+                rc = rmu_merge_to_keys_launch(pA, parts_total, nb, kp, (u64*)t.ckeys.p, s);
                 if (rc) return fail(rc, "rmu_index_search: screening merge");
-                // |s~ - s_fp32| <= 1e-4 * |x|max * |q| (derivation in scan_screen.hip)
-                rc = rmu_rescore_launch((const u64*)t.ckeys.p, kp, idx->x, qdev, nb, k, 1.0e-4f * idx->xnorm_max, row_base, d_s, d_r,
+                // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip)
+                rc = rmu_rescore_launch((const u64*)t.ckeys.p, kp, idx->x, qdev, nb, k, idx->xnorm_max, idx->dx_max, row_base, d_s, d_r,
                                         (int*)t.flag.p, s);
                 if (rc) return fail(rc, "rmu_index_search: re-score launch");
                 int hflag = 0;
                 HIP_TRY(hipMemcpyAsync(&hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                t.grid = S.grid; t.block = 256; t.lds = rmu_screen_lds_bytes(); t.passes += 1;
-                t.screened = hflag == 0 ? 1 : -hflag;   // >0: answered by the screen; <0: that many queries fell back
-                if (timed) { float ms = 0.f; if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms; }
+                t.grid = S.grid; t.block = 256; t.lds = rmu_screen_lds_bytes(); t.passes += nA > 0 ? 2 : 1;
+                t.screened = hflag == 0 ? 1 : -hflag;   // >0: answered by the screen; <0: that many queries were re-run exactly
+                if (timed) {
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms;
+                    if (nA > 0 && hipEventElapsedTime(&ms, t.ev[4], t.ev[5]) == hipSuccess) scan_total += ms;
+                }
                 done = hflag == 0;
-                if (done) HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));   // (kept tidy for the next block)
-                else HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));        // exact scan below restarts the thresholds
+                if (!done && hflag <= nb / 8) {
+                    // few queries failed the sufficiency test: re-run only those on the exact scan and patch their rows in
+                    std::vector<int> hf((size_t)nb);
+                    HIP_TRY(hipMemcpy(hf.data(), (const int*)t.flag.p + 1, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost));
+                    std::vector<int64_t> pos;
+                    for (int64_t i = 0; i < nb; ++i) if (hf[(size_t)i]) pos.push_back(i);
+                    const int64_t nf = (int64_t)pos.size();
+                    if (t.fb_i.ensure((size_t)nf * sizeof(int64_t)) || t.fbq.ensure((size_t)nf * dpad * sizeof(float)) ||
+                        t.fb_s.ensure((size_t)nf * k * sizeof(float)) || t.fb_r.ensure((size_t)nf * k * sizeof(int64_t)))
+                        return fail(RMU_E_OOM, "rmu_index_search: re-run workspace");
+                    HIP_TRY(hipMemcpyAsync(t.fb_i.p, pos.data(), (size_t)nf * sizeof(int64_t), hipMemcpyHostToDevice, s));
+                    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)nf), dim3(128), 0, s, qdev, dpad, dpad, (const int64_t*)t.fb_i.p, nf,
+                                       (float*)t.fbq.p);
+                    HIP_TRY(hipGetLastError());
+                    rc = exact_scan((const float*)t.fbq.p, nf, (float*)t.fb_s.p, (int64_t*)t.fb_r.p);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(k_scatter_results, dim3((unsigned)nf), dim3(128), 0, s, (const float*)t.fb_s.p,
+                                       (const int64_t*)t.fb_r.p, (const int64_t*)t.fb_i.p, nf, k, d_s, d_r);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipStreamSynchronize(s));   // pos[] (host) and the fb_* buffers are reused by the next block
+                    done = true;
+                }
             }
         }
-        // ---- fused scan ------------------------------------------------------------------------------
-        if (done) {
-            // outputs are already in d_s / d_r
-        } else if (idx->n > 0) {
-            if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
-            rc = rmu_scan_launch(&L, s);
-            if (rc) return fail(rc, std::string("rmu_index_search: scan launch: ") + hipGetErrorString(hipGetLastError()));
-            if (timed) HIP_TRY(hipEventRecord(t.ev[3], s));
-            t.grid = L.grid; t.block = 256; t.lds = L.lds_bytes; t.passes += 1;
-        } else {
-            HIP_TRY(hipMemsetAsync(L.partial, 0, pbytes, s));
-        }
         if (!done) {
-        const int64_t skeys = (int64_t)32 * nb * k;
-        u64* scratch = (L.parts >= 64 && nb <= 1024 && !t.mscratch.ensure((size_t)skeys * sizeof(u64))) ? (u64*)t.mscratch.p : nullptr;
-        rc = rmu_merge_keys_launch2(L.partial, L.parts, nb, k, row_base, 0, nullptr, d_s, d_r, scratch, skeys, s);
-        if (rc) return fail(rc, "rmu_index_search: merge launch");
+            rc = exact_scan(qdev, nb, d_s, d_r);
+            if (rc) return rc;
         }
         if (!out_dev) {
             HIP_TRY(hipMemcpyAsync(out_scores + q0 * k, d_s, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -575,7 +652,8 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // workspace is reused by the next query block (and host outputs must land): drain per block
         if (!hip_stream || q0 + nb < nq || !out_dev) HIP_TRY(hipStreamSynchronize(s));
         if (g_dbg) { u64 h[16]; (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg] slow_tiles=%llu compactions=%llu appends=%llu tiles=%llu slow_clk=%llu compact_clk=%llu addwait_clk=%llu endwait_clk=%llu check_clk=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]); }
-        if (timed && idx->n > 0 && !done) {
+        if (exact_timed) {
+            HIP_TRY(hipEventSynchronize(t.ev[3]));
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms;
         }

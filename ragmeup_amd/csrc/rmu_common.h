@@ -94,6 +94,7 @@ __device__ __forceinline__ void rmu_bitonic_merge_desc(u64 (&key)[NPL], int lane
 struct ScanLaunch {
     const float* x;        // [n_rows, dpad] fp32 row-major, HBM resident
     int64_t n_rows;
+    int64_t row0;          // screening scan only: first row of the range (rows [row0, row0 + n_rows) of the image)
     int dpad;              // row stride in floats (multiple of 96)
     const float* q;        // [nq, dpad] fp32 device (padded like the rows)
     int nq;
@@ -116,11 +117,14 @@ int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int
                            const float* qnorm2, float* out_scores, int64_t* out_rows, u64* scratch, int64_t scratch_keys,
                            hipStream_t s);
 int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, hipStream_t s);
-// fp16 hi/lo screening path (scan_screen.hip)
-int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> split image
+// fp16 screening path (scan_screen.hip)
+#define RMU_IMG_ROW_BYTES 768                          /* fp16(64 x) image of a 384-d row */
+int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> fp16 image
+int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStream_t s); // K'-th best of a pre-pass -> gthr
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s);                             // x/q = split images, k = K'
 int rmu_screen_lds_bytes();
-int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float eps_unit,
+int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s);       // |x - image|^2 per row
+int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
                        int64_t row_base, float* out_s, int64_t* out_r, int* flagged, hipStream_t s);
 int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
                            float* out_scores, int64_t* out_rows, u64* scratch_keys, hipStream_t s);

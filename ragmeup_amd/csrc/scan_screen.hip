@@ -1,20 +1,26 @@
-// scan_screen.hip -- fp16 hi/lo SCREENING scan + exact fp32 re-scoring (gfx950 / MI355X only).
+// scan_screen.hip -- fp16 SCREENING scan + exact fp32 re-scoring (gfx950 / MI355X only).
 //
-// Same job as scan_topk.hip (the FLAT search behind server/RAGHelper.py:497-499), 5x cheaper in MFMA time, and
+// Same job as scan_topk.hip (the FLAT search behind server/RAGHelper.py:497-499) at a fraction of the MFMA time, and
 // still exact: the screen only PROPOSES candidates; the returned ids/scores come from an fp32 re-score in the
-// exact kernel's own summation order, guarded by a sufficiency test with fallback to the exact scan.
+// exact kernel's own summation order, guarded by a per-query sufficiency test; queries that fail it are answered
+// by the exact scan.
 //
-// Split image (built at add time, same byte geometry as the fp32 matrix: 1536 B per 384-d row): for every 8
-// consecutive k, [h0..h7 | l0..l7] with y = 64*x, h = fp16(y), l = fp16(y - h) (the 2^6 scale keeps l out of the fp16
-// subnormal range for |x| >= ~1e-3; |x| must stay below ~1000).  Queries are split the same way.
-//   4096 * s~ = sum (h.qh + h.ql + l.qh)                  (3 x v_mfma_f32_32x32x16_f16 per 16 k, ONE fp32 accumulator)
-// Error vs the true dot product (unit scale): dropped l.ql and the residual of the 22-bit split are < 1e-6, the
-// fp32 accumulation of 3*384 products is bounded by 1152 * 2^-24 * sum|x_i q_i| <= 6.9e-5; the exact fp32 kernel is
-// itself within 384 * 2^-24 = 2.3e-5 of the truth.  EPS = 1e-4 * |x|max * |q| bounds |s~ - s_fp32| with margin.
-// Sufficiency (per query): with the approximate top-K' (K' = 24) sorted, tau = k-th best s~.  If fewer than K'
+// Screening image (built at add time, HALF the bytes of the fp32 matrix: 768 B per 384-d row): h = fp16(64 * x) in
+// natural k order (the 2^6 scale keeps |x| >= 1e-6 out of the fp16 subnormal range; |x| must stay below ~1000).
+// Queries are converted the same way per call.
+//   4096 * s~ = sum h_x . h_q                    (ONE v_mfma_f32_32x32x16_f16 per 16 k, one fp32 accumulator)
+// Error vs the exact kernel's fp32 score, with dx = x - h_x/64 (row), dq = q - h_q/64 (query), by Cauchy-Schwarz:
+//   |sum (x q - h_x h_q)/4096| <= |dx| |q| + |x| |dq| + |dx| |dq|.
+// |dx|max is MEASURED when rows are added (k_img_err; ~1.7e-4 |x| for real data, 4.9e-4 |x| worst case) and |dq| is
+// measured per query in the re-score kernel, so subnormal flushes and odd value ranges are covered by construction.
+// The fp32 accumulation of 384 exact fp16 products adds <= 408 * 2^-24 = 2.5e-5 |x||q| and the exact kernel is itself
+// within 384 * 2^-24 = 2.3e-5 |x||q| of the true dot product:
+//   EPS(q) = |dx|max |q| + |x|max |dq| + |dx|max |dq| + 5e-5 |x|max |q|          (~4e-4 for unit vectors)
+// Sufficiency (per query): with the approximate top-K' (K' = 32) sorted, tau = k-th best s~.  If fewer than K'
 // candidates exist, or s~[K'-1] < tau - 2*EPS, every row outside the candidate set has an exact score below k rows
-// of the set, so the exact top-k is inside it.  Otherwise the query is flagged and the caller re-runs the batch on
-// the exact scan.
+// of the set, so the exact top-k is inside it.  Otherwise the query is flagged and re-run on the exact scan.
+// (An earlier hi/lo split variant, 3 MFMAs per 16 k with EPS = 1e-4, ran at 25 ms for the 10M x 1024 headline; its
+// ablations showed the LDS/L2 path, not the MFMA pipe, setting the time, which is what halving the bytes attacks.)
 #include <cstdlib>
 #include <type_traits>
 #include "rmu_common.h"
@@ -25,21 +31,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int SD = 384;                 // floats per row (split image: same 1536 B)
-constexpr int ROWB = SD * 4;
+constexpr int SD = 384;                 // floats per row
+constexpr int ROWB = SD * 4;            // fp32 row bytes (re-score)
+constexpr int IMGB = RMU_IMG_ROW_BYTES; // 768: screening-image bytes per row
+static_assert(IMGB == SD * 2, "image geometry");
 constexpr int S_RT = 32;                // rows per tile (4 waves share it, one 32-query group each)
-constexpr int S_CKB = 768;              // bytes per row per chunk (12 steps of 64 B)
-constexpr int S_U16 = S_CKB / 16;       // 48 units
-constexpr int S_NCH = ROWB / S_CKB;     // 2 chunks per tile
-constexpr int S_TS = S_CKB / 64;        // 12 steps per chunk, 3 MFMAs each
-constexpr int S_RING = 4;                // 4 chunks (96 KiB) in flight: the f16 MFMAs are 5x shorter than the f32 ones and
-                                         // two chunks no longer covered the ~4 us loaded L2/HBM latency (35 -> 25 ms)
-constexpr int S_SLOT = S_RT * S_CKB;    // 24 KiB
-constexpr int S_NI = S_RT * S_U16 / 256;  // 6 DMA wave-instructions per wave per chunk
+constexpr int S_U16 = IMGB / 16;        // 48 16-byte units per row
+constexpr int S_TS = SD / 16;           // 24 MFMA steps per tile
+constexpr int S_RING = 4;               // tiles (24 KiB each) in the LDS ring
+constexpr int S_SLOT = S_RT * IMGB;     // 24 KiB
+constexpr int S_NI = S_RT * S_U16 / 256;  // 6 DMA wave-instructions per wave per tile
+constexpr int S_PRE = 4;                // A-fragment prefetch depth in steps (one step is a single 32-cycle MFMA)
 struct ScreenCfg {
-    // K' = 24 candidates per (chunk, query); the overflow check runs twice per tile (<= 16 appends per slot between
-    // checks) and a compaction is due only after 16 further appends: CAP = 24 + 16 + 16
-    static constexpr int CAP = 56, NPL = 1, A = 16;
+    // K' = 32 candidates per (chunk, query); a slow path appends a tile's 16 scores per lane in groups of 6, 6 and 4 (both
+    // lane halves feed the same query slot: <= 12 appends per slot between overflow checks) and a compaction is due only
+    // after 12 further appends: CAP = 32 + 12 + 12
+    static constexpr int CAP = 56, NPL = 1, A = 12;
     static constexpr int RING_BYTES = S_RING * S_SLOT;
     static constexpr int CAND_BYTES = 4 * 32 * CAP * 8;
     static constexpr int TRASH_OFF = RING_BYTES + CAND_BYTES + 4 * 32 * 4 + 4 * 32 * 4;
@@ -50,24 +57,42 @@ static_assert(ScreenCfg::LDS_BYTES <= 160 * 1024, "LDS");
 
 extern __shared__ __attribute__((aligned(16))) char ssm[];
 
-// fp32 rows [n, 384] -> split image [n, 1536 B]; one thread per group of 8 k
+// fp32 rows [n, 384] -> screening image [n, 768 B]; one thread per group of 8 k
 __global__ void k_split_rows(const float* __restrict__ src, char* __restrict__ dst, int64_t n_groups) {
     const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gidx >= n_groups) return;
     const float* s = src + gidx * 8;
-    f16x8 hi, lo;
+    f16x8 hi;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float y = s[e] * 64.0f;
-        const _Float16 h = (_Float16)y;
-        hi[e] = h;
-        lo[e] = (_Float16)(y - (float)h);
-    }
-    *(f16x8*)(dst + gidx * 32) = hi;
-    *(f16x8*)(dst + gidx * 32 + 16) = lo;
+    for (int e = 0; e < 8; ++e) hi[e] = (_Float16)(s[e] * 64.0f);
+    *(f16x8*)(dst + gidx * 16) = hi;
 }
 
-template <bool LA, int PF>   // PF = L2 prefetch distance in chunks (0 = off)
+// gthr[q] <- the K'-th best approximate score of a finished pre-pass (a lower bound of the final K'-th best)
+__global__ void k_seed_thr(const u64* __restrict__ keys, int kp, int64_t nq, u32* __restrict__ gthr) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const u64 kk = keys[q * kp + kp - 1];
+    if (kk) atomicMax(gthr + q, (u32)(kk >> 32));
+}
+
+// err2[r] = |x_r - h_r / 64|^2: the measured rounding error of the screening image, one wave per row
+__global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, int64_t n, float* __restrict__ err2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float* row = x + r * SD;
+    float s = 0.f;
+    for (int c = lane; c < SD; c += 64) {
+        const float d = row[c] - (float)(_Float16)(row[c] * 64.0f) * (1.0f / 64.0f);
+        s = fmaf(d, d, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) err2[r] = s * 1.0001f;   // summation slack
+}
+
+template <int EXP = 0>   // EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads
 __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     using C = ScreenCfg;
     const int lane = threadIdx.x & 63;
@@ -90,6 +115,7 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     int64_t t1 = t0 + a.tiles_per_chunk;
     if (t1 > tiles_total) t1 = tiles_total;
     const int ntiles = (int)(t1 > t0 ? t1 - t0 : 0);
+    const char* img = (const char*)a.x + a.row0 * (int64_t)IMGB;      // rows [row0, row0 + n_rows) of the image
 
     char* ring = ssm;
     u64* cand_w = (u64*)(ssm + C::RING_BYTES) + (size_t)w * 32 * C::CAP;
@@ -97,7 +123,6 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     float* thr_w = (float*)(ssm + C::RING_BYTES + C::CAND_BYTES + 4 * 32 * 4) + w * 32;
     const int q_idx = (qt * 4 + w) * 32 + j;
     const bool q_ok = q_idx < a.nq;
-    ((u32*)(ssm + C::GT_OFF))[w * 64 + lane] = 0u;
     if (lane < 32) {
         cnt_w[lane] = 0;
         thr_w[lane] = q_ok ? -INFINITY : INFINITY;
@@ -106,16 +131,17 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     float thr_s = thr;                                  // thr * 4096: filter threshold in the accumulator's scale (+-inf here)
     u32* gthr_w = a.gthr + (qt * 4 + w) * 32;
     const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
+    auto refresh_gthr = [&]() {   // 4-byte LDS-DMA of this wave's 32 shared thresholds (both lane halves load the same)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gthr_w + j),
+                                         (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
+    };
 
-    // ---- query fragments (split image of the query batch): step T covers k [16T, 16T+16); lane half h owns 8 of them
-    f16x8 qh[SD / 16], ql[SD / 16];
+    // ---- query fragments: step T covers k [16T, 16T+16); lane half h owns 8 of them -----------------------------------
+    f16x8 qh[S_TS];
     {
-        const char* qrow = (const char*)a.q + (size_t)(q_ok ? q_idx : 0) * ROWB + h * 32;
+        const char* qrow = (const char*)a.q + (size_t)(q_ok ? q_idx : 0) * IMGB + h * 16;
 #pragma unroll
-        for (int T = 0; T < SD / 16; ++T) {
-            qh[T] = *(const f16x8*)(qrow + T * 64);
-            ql[T] = *(const f16x8*)(qrow + T * 64 + 16);
-        }
+        for (int T = 0; T < S_TS; ++T) qh[T] = *(const f16x8*)(qrow + T * 32);
     }
 
     // ---- DMA source map: LDS unit f -> row f/48, physical unit f%48 holds logical unit p ^ (row & 15) ---------------
@@ -124,40 +150,46 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     for (int n = 0; n < S_NI; ++n) {
         const int f = (n * 4 + w) * 64 + lane;
         const int i = f / S_U16, p = f % S_U16;
-        dma_off[n] = (u32)(i * ROWB + (p ^ (i & 15)) * 16);
+        dma_off[n] = (u32)(i * IMGB + (p ^ (i & 15)) * 16);
     }
-    // L2 prefetch: the 8 query-tile workgroups of an XCD stream the same rows in lock step, so every chunk's first touch
-    // is an HBM miss that all eight wait on.  Each wave therefore touches 48 of the 192 lines of the chunk PF chunks
-    // ahead (one dword per 128-B line, result discarded) so that the LDS-DMA finds its lines in L2.  The load is part
-    // of the chunk's VMEM group, i.e. it is covered by the same counted vmcnt; its destination is one dedicated VGPR.
-    u32 pf_dummy = 0;
-    const int pf_lane = (w * 64 + lane) < 192 ? (w * 64 + lane) : 191;
-    const u32 pf_off = (u32)((pf_lane / 6) * ROWB + (pf_lane % 6) * 128);
-    auto issue_chunk = [&](int cc) {
-        int tl = cc / S_NCH;
-        const int c = cc % S_NCH;
+    auto issue_tile = [&](int tt) {
+        if (EXP & 1) return;   // ablation: no corpus DMA at all
+        int tl = tt;
         if (tl >= ntiles) tl = ntiles - 1;
-        const char* sbase = (const char*)a.x + ((t0 + tl) * S_RT) * (int64_t)ROWB + c * S_CKB;
-        char* slot = ring + (cc % S_RING) * S_SLOT;
-        if (PF > 0) {
-            int tp = (cc + PF) / S_NCH;
-            if (tp >= ntiles) tp = ntiles - 1;
-            const char* pbase = (const char*)a.x + ((t0 + tp) * S_RT) * (int64_t)ROWB + ((cc + PF) % S_NCH) * S_CKB + pf_off;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_dummy) : "v"(pbase));
-        }
+        const char* sbase = img + ((t0 + tl) * S_RT) * (int64_t)IMGB;
+        char* slot = ring + (tt % S_RING) * S_SLOT;
 #pragma unroll
         for (int n = 0; n < S_NI; ++n)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
                                              (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
     };
-    // A fragments: row j, step t of the chunk: hi unit 4t + 2h, lo unit +1 (physical = logical ^ (row & 15))
-    // (lo unit = hi unit ^ 1, i.e. byte ^ 16: all other address terms have bit 4 clear, so it folds into the base)
-    int abase_hi[4], abase_lo[4];
+    // A fragment of (row j, step t): logical unit 2t + h = 16 (t >> 3) + (2 (t & 7) + h); the XOR swizzle touches the low
+    // four bits only, so eight per-lane bases + an immediate (t >> 3) * 256 address everything
+    int abase[8];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        abase_hi[m] = j * S_CKB + (((4 * m + 2 * h) ^ (j & 15)) * 16);
-        abase_lo[m] = abase_hi[m] ^ 16;
-    }
+    for (int m = 0; m < 8; ++m) abase[m] = j * IMGB + (((2 * m + h) ^ (j & 15)) * 16);
+    f16x8 fr[S_PRE];
+#pragma unroll
+    for (int m = 0; m < S_PRE; ++m) fr[m] = f16x8{};
+    // Fragment reads and the waits on them are inline asm: left to itself hipcc sinks every ds_read to just before the MFMA
+    // that consumes it and waits lgkmcnt(0) there (a 32-cycle MFMA cannot hide an LDS round trip).  The reads keep their
+    // program order (volatile), S_PRE of them are in flight, and `frag_wait` ties the counted wait to the register the MFMA
+    // reads, so the MFMA cannot be scheduled above it.
+    const u32 ring_addr = lds_addr(ring);
+    auto read_frag = [&](f16x8& dst, int slot_off, int t) {
+        if (EXP & 2) {         // ablation: no LDS fragment reads (keep the register live and opaque)
+            asm volatile("" : "+v"(dst));
+            return;
+        }
+        const u32 addr = ring_addr + (u32)(abase[t & 7] + slot_off);
+        if ((t >> 3) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+        else if ((t >> 3) == 1) asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dst) : "v"(addr));
+        else asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(dst) : "v"(addr));
+    };
+    auto frag_wait = [&](f16x8& f) {
+        if (EXP & 2) return;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1));
+    };
 
     const u32 cnt_addr = lds_addr(cnt_w + j);
     const u32 cand_addr = lds_addr(cand_w + j * C::CAP);
@@ -177,16 +209,8 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
             thr_s = thr * 4096.0f;
         }
     };
-    struct Frag { f16x8 hi, lo; };
-    // slot_off and t are compile-time at every call site: the address is a base VGPR + an immediate offset
-    auto read_frag = [&](int slot_off, int t) -> Frag {
-        Frag f;
-        f.hi = *(const f16x8*)(ring + abase_hi[t & 3] + (slot_off + (t >> 2) * 256));
-        f.lo = *(const f16x8*)(ring + abase_lo[t & 3] + (slot_off + (t >> 2) * 256));
-        return f;
-    };
-    constexpr int GRP = S_NI + (PF > 0 ? 1 : 0);   // VMEM ops per chunk group
-    constexpr int WAITN = LA ? GRP * (S_RING - 3) : GRP * (S_RING - 2);
+    constexpr int GRP = S_NI;                              // corpus VMEM ops per tile group
+    constexpr int WAITN = GRP * (S_RING - 3);              // at a tile's barrier only the newest tile may be in flight
 
     struct Acc { f32x16 a; };                          // 4096 * s~  (rows and queries are both scaled by 2^6)
     auto score = [](const Acc& p, int r) { return p.a[r] * (1.0f / 4096.0f); };
@@ -208,107 +232,91 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         check_compact();
     };
 
-    int cc = 0;
-    static_assert(LA && S_RING == 4 && S_NCH == 2, "static ring slots: tile parity p uses slots 2p, 2p+1");
-    Frag a_cur;
-    a_cur.hi = f16x8{}; a_cur.lo = f16x8{};
-    // one tile (PAR = tile parity = which half of the ring it lives in): 72 MFMAs into `acc`; the previous tile's scores
-    // are filtered in the first gaps (slot r behind MFMA r+1), then ONE branch (see scan_topk.hip for why)
-    auto tile_body = [&](auto par_c, Acc& acc, Acc& prev, int64_t prev_rbase) {
-        constexpr int PAR = decltype(par_c)::value;
+    int tt = 0;
+    // one tile: 24 MFMAs into `acc`; the previous tile's 16 scores per lane are filtered in the first gaps (slot r behind
+    // MFMA r+1), then ONE branch (see scan_topk.hip for why).  Fragments run S_PRE steps ahead of the MFMA that eats them.
+    auto tile_body = [&](Acc& acc, Acc& prev, int64_t prev_rbase) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.a[r] = 0.f;
         pmask = 0;
-#pragma unroll
-        for (int c = 0; c < S_NCH; ++c, ++cc) {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
-            __builtin_amdgcn_s_barrier();
-            if (c == 0) {
-                const u32 go = gt_lds[j];
-                thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
-                thr = fmaxf(thr_loc, thr_g);
-                thr_s = thr * 4096.0f;
-            }
-            if (c == S_NCH - 1)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gthr_w + j),
-                                                 (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
-            issue_chunk(cc + S_RING - 1);
-            constexpr int SL0 = 2 * PAR;                       // ring slot of chunk 0 of this tile
-            const int slot_off = (SL0 + c) * S_SLOT;            // compile-time after unrolling
-            const int next_off = ((SL0 + c + 1) % S_RING) * S_SLOT;
-#pragma unroll
-            for (int t = 0; t < S_TS; ++t) {
-                const int gs = c * S_TS + t;
-                const Frag a_nxt = (t + 1 < S_TS) ? read_frag(slot_off, t + 1) : read_frag(next_off, 0);
-                if (gs == 6 && __builtin_expect(__any(pmask != 0), 0) && !(a.share_thr & 2)) {
-#pragma unroll
-                    for (int g2 = 0; g2 < 2; ++g2) {
-                        slow_begin(0xFFu << (8 * g2));
-#pragma unroll
-                        for (int r = 8 * g2; r < 8 * g2 + 8; ++r) slow_slot_r(prev, r, prev_rbase);
-                        slow_end();
-                    }
-                }
-                const f16x8 bh = qh[gs], bl = ql[gs];
-                acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.hi, bh, acc.a, 0, 0, 0);
-                if (gs < 6 && 3 * gs >= 1 && 3 * gs <= 16) mask_slot(prev, 3 * gs - 1);
-                acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.hi, bl, acc.a, 0, 0, 0);
-                if (gs < 6 && 3 * gs + 1 <= 16) mask_slot(prev, 3 * gs);
-                acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur.lo, bh, acc.a, 0, 0, 0);
-                if (gs < 6 && 3 * gs + 2 <= 16) mask_slot(prev, 3 * gs + 1);
-                a_cur = a_nxt;
-                if (gs >= 6) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                }
-            }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const u32 go = gt_lds[j];
+            thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
+            thr = fmaxf(thr_loc, thr_g);
+            thr_s = thr * 4096.0f;
         }
+        refresh_gthr();
+        issue_tile(tt + S_RING - 1);
+        const int cur_off = (tt % S_RING) * S_SLOT, nxt_off = ((tt + 1) % S_RING) * S_SLOT;
+#pragma unroll
+        for (int t = 0; t < S_TS; ++t) {
+            if (t == 18 && __builtin_expect(__any(pmask != 0), 0) && !(a.share_thr & 2)) {
+#pragma unroll
+                for (int g2 = 0; g2 < 3; ++g2) {
+                    constexpr int lo3[4] = {0, 6, 12, 16};
+                    slow_begin(((1u << lo3[g2 + 1]) - 1u) & ~((1u << lo3[g2]) - 1u));
+#pragma unroll
+                    for (int r = lo3[g2]; r < lo3[g2 + 1]; ++r) slow_slot_r(prev, r, prev_rbase);
+                    slow_end();
+                }
+            }
+            frag_wait(fr[t % S_PRE]);
+            acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t % S_PRE], qh[t], acc.a, 0, 0, 0);
+            if (t >= 1 && t <= 16) mask_slot(prev, t - 1);
+            if (t + S_PRE < S_TS) read_frag(fr[t % S_PRE], cur_off, t + S_PRE);
+            else read_frag(fr[t % S_PRE], nxt_off, t + S_PRE - S_TS);
+        }
+        ++tt;
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
 
     if (ntiles > 0) {
+        refresh_gthr();                                    // oldest VMEM op: seeded / already published thresholds
 #pragma unroll
-        for (int c0 = 0; c0 < S_RING - 1; ++c0) issue_chunk(c0);
-        if (LA) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP * (S_RING - 2)) : "memory");
-            __builtin_amdgcn_s_barrier();
-            a_cur = read_frag(0, 0);
-        }
+        for (int c0 = 0; c0 < S_RING - 1; ++c0) issue_tile(c0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP * (S_RING - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) read_frag(fr[m], 0, m);
         Acc accA, accB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB.a[r] = -INFINITY;
-        const int64_t lane_r0 = t0 * S_RT + 4 * h;
+        const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
         auto rb = [&](int t) { return lane_r0 + (int64_t)t * S_RT; };
-        tile_body(P0{}, accA, accB, rb(-1));              // tile 0 -> ring slots 0,1
+        tile_body(accA, accB, rb(-1));
         int tl = 1;
         for (; tl + 1 < ntiles; tl += 2) {
-            tile_body(P1{}, accB, accA, rb(tl - 1));       // odd tile -> slots 2,3
-            tile_body(P0{}, accA, accB, rb(tl));           // even tile -> slots 0,1
+            tile_body(accB, accA, rb(tl - 1));
+            tile_body(accA, accB, rb(tl));
         }
         bool last_in_a = true;
         if (tl < ntiles) {
-            tile_body(P1{}, accB, accA, rb(tl - 1));
+            tile_body(accB, accA, rb(tl - 1));
             last_in_a = false;
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) : : "memory");
+        // the fragment reads issued for a tile that does not exist are still in flight: their registers must stay
+        // allocated until the data has landed (the compiler sees dead values and would reuse the registers under them)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) : : "memory");
         {
             Acc last;
 #pragma unroll
             for (int r = 0; r < 16; ++r) last.a[r] = last_in_a ? accA.a[r] : accB.a[r];
             const int64_t rbl = rb(ntiles - 1);
+            const int64_t row_end = a.row0 + a.n_rows;
             pmask = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 mask_slot(last, r);
-                if (rbl + (r & 3) + 8 * (r >> 2) >= a.n_rows) pmask &= ~(1u << r);
+                if (rbl + (r & 3) + 8 * (r >> 2) >= row_end) pmask &= ~(1u << r);
             }
             if (__any(pmask != 0)) {
 #pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
-                    slow_begin(0xFFu << (8 * g2));
+                for (int g2 = 0; g2 < 3; ++g2) {
+                    constexpr int lo3[4] = {0, 6, 12, 16};
+                    slow_begin(((1u << lo3[g2 + 1]) - 1u) & ~((1u << lo3[g2]) - 1u));
 #pragma unroll
-                    for (int r = 8 * g2; r < 8 * g2 + 8; ++r) slow_slot_r(last, r, rbl);
+                    for (int r = lo3[g2]; r < lo3[g2 + 1]; ++r) slow_slot_r(last, r, rbl);
                     slow_end();
                 }
             }
@@ -337,9 +345,9 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
 // for t in 0..47, c in 0..3: acc = fma(x[8t+c], q[8t+c], acc); acc = fma(x[8t+4+c], q[8t+4+c], acc)
 // (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain; lanes < 32 hold k = 8t+c, lanes >= 32 hold k = 8t+4+c).
 __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, int kp, const float* __restrict__ x,
-                                                 const float* __restrict__ q, int64_t nq, int k, float eps_unit,
+                                                 const float* __restrict__ q, int64_t nq, int k, float xnorm_max, float dx_max,
                                                  int64_t row_base, float* __restrict__ out_s, int64_t* __restrict__ out_r,
-                                                 int* __restrict__ flagged) {
+                                                 int* __restrict__ flagged /* [0] = count, [1 + q] = 1 if query q failed */) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
     const u32 row = valid ? rmu_key_row(ck) : 0u;
     const float* qv = q + qi * SD;
     const float* xv = x + (int64_t)row * SD;
-    float acc = 0.f, qn2 = 0.f;
+    float acc = 0.f, qn2 = 0.f, dq2 = 0.f;
     for (int t = 0; t < SD / 8; ++t) {
         const f32x4 qa = *(const f32x4*)(qv + 8 * t), qb = *(const f32x4*)(qv + 8 * t + 4);
         const f32x4 xa = *(const f32x4*)(xv + 8 * t), xb = *(const f32x4*)(xv + 8 * t + 4);
@@ -359,16 +367,24 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
             acc = fmaf(xb[c], qb[c], acc);
             qn2 = fmaf(qa[c], qa[c], qn2);
             qn2 = fmaf(qb[c], qb[c], qn2);
+            const float da = qa[c] - (float)(_Float16)(qa[c] * 64.0f) * (1.0f / 64.0f);
+            const float db = qb[c] - (float)(_Float16)(qb[c] * 64.0f) * (1.0f / 64.0f);
+            dq2 = fmaf(da, da, dq2);
+            dq2 = fmaf(db, db, dq2);
         }
     }
     // sufficiency test on the approximate scores
     const int nvalid = __builtin_popcountll(__ballot(valid));
     const float tau = __shfl(sa, k - 1);                        // k-th best approximate score (or -inf)
     const float smin = __shfl(sa, kp - 1);                      // worst kept candidate
-    const float eps = eps_unit * sqrtf(qn2);
+    const float qn = sqrtf(qn2) * 1.0001f, dq = sqrtf(dq2) * 1.0001f;
+    const float eps = dx_max * qn + xnorm_max * dq + dx_max * dq + 5.0e-5f * xnorm_max * qn;   // see the header
     const bool complete = nvalid < kp;                           // every live row was a candidate
     const bool ok = complete || (smin < tau - 2.0f * eps);
-    if (!ok && lane == 0) atomicAdd(flagged, 1);
+    if (lane == 0) {
+        flagged[1 + qi] = ok ? 0 : 1;
+        if (!ok) atomicAdd(flagged, 1);
+    }
     u64 key[1];
     u32 rank[1];
     key[0] = valid ? rmu_make_key(acc + 0.0f, row) : 0ull;
@@ -393,31 +409,44 @@ int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s)
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-template <bool LA, int PF>
+int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStream_t s) {
+    hipLaunchKernelGGL(k_seed_thr, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, keys, kp, nq, gthr);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+
+template <int EXP>
 static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)scan_screen_kernel<LA, PF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)scan_screen_kernel<EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ScreenCfg::LDS_BYTES) != hipSuccess)
             return RMU_E_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((scan_screen_kernel<LA, PF>), dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
+    hipLaunchKernelGGL((scan_screen_kernel<EXP>), dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
 int rmu_screen_lds_bytes() { return ScreenCfg::LDS_BYTES; }
 
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
-    // L2 software prefetch measured neutral-to-negative (26.3 -> 27.2 ms): off by default, RMU_SCREEN_PF=8 enables it
-    static const int pf = getenv("RMU_SCREEN_PF") ? atoi(getenv("RMU_SCREEN_PF")) : 0;
-    return pf > 0 ? screen_launch_cfg<true, 8>(p, s) : screen_launch_cfg<true, 0>(p, s);
+    static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;   // timing ablations, wrong results
+    if (ex == 1) return screen_launch_cfg<1>(p, s);
+    if (ex == 2) return screen_launch_cfg<2>(p, s);
+    if (ex == 3) return screen_launch_cfg<3>(p, s);
+    return screen_launch_cfg<0>(p, s);
 }
 
-int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float eps_unit,
+int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s) {
+    if (n_rows <= 0) return RMU_OK;
+    hipLaunchKernelGGL(k_img_err, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, x, n_rows, err2);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+
+int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
                        int64_t row_base, float* out_s, int64_t* out_r, int* flagged, hipStream_t s) {
     if (kp < k || kp > 64) return RMU_E_INVALID;
-    hipLaunchKernelGGL(k_rescore, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, eps_unit, row_base,
+    hipLaunchKernelGGL(k_rescore, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
                        out_s, out_r, flagged);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }

@@ -299,7 +299,7 @@ def test_rccl_allgather_path_world1(rmu, corpus50k):
             dist.destroy_process_group()
 
 
-# ---- fp16 hi/lo screening pass + exact fp32 re-score (nq >= 128, k <= 16, dim 384) ------------------------------------
+# ---- fp16 screening pass + exact fp32 re-score (nq >= 128, k <= 16, dim 384) ------------------------------------------
 @pytest.mark.parametrize("nq,k", [(128, 10), (200, 1), (256, 16), (1024, 10)])
 def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
     x = O.make_corpus(60_000)
@@ -318,17 +318,22 @@ def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
 
 
 def test_screened_search_falls_back_on_dense_ties(rmu):
-    """More than K' = 24 exact duplicates of the best row: the sufficiency test must flag the query and the exact scan
-    must answer -- ids still in ascending-row order among the ties."""
+    """More than K' = 32 exact duplicates of the best row: the sufficiency test must flag that query and the exact scan
+    must answer it (only it: the other 199 stay on the screened path) -- ids in ascending-row order among the ties."""
     x = O.make_corpus(20_000)
     xd = np.concatenate([x, np.repeat(x[77:78], 40, axis=0)])            # row 77 exists 41 times
     q = np.concatenate([x[77:78], O.make_queries(x, 199)[0]])
     idx = rmu.FlatIndex(384)
     idx.add(xd)
     s, r = idx.search(q, 10)
-    assert idx.last_screened() < 0                                            # fell back
+    assert idx.last_screened() == -1                                          # exactly one query was re-run
     assert_topk_parity(s, r, *O.flat_search(q, xd, 10))
     assert list(r[0]) == [77] + list(range(20_000, 20_009))
+    # every query hits the duplicates: more than 1/8 of the batch fails -> the whole batch goes to the exact scan
+    q2 = np.repeat(x[77:78], 128, axis=0) + np.float32(1e-4) * O.make_queries(x, 128)[0]
+    s2, r2 = idx.search(q2, 10)
+    assert idx.last_screened() <= -100
+    assert_topk_parity(s2, r2, *O.flat_search(q2, xd, 14))
     idx.close()
 
 
