@@ -72,6 +72,15 @@ struct Tls {
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm, fbq, fb_s, fb_r, fb_i;
+    std::vector<hipEvent_t> lev;   // per-launch events of the screening ladder
+    int ensure_events(int n) {
+        while ((int)lev.size() < n) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return RMU_E_HIP;
+            lev.push_back(e);
+        }
+        return RMU_OK;
+    }
     bool timing = false;
     float scan_ms = -1.f, search_ms = -1.f;
     int grid = 0, block = 0, lds = 0, passes = 0, screened = 0;
@@ -557,51 +566,63 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // ---- screened path: fp16 scan proposes K' = 32 candidates, exact fp32 re-score decides -------------------------
         bool done = false;
         static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 128;
-        static const int pre_den = getenv("RMU_SCREEN_PRE") ? atoi(getenv("RMU_SCREEN_PRE")) : 12;   // pre-pass = n / pre_den rows (0 = off)
+        static const int lvl_min = getenv("RMU_SCREEN_MINLVL") ? atoi(getenv("RMU_SCREEN_MINLVL")) : 2048;
+        static const int lvl_ratio = getenv("RMU_SCREEN_RATIO") ? atoi(getenv("RMU_SCREEN_RATIO")) : 3;   // <= 1: single launch
         if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && k <= 16 && idx->n > 0 &&
             idx->xnorm_max > 0.f && idx->xnorm_max < 500.f) {   // fp16(64*x) must not overflow
             const int kp = 32;
-            // pre-pass over the first n/12 rows: its merged K'-th best seeds the shared thresholds of the main pass, which
-            // then starts with the bound a cold chunk would only reach after ~n/12 * (chunks) rows
-            const int64_t nA = (pre_den > 0 && idx->n >= (1 << 20)) ? (idx->n / pre_den) / 32 * 32 : 0;
-            ScanLaunch A{}, S{};
-            S.x = (const float*)idx->split; S.row0 = nA; S.n_rows = idx->n - nA; S.dpad = dpad; S.nq = (int)nb; S.k = kp;
-            rc = rmu_scan_plan(&S);
-            if (!rc && nA > 0) {
-                A = S; A.row0 = 0; A.n_rows = nA;
-                rc = rmu_scan_plan(&A);
+            // Threshold ladder: the corpus is scanned in row ranges of geometrically growing size (ratio 3, first >= 2k
+            // rows); after each range its candidates are merged with the running top-K' and the K'-th best seeds the
+            // shared per-query thresholds of the next launch.  A cold launch appends K' ln(rows/K') candidates per query
+            // and CHUNK, a seeded one only K' (ratio - 1) per query in total, and every append stalls a whole workgroup
+            // for ~3k cycles: this cut the filter overhead of the 10M x 1024 scan from 5.2 to ~2 ms.
+            std::vector<int64_t> bounds{idx->n};
+            if (lvl_ratio > 1 && idx->n >= 262144)
+                for (int64_t c = idx->n / lvl_ratio / 32 * 32; c >= lvl_min && bounds.size() < 16; c = c / lvl_ratio / 32 * 32)
+                    bounds.insert(bounds.begin(), c);
+            const int nl = (int)bounds.size();
+            std::vector<ScanLaunch> lv((size_t)nl);
+            int slots = nl - 1;
+            bool plan_ok = true;
+            for (int l = 0; l < nl && plan_ok; ++l) {
+                ScanLaunch& S = lv[(size_t)l];
+                S = ScanLaunch{};
+                S.x = (const float*)idx->split; S.row0 = l ? bounds[(size_t)l - 1] : 0; S.n_rows = bounds[(size_t)l] - S.row0;
+                S.dpad = dpad; S.nq = (int)nb; S.k = kp;
+                plan_ok = rmu_scan_plan(&S) == RMU_OK && S.wq == 4 && S.kv == 0;
+                slots += S.parts;
             }
-            if (!rc && S.wq == 4 && S.kv == 0 && (nA == 0 || (A.wq == 4 && A.kv == 0))) {
-                const int parts_total = S.parts + (nA > 0 ? A.parts : 0);
-                const size_t sp = (size_t)parts_total * nb * kp * sizeof(u64);
+            if (plan_ok) {
+                const size_t part_keys = (size_t)nb * kp;
                 const size_t gbytes = (size_t)((nb + 127) / 128 * 128 + 64) * sizeof(u32);
-                if (t.partial.ensure(sp) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) || t.gthr.ensure(gbytes) ||
-                    t.ckeys.ensure((size_t)nb * kp * sizeof(u64)) || t.flag.ensure((size_t)(nb + 1) * sizeof(int)))
+                if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
+                    t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.flag.ensure((size_t)(nb + 1) * sizeof(int)) ||
+                    t.ensure_events(2 * nl))
                     return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
                 const int sflags = share | ((getenv("RMU_SCREEN_NOFILTER") != nullptr) ? 2 : 0);
-                u64* pA = (u64*)t.partial.p;
-                u64* pS = pA + (nA > 0 ? (size_t)A.parts * nb * kp : 0);
-                S.partial = pS; S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = nullptr; S.q = (const float*)t.qsplit.p;
                 HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
                 HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
                 rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
                 if (rc) return fail(rc, "rmu_index_search: query conversion");
-                if (nA > 0) {
-                    A.partial = pA; A.gthr = S.gthr; A.share_thr = sflags; A.dbg = nullptr; A.q = S.q;
-                    if (timed) HIP_TRY(hipEventRecord(t.ev[4], s));
-                    rc = rmu_screen_launch(&A, s);
-                    if (rc) return fail(rc, "rmu_index_search: screening pre-pass launch");
-                    if (timed) HIP_TRY(hipEventRecord(t.ev[5], s));
-                    rc = rmu_merge_to_keys_launch(pA, A.parts, nb, kp, (u64*)t.ckeys.p, s);
-                    if (!rc) rc = rmu_seed_thr_launch((const u64*)t.ckeys.p, kp, nb, S.gthr, s);
-                    if (rc) return fail(rc, "rmu_index_search: threshold seeding");
+                u64* base = (u64*)t.partial.p;
+                int cursor = 0;     // slot index: [merged keys of the ranges so far][this range's parts] ...
+                for (int l = 0; l < nl; ++l) {
+                    ScanLaunch& S = lv[(size_t)l];
+                    const int first = cursor;               // slot of the running top-K' (l > 0), else of this range's first part
+                    if (l > 0) cursor += 1;
+                    S.partial = base + (size_t)cursor * part_keys;
+                    S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = g_dbg; S.q = (const float*)t.qsplit.p;
+                    if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l)], s));
+                    rc = rmu_screen_launch(&S, s);
+                    if (rc) return fail(rc, "rmu_index_search: screening launch");
+                    if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l + 1)], s));
+                    cursor += S.parts;
+                    if (g_dbg) { u64 h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg range %d: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu\n", l, (long long)S.n_rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); (void)hipMemset(g_dbg, 0, 128); }
+                    u64* merged = l + 1 < nl ? base + (size_t)cursor * part_keys : (u64*)t.ckeys.p;
+                    rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, kp, merged, s);
+                    if (!rc && l + 1 < nl) rc = rmu_seed_thr_launch(merged, kp, nb, (u32*)t.gthr.p, s);
+                    if (rc) return fail(rc, "rmu_index_search: screening merge / threshold seeding");
                 }
-                if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
-                rc = rmu_screen_launch(&S, s);
-                if (rc) return fail(rc, "rmu_index_search: screening launch");
-                if (timed) HIP_TRY(hipEventRecord(t.ev[3], s));
-                rc = rmu_merge_to_keys_launch(pA, parts_total, nb, kp, (u64*)t.ckeys.p, s);
-                if (rc) return fail(rc, "rmu_index_search: screening merge");
                 // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip)
                 rc = rmu_rescore_launch((const u64*)t.ckeys.p, kp, idx->x, qdev, nb, k, idx->xnorm_max, idx->dx_max, row_base, d_s, d_r,
                                         (int*)t.flag.p, s);
@@ -609,13 +630,13 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                 int hflag = 0;
                 HIP_TRY(hipMemcpyAsync(&hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                t.grid = S.grid; t.block = 256; t.lds = rmu_screen_lds_bytes(); t.passes += nA > 0 ? 2 : 1;
+                t.grid = lv.back().grid; t.block = 256; t.lds = rmu_screen_lds_bytes(); t.passes += nl;
                 t.screened = hflag == 0 ? 1 : -hflag;   // >0: answered by the screen; <0: that many queries were re-run exactly
-                if (timed) {
-                    float ms = 0.f;
-                    if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms;
-                    if (nA > 0 && hipEventElapsedTime(&ms, t.ev[4], t.ev[5]) == hipSuccess) scan_total += ms;
-                }
+                if (timed)
+                    for (int l = 0; l < nl; ++l) {
+                        float ms = 0.f;
+                        if (hipEventElapsedTime(&ms, t.lev[(size_t)(2 * l)], t.lev[(size_t)(2 * l + 1)]) == hipSuccess) scan_total += ms;
+                    }
                 done = hflag == 0;
                 if (!done && hflag <= nb / 8) {
                     // few queries failed the sufficiency test: re-run only those on the exact scan and patch their rows in
@@ -651,7 +672,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         }
         // workspace is reused by the next query block (and host outputs must land): drain per block
         if (!hip_stream || q0 + nb < nq || !out_dev) HIP_TRY(hipStreamSynchronize(s));
-        if (g_dbg) { u64 h[16]; (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg] slow_tiles=%llu compactions=%llu appends=%llu tiles=%llu slow_clk=%llu compact_clk=%llu addwait_clk=%llu endwait_clk=%llu check_clk=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]); }
+        if (g_dbg) { u64 h[16]; (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg] slow_tiles=%llu compactions=%llu appends=%llu tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); }
         if (exact_timed) {
             HIP_TRY(hipEventSynchronize(t.ev[3]));
             float ms = 0.f;

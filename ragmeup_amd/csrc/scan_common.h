@@ -48,7 +48,8 @@ __device__ __forceinline__ void rank_keys(const u64 (&key)[NPL], u32 n, u32 (&ra
 template <class C>
 __device__ __forceinline__ void compact_slot(int j, u64* cand_w, u32* cnt_w, float* thr_w, int k, int lane,
                                              u32* gthr_w /* global, this wave's 32 queries */) {
-    const u32 n = cnt_w[j];
+    const u32 n_raw = cnt_w[j];
+    const u32 n = n_raw < (u32)C::CAP ? n_raw : (u32)C::CAP;   // the screening scan lets the count run past a full slot
     u64 key[C::NPL];
     u32 rank[C::NPL];
 #pragma unroll

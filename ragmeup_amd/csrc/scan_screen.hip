@@ -41,12 +41,11 @@ constexpr int S_TS = SD / 16;           // 24 MFMA steps per tile
 constexpr int S_RING = 4;               // tiles (24 KiB each) in the LDS ring
 constexpr int S_SLOT = S_RT * IMGB;     // 24 KiB
 constexpr int S_NI = S_RT * S_U16 / 256;  // 6 DMA wave-instructions per wave per tile
-constexpr int S_PRE = 4;                // A-fragment prefetch depth in steps (one step is a single 32-cycle MFMA)
 struct ScreenCfg {
-    // K' = 32 candidates per (chunk, query); a slow path appends a tile's 16 scores per lane in groups of 6, 6 and 4 (both
-    // lane halves feed the same query slot: <= 12 appends per slot between overflow checks) and a compaction is due only
-    // after 12 further appends: CAP = 32 + 12 + 12
-    static constexpr int CAP = 56, NPL = 1, A = 12;
+    // K' = 32 candidates per (chunk, query) in slots of CAP = 56.  Appends reserve their position with ds_add_rtn; a
+    // position past the slot is retried after the compaction (back to K' entries) that it triggers, and a slot is
+    // compacted early once an append lands in its last A entries.
+    static constexpr int CAP = 56, NPL = 1, A = 4;
     static constexpr int RING_BYTES = S_RING * S_SLOT;
     static constexpr int CAND_BYTES = 4 * 32 * CAP * 8;
     static constexpr int TRASH_OFF = RING_BYTES + CAND_BYTES + 4 * 32 * 4 + 4 * 32 * 4;
@@ -92,9 +91,12 @@ __global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, in
     if (lane == 0) err2[r] = s * 1.0001f;   // summation slack
 }
 
-template <int EXP = 0>   // EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads
+// EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads
+// S_PRE = A-fragment prefetch depth in steps (one step is a single 32-cycle MFMA)
+template <int EXP = 0, int S_PRE = 4>
 __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     using C = ScreenCfg;
+    static_assert(S_TS % S_PRE == 0, "fragment register ring must close over a tile");
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = query group, all waves read the same rows
     const int h = lane >> 5, j = lane & 31;
@@ -214,22 +216,44 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
 
     struct Acc { f32x16 a; };                          // 4096 * s~  (rows and queries are both scaled by 2^6)
     auto score = [](const Acc& p, int r) { return p.a[r] * (1.0f / 4096.0f); };
-    u32 pmask = 0, wr_addr = 0, res_pos = 0;
+    u32 pmask = 0, res_pos = 0;
     auto mask_slot = [&](const Acc& prev, int r) { pmask |= (prev.a[r] > thr_s) ? (1u << r) : 0u; };
-    auto slow_begin = [&](u32 bits) {
-        const u32 n = __builtin_popcount(pmask & bits);
-        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(res_pos) : "v"(cnt_addr), "v"(n) : "memory");
-        wr_addr = cand_addr + res_pos * 8u;
-    };
-    auto slow_slot_r = [&](const Acc& prev, int r, int64_t rbase) {
-        const u64 key = rmu_make_key(score(prev, r) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
-        const bool pass = (pmask >> r) & 1u;
-        lds_store_b64_nofence(pass ? wr_addr : trash_addr, key);
-        wr_addr += pass ? 8u : 0u;
-    };
-    auto slow_end = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        check_compact();
+    // Append the passing scores of one tile (bits of pmask) to this lane's query slot.  In the seeded main pass an event
+    // is almost always a single score in a single lane, so the 16 accumulator slots are visited under a wave-uniform
+    // branch each (one ballot per slot) and only slots with a passing lane pay for key + ds_add_rtn + store.  (Selecting
+    // "my lowest set bit" per lane instead made hipcc index the accumulators through scratch, and a scratch access waits
+    // vmcnt(0), i.e. drains the whole LDS-DMA ring: ~10k cycles per event.)  A position past the slot means "full": the
+    // compaction this triggers frees room and the score is retried.
+    u32 d_slow = 0, d_rounds = 0, d_comp = 0, d_app = 0;
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_all = a.dbg ? clock64() : 0;
+    auto slow_path = [&](const Acc& p, int64_t rbase) {
+        unsigned long long c0 = 0;
+        if (a.dbg) { ++d_slow; d_app += __builtin_popcount(pmask); c0 = clock64(); }
+        u32 todo = pmask;
+        do {
+            u32 left = 0;
+            bool nearly_full = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool has = (todo >> r) & 1u;
+                if (__any(has)) {                                   // wave-uniform: most slots are skipped
+                    if (a.dbg) ++d_rounds;
+                    const u64 key = rmu_make_key(score(p, r) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(res_pos) : "v"(cnt_addr), "v"(has ? 1u : 0u) : "memory");
+                    const bool fits = has && res_pos < (u32)C::CAP;
+                    lds_store_b64_nofence(fits ? cand_addr + res_pos * 8u : trash_addr, key);
+                    nearly_full |= has && res_pos >= (u32)(C::CAP - C::A);
+                    left |= (has && !fits) ? (1u << r) : 0u;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (__any(nearly_full)) {                               // some slot is (nearly) full: compact, then retry what did not fit
+                check_compact();
+                if (a.dbg) ++d_comp;
+            }
+            todo = left;
+        } while (__any(todo != 0));
+        if (a.dbg) d_clk_slow += clock64() - c0;
     };
 
     int tt = 0;
@@ -239,8 +263,11 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.a[r] = 0.f;
         pmask = 0;
+        unsigned long long cb = 0;
+        if (a.dbg) cb = clock64();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
         __builtin_amdgcn_s_barrier();
+        if (a.dbg) d_clk_bar += clock64() - cb;
         {
             const u32 go = gt_lds[j];
             thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
@@ -252,16 +279,7 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         const int cur_off = (tt % S_RING) * S_SLOT, nxt_off = ((tt + 1) % S_RING) * S_SLOT;
 #pragma unroll
         for (int t = 0; t < S_TS; ++t) {
-            if (t == 18 && __builtin_expect(__any(pmask != 0), 0) && !(a.share_thr & 2)) {
-#pragma unroll
-                for (int g2 = 0; g2 < 3; ++g2) {
-                    constexpr int lo3[4] = {0, 6, 12, 16};
-                    slow_begin(((1u << lo3[g2 + 1]) - 1u) & ~((1u << lo3[g2]) - 1u));
-#pragma unroll
-                    for (int r = lo3[g2]; r < lo3[g2 + 1]; ++r) slow_slot_r(prev, r, prev_rbase);
-                    slow_end();
-                }
-            }
+            if (t == 18 && __builtin_expect(__any(pmask != 0), 0) && !(a.share_thr & 2)) slow_path(prev, prev_rbase);
             frag_wait(fr[t % S_PRE]);
             acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t % S_PRE], qh[t], acc.a, 0, 0, 0);
             if (t >= 1 && t <= 16) mask_slot(prev, t - 1);
@@ -284,20 +302,16 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         for (int r = 0; r < 16; ++r) accB.a[r] = -INFINITY;
         const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
         auto rb = [&](int t) { return lane_r0 + (int64_t)t * S_RT; };
-        tile_body(accA, accB, rb(-1));
-        int tl = 1;
-        for (; tl + 1 < ntiles; tl += 2) {
-            tile_body(accB, accA, rb(tl - 1));
-            tile_body(accA, accB, rb(tl));
-        }
-        bool last_in_a = true;
-        if (tl < ntiles) {
-            tile_body(accB, accA, rb(tl - 1));
-            last_in_a = false;
+        const bool last_in_a = ((ntiles - 1) & 1) == 0;   // even tiles accumulate in A
+        for (int tl = 0; tl < ntiles; tl += 2) {          // two copies of the body: accumulator parity
+            tile_body(accA, accB, rb(tl - 1));              // (tile -1 = the -inf accumulators: nothing passes)
+            if (tl + 1 < ntiles) tile_body(accB, accA, rb(tl));
         }
         // the fragment reads issued for a tile that does not exist are still in flight: their registers must stay
         // allocated until the data has landed (the compiler sees dead values and would reuse the registers under them)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]) : : "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) asm volatile("" : "+v"(fr[m]));
         {
             Acc last;
 #pragma unroll
@@ -310,16 +324,22 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
                 mask_slot(last, r);
                 if (rbl + (r & 3) + 8 * (r >> 2) >= row_end) pmask &= ~(1u << r);
             }
-            if (__any(pmask != 0)) {
+            if (__any(pmask != 0)) slow_path(last, rbl);
+        }
+    }
+    if (a.dbg) {
+        u32 app = d_app;
 #pragma unroll
-                for (int g2 = 0; g2 < 3; ++g2) {
-                    constexpr int lo3[4] = {0, 6, 12, 16};
-                    slow_begin(((1u << lo3[g2 + 1]) - 1u) & ~((1u << lo3[g2]) - 1u));
-#pragma unroll
-                    for (int r = lo3[g2]; r < lo3[g2 + 1]; ++r) slow_slot_r(last, r, rbl);
-                    slow_end();
-                }
-            }
+        for (int o = 32; o > 0; o >>= 1) app += __shfl_xor(app, o);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)a.dbg + 0, (unsigned long long)d_slow);
+            atomicAdd((unsigned long long*)a.dbg + 1, (unsigned long long)d_comp);
+            atomicAdd((unsigned long long*)a.dbg + 2, (unsigned long long)app);
+            atomicAdd((unsigned long long*)a.dbg + 3, (unsigned long long)ntiles);
+            atomicAdd((unsigned long long*)a.dbg + 4, (unsigned long long)d_rounds);
+            atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
+            atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
+            atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
         }
     }
     // ---- emit: best K' approximate candidates of this (chunk, query), sorted ---------------------------------------------
@@ -414,16 +434,16 @@ int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStrea
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-template <int EXP>
+template <int EXP, int PRE = 4>
 static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)scan_screen_kernel<EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)scan_screen_kernel<EXP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ScreenCfg::LDS_BYTES) != hipSuccess)
             return RMU_E_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((scan_screen_kernel<EXP>), dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
+    hipLaunchKernelGGL((scan_screen_kernel<EXP, PRE>), dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
@@ -434,6 +454,10 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     if (ex == 1) return screen_launch_cfg<1>(p, s);
     if (ex == 2) return screen_launch_cfg<2>(p, s);
     if (ex == 3) return screen_launch_cfg<3>(p, s);
+    static const int pre = getenv("RMU_SCREEN_SPRE") ? atoi(getenv("RMU_SCREEN_SPRE")) : 4;
+    if (pre == 6) return screen_launch_cfg<0, 6>(p, s);
+    if (pre == 8) return screen_launch_cfg<0, 8>(p, s);
+    if (pre == 3) return screen_launch_cfg<0, 3>(p, s);
     return screen_launch_cfg<0>(p, s);
 }
 
