@@ -566,7 +566,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // ---- screened path: fp16 scan proposes K' = 32 candidates, exact fp32 re-score decides -------------------------
         bool done = false;
         static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 128;
-        static const int lvl_min = getenv("RMU_SCREEN_MINLVL") ? atoi(getenv("RMU_SCREEN_MINLVL")) : 2048;
+        static const int lvl_min = getenv("RMU_SCREEN_MINLVL") ? atoi(getenv("RMU_SCREEN_MINLVL")) : 256;
         static const int lvl_ratio = getenv("RMU_SCREEN_RATIO") ? atoi(getenv("RMU_SCREEN_RATIO")) : 3;   // <= 1: single launch
         if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && k <= 16 && idx->n > 0 &&
             idx->xnorm_max > 0.f && idx->xnorm_max < 500.f) {   // fp16(64*x) must not overflow
@@ -577,9 +577,13 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             // and CHUNK, a seeded one only K' (ratio - 1) per query in total, and every append stalls a whole workgroup
             // for ~3k cycles: this cut the filter overhead of the 10M x 1024 scan from 5.2 to ~2 ms.
             std::vector<int64_t> bounds{idx->n};
-            if (lvl_ratio > 1 && idx->n >= 262144)
-                for (int64_t c = idx->n / lvl_ratio / 32 * 32; c >= lvl_min && bounds.size() < 16; c = c / lvl_ratio / 32 * 32)
-                    bounds.insert(bounds.begin(), c);
+            if (lvl_ratio > 1 && idx->n >= 262144) {
+                int64_t c = idx->n / lvl_ratio / 32 * 32;
+                for (; c >= 65536 && bounds.size() < 24; c = c / lvl_ratio / 32 * 32) bounds.insert(bounds.begin(), c);
+                // below 64k rows a range is a handful of tiles per workgroup and its appends cost next to nothing: ratio 8, down
+                // to a first range so small (<= lvl_min rows) that its cold start -- every score is appended -- does not matter
+                for (c = bounds.front() / 8 / 32 * 32; c >= lvl_min && bounds.size() < 24; c = c / 8 / 32 * 32) bounds.insert(bounds.begin(), c);
+            }
             const int nl = (int)bounds.size();
             std::vector<ScanLaunch> lv((size_t)nl);
             int slots = nl - 1;
@@ -589,12 +593,12 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                 S = ScanLaunch{};
                 S.x = (const float*)idx->split; S.row0 = l ? bounds[(size_t)l - 1] : 0; S.n_rows = bounds[(size_t)l] - S.row0;
                 S.dpad = dpad; S.nq = (int)nb; S.k = kp;
-                plan_ok = rmu_scan_plan(&S) == RMU_OK && S.wq == 4 && S.kv == 0;
+                plan_ok = rmu_screen_plan(&S) == RMU_OK;
                 slots += S.parts;
             }
             if (plan_ok) {
                 const size_t part_keys = (size_t)nb * kp;
-                const size_t gbytes = (size_t)((nb + 127) / 128 * 128 + 64) * sizeof(u32);
+                const size_t gbytes = (size_t)((nb + 255) / 256 * 256 + 64) * sizeof(u32);
                 if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
                     t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.flag.ensure((size_t)(nb + 1) * sizeof(int)) ||
                     t.ensure_events(2 * nl))
@@ -630,7 +634,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                 int hflag = 0;
                 HIP_TRY(hipMemcpyAsync(&hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
-                t.grid = lv.back().grid; t.block = 256; t.lds = rmu_screen_lds_bytes(); t.passes += nl;
+                t.grid = lv.back().grid; t.block = 256; t.lds = lv.back().lds_bytes; t.passes += nl;
                 t.screened = hflag == 0 ? 1 : -hflag;   // >0: answered by the screen; <0: that many queries were re-run exactly
                 if (timed)
                     for (int l = 0; l < nl; ++l) {

@@ -106,6 +106,7 @@ struct ScanLaunch {
     u64* dbg;              // optional debug counters (nullptr in production): [0] slow tiles, [1] compactions, [2] appends, [3] tiles
     // filled by rmu_scan_plan
     int wq, kv, s_chunks, nqt, tiles_per_chunk, grid, lds_bytes;
+    int qg;                // screening scan only: 32-query groups per wave (rmu_screen_plan)
 };
 
 int rmu_scan_plan(ScanLaunch* p);                        // chooses geometry; returns 0 or RMU_E_INVALID
@@ -122,7 +123,8 @@ int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u
 int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> fp16 image
 int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStream_t s); // K'-th best of a pre-pass -> gthr
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s);                             // x/q = split images, k = K'
-int rmu_screen_lds_bytes();
+int rmu_screen_lds_bytes(int qg);
+int rmu_screen_plan(ScanLaunch* p);                      // geometry of one screening launch (k = K' <= 32)
 int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s);       // |x - image|^2 per row
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
                        int64_t row_base, float* out_s, int64_t* out_r, int* flagged, hipStream_t s);

@@ -35,24 +35,34 @@ constexpr int SD = 384;                 // floats per row
 constexpr int ROWB = SD * 4;            // fp32 row bytes (re-score)
 constexpr int IMGB = RMU_IMG_ROW_BYTES; // 768: screening-image bytes per row
 static_assert(IMGB == SD * 2, "image geometry");
-constexpr int S_RT = 32;                // rows per tile (4 waves share it, one 32-query group each)
-constexpr int S_U16 = IMGB / 16;        // 48 16-byte units per row
-constexpr int S_TS = SD / 16;           // 24 MFMA steps per tile
-constexpr int S_RING = 4;               // tiles (24 KiB each) in the LDS ring
-constexpr int S_SLOT = S_RT * IMGB;     // 24 KiB
-constexpr int S_NI = S_RT * S_U16 / 256;  // 6 DMA wave-instructions per wave per tile
+constexpr int S_RT = 32;                // rows per tile (the 4 waves of a workgroup share it)
+constexpr int S_CKB = IMGB / 2;         // 384 B per row per chunk: a tile is streamed as two half-k chunks
+constexpr int S_U16 = S_CKB / 16;       // 24 16-byte units per row per chunk
+constexpr int S_TS = SD / 16;           // 24 MFMA steps per tile ...
+constexpr int S_CS = S_TS / 2;          // ... 12 per chunk
+constexpr int S_SLOT = S_RT * S_CKB;    // 12 KiB ring slot
+constexpr int S_NI = S_RT * S_U16 / 256;  // 3 DMA wave-instructions per wave per chunk
+// G = 32-query groups per wave.  The v2 kernel (G = 1) was bound by LDS bandwidth: four waves each reading the whole tile
+// need 4 x 1 KiB per 32-cycle MFMA = all 128 B/clk of the LDS before the DMA writes are counted (ablations in
+// DESIGN.md 4.3).  With G = 2 every A fragment feeds two MFMAs (64 queries per wave, 256 per workgroup), halving LDS
+// and L2 bytes per MFMA; the price is 80 KiB of candidate slots, hence the smaller ring slots and CAP.
+template <int G>
 struct ScreenCfg {
-    // K' = 32 candidates per (chunk, query) in slots of CAP = 56.  Appends reserve their position with ds_add_rtn; a
-    // position past the slot is retried after the compaction (back to K' entries) that it triggers, and a slot is
-    // compacted early once an append lands in its last A entries.
-    static constexpr int CAP = 56, NPL = 1, A = 4;
-    static constexpr int RING_BYTES = S_RING * S_SLOT;
-    static constexpr int CAND_BYTES = 4 * 32 * CAP * 8;
-    static constexpr int TRASH_OFF = RING_BYTES + CAND_BYTES + 4 * 32 * 4 + 4 * 32 * 4;
+    // K' = 32 candidates per (chunk, query).  Appends reserve their position with ds_add_rtn; a position past the slot
+    // is retried after the compaction (back to K' entries) that it triggers, and a slot is compacted early once an
+    // append lands in its last A entries.
+    static constexpr int QW = 32 * G;                       // queries per wave
+    static constexpr int CAP = G == 2 ? 40 : 56, NPL = 1, A = 4;
+    static constexpr int NR = G == 2 ? 6 : 8;               // ring slots
+    static constexpr int RING_BYTES = NR * S_SLOT;
+    static constexpr int CAND_BYTES = 4 * QW * CAP * 8;
+    static constexpr int CNT_OFF = RING_BYTES + CAND_BYTES;
+    static constexpr int THR_OFF = CNT_OFF + 4 * QW * 4;
+    static constexpr int TRASH_OFF = THR_OFF + 4 * QW * 4;
     static constexpr int GT_OFF = TRASH_OFF + 256 * 8;
     static constexpr int LDS_BYTES = GT_OFF + 4 * 256;
 };
-static_assert(ScreenCfg::LDS_BYTES <= 160 * 1024, "LDS");
+static_assert(ScreenCfg<1>::LDS_BYTES <= 160 * 1024 && ScreenCfg<2>::LDS_BYTES <= 160 * 1024, "LDS");
 
 extern __shared__ __attribute__((aligned(16))) char ssm[];
 
@@ -91,14 +101,15 @@ __global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, in
     if (lane == 0) err2[r] = s * 1.0001f;   // summation slack
 }
 
-// EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads
-// S_PRE = A-fragment prefetch depth in steps (one step is a single 32-cycle MFMA)
-template <int EXP = 0, int S_PRE = 4>
+// EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads; bit 2 = debug counters
+// S_PRE = A-fragment prefetch depth in steps
+template <int G, int EXP = 0, int S_PRE = 4>
 __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
-    using C = ScreenCfg;
-    static_assert(S_TS % S_PRE == 0, "fragment register ring must close over a tile");
+    using C = ScreenCfg<G>;
+    constexpr bool DBG = (EXP & 4) != 0;   // cycle / event counters into a.dbg (RMU_SCAN_EXP=7)
+    static_assert(S_CS % S_PRE == 0, "fragment register ring must close over a chunk");
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = query group, all waves read the same rows
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = query groups, all waves read the same rows
     const int h = lane >> 5, j = lane & 31;
     int s_idx, qt;
     {
@@ -120,56 +131,67 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     const char* img = (const char*)a.x + a.row0 * (int64_t)IMGB;      // rows [row0, row0 + n_rows) of the image
 
     char* ring = ssm;
-    u64* cand_w = (u64*)(ssm + C::RING_BYTES) + (size_t)w * 32 * C::CAP;
-    u32* cnt_w = (u32*)(ssm + C::RING_BYTES + C::CAND_BYTES) + w * 32;
-    float* thr_w = (float*)(ssm + C::RING_BYTES + C::CAND_BYTES + 4 * 32 * 4) + w * 32;
-    const int q_idx = (qt * 4 + w) * 32 + j;
-    const bool q_ok = q_idx < a.nq;
-    if (lane < 32) {
+    u64* cand_w = (u64*)(ssm + C::RING_BYTES) + (size_t)w * C::QW * C::CAP;
+    u32* cnt_w = (u32*)(ssm + C::CNT_OFF) + w * C::QW;
+    float* thr_w = (float*)(ssm + C::THR_OFF) + w * C::QW;
+    const int q_base = (qt * 4 + w) * C::QW;             // this wave's first query; group g, lane j owns q_base + 32 g + j
+    bool q_ok[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) q_ok[g] = q_base + 32 * g + j < a.nq;
+    if (lane < C::QW) {
         cnt_w[lane] = 0;
-        thr_w[lane] = q_ok ? -INFINITY : INFINITY;
+        thr_w[lane] = (q_base + lane < a.nq) ? -INFINITY : INFINITY;
     }
-    float thr = q_ok ? -INFINITY : INFINITY, thr_loc = thr, thr_g = -INFINITY;
-    float thr_s = thr;                                  // thr * 4096: filter threshold in the accumulator's scale (+-inf here)
-    u32* gthr_w = a.gthr + (qt * 4 + w) * 32;
+    float thr_loc[G], thr_g[G], thr_s[G];                // thr_s = max(local, shared) * 4096: the accumulator's scale
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        thr_loc[g] = q_ok[g] ? -INFINITY : INFINITY;
+        thr_g[g] = -INFINITY;
+        thr_s[g] = thr_loc[g];
+    }
+    u32* gthr_w = a.gthr + q_base;
     const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
-    auto refresh_gthr = [&]() {   // 4-byte LDS-DMA of this wave's 32 shared thresholds (both lane halves load the same)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gthr_w + j),
+    auto refresh_gthr = [&]() {   // 4-byte LDS-DMA of this wave's shared thresholds (G = 1: both lane halves load the same)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gthr_w + (lane & (C::QW - 1))),
                                          (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
     };
 
     // ---- query fragments: step T covers k [16T, 16T+16); lane half h owns 8 of them -----------------------------------
-    f16x8 qh[S_TS];
-    {
-        const char* qrow = (const char*)a.q + (size_t)(q_ok ? q_idx : 0) * IMGB + h * 16;
+    f16x8 qh[G][S_TS];
 #pragma unroll
-        for (int T = 0; T < S_TS; ++T) qh[T] = *(const f16x8*)(qrow + T * 32);
+    for (int g = 0; g < G; ++g) {
+        const char* qrow = (const char*)a.q + (size_t)(q_ok[g] ? q_base + 32 * g + j : 0) * IMGB + h * 16;
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) qh[g][T] = *(const f16x8*)(qrow + T * 32);
     }
 
-    // ---- DMA source map: LDS unit f -> row f/48, physical unit f%48 holds logical unit p ^ (row & 15) ---------------
+    // ---- DMA source map: LDS unit f -> row f/24, physical unit f%24 holds logical unit p ^ ((row >> 1) & 7).  LDS rows are
+    // 384 B = 96 banks apart, so rows alternate between two bank halves; the XOR spreads 8 row pairs over the 8 units of an
+    // aligned block: any 16 consecutive rows reading one logical unit touch 16 distinct 4-bank groups (conflict free).
     u32 dma_off[S_NI];
 #pragma unroll
     for (int n = 0; n < S_NI; ++n) {
         const int f = (n * 4 + w) * 64 + lane;
         const int i = f / S_U16, p = f % S_U16;
-        dma_off[n] = (u32)(i * IMGB + (p ^ (i & 15)) * 16);
+        dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16);
     }
-    auto issue_tile = [&](int tt) {
+    const int nchunks = 2 * ntiles;
+    auto issue_chunk = [&](int cc) {
         if (EXP & 1) return;   // ablation: no corpus DMA at all
-        int tl = tt;
-        if (tl >= ntiles) tl = ntiles - 1;
-        const char* sbase = img + ((t0 + tl) * S_RT) * (int64_t)IMGB;
-        char* slot = ring + (tt % S_RING) * S_SLOT;
+        int ce = cc;
+        if (ce >= nchunks) ce = nchunks - 1;
+        const char* sbase = img + ((t0 + (ce >> 1)) * S_RT) * (int64_t)IMGB + (ce & 1) * S_CKB;
+        char* slot = ring + (cc % C::NR) * S_SLOT;
 #pragma unroll
         for (int n = 0; n < S_NI; ++n)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
                                              (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
     };
-    // A fragment of (row j, step t): logical unit 2t + h = 16 (t >> 3) + (2 (t & 7) + h); the XOR swizzle touches the low
-    // four bits only, so eight per-lane bases + an immediate (t >> 3) * 256 address everything
-    int abase[8];
+    // A fragment of (row j, chunk step t): logical unit 2t + h = 8 (t >> 2) + (2 (t & 3) + h); the XOR touches the low three
+    // bits only, so four per-lane bases + an immediate (t >> 2) * 128 address a whole chunk
+    int abase[4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) abase[m] = j * IMGB + (((2 * m + h) ^ (j & 15)) * 16);
+    for (int m = 0; m < 4; ++m) abase[m] = j * S_CKB + (((2 * m + h) ^ ((j >> 1) & 7)) * 16);
     f16x8 fr[S_PRE];
 #pragma unroll
     for (int m = 0; m < S_PRE; ++m) fr[m] = f16x8{};
@@ -183,123 +205,168 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
             asm volatile("" : "+v"(dst));
             return;
         }
-        const u32 addr = ring_addr + (u32)(abase[t & 7] + slot_off);
-        if ((t >> 3) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
-        else if ((t >> 3) == 1) asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dst) : "v"(addr));
-        else asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(dst) : "v"(addr));
+        const u32 addr = ring_addr + (u32)(abase[t & 3] + slot_off);
+        if ((t >> 2) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+        else if ((t >> 2) == 1) asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(dst) : "v"(addr));
+        else asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dst) : "v"(addr));
     };
     auto frag_wait = [&](f16x8& f) {
         if (EXP & 2) return;
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1));
     };
 
-    const u32 cnt_addr = lds_addr(cnt_w + j);
-    const u32 cand_addr = lds_addr(cand_w + j * C::CAP);
+    u32 cnt_addr[G], cand_addr[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        cnt_addr[g] = lds_addr(cnt_w + 32 * g + j);
+        cand_addr[g] = lds_addr(cand_w + (32 * g + j) * C::CAP);
+    }
     const u32 trash_addr = lds_addr(ssm + C::TRASH_OFF) + threadIdx.x * 8u;
+    auto set_thr = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; ++g) thr_s[g] = fmaxf(thr_loc[g], thr_g[g]) * 4096.0f;
+    };
     auto check_compact = [&]() {
-        const u32 c = cnt_w[j];
-        const u64 bal = __ballot(c > (u32)(C::CAP - C::A));
-        u32 mask = (u32)bal | (u32)(bal >> 32);
+        const u32 c = cnt_w[lane & (C::QW - 1)];
+        u64 mask = __ballot(c > (u32)(C::CAP - C::A));
+        if (G == 1) mask = (u32)mask | (u32)(mask >> 32);
         if (mask) {
             while (mask) {
-                const int jj = __builtin_ctz(mask);
+                const int jj = __builtin_ctzll(mask);
                 mask &= mask - 1;
                 compact_slot<C>(jj, cand_w, cnt_w, thr_w, a.k, lane, gthr_w);
             }
-            thr_loc = thr_w[j];
-            thr = fmaxf(thr_loc, thr_g);
-            thr_s = thr * 4096.0f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) thr_loc[g] = thr_w[32 * g + j];
+            set_thr();
         }
     };
-    constexpr int GRP = S_NI;                              // corpus VMEM ops per tile group
-    constexpr int WAITN = GRP * (S_RING - 3);              // at a tile's barrier only the newest tile may be in flight
+    constexpr int GRP = S_NI;                              // corpus VMEM ops per chunk group
+    constexpr int WAITN = GRP * (C::NR - 3);               // at a chunk's barrier only chunks >= cc + 2 may be in flight
 
     struct Acc { f32x16 a; };                          // 4096 * s~  (rows and queries are both scaled by 2^6)
     auto score = [](const Acc& p, int r) { return p.a[r] * (1.0f / 4096.0f); };
-    u32 pmask = 0, res_pos = 0;
-    auto mask_slot = [&](const Acc& prev, int r) { pmask |= (prev.a[r] > thr_s) ? (1u << r) : 0u; };
-    // Append the passing scores of one tile (bits of pmask) to this lane's query slot.  In the seeded main pass an event
-    // is almost always a single score in a single lane, so the 16 accumulator slots are visited under a wave-uniform
-    // branch each (one ballot per slot) and only slots with a passing lane pay for key + ds_add_rtn + store.  (Selecting
-    // "my lowest set bit" per lane instead made hipcc index the accumulators through scratch, and a scratch access waits
-    // vmcnt(0), i.e. drains the whole LDS-DMA ring: ~10k cycles per event.)  A position past the slot means "full": the
-    // compaction this triggers frees room and the score is retried.
+    u32 pmask[G], res_pos = 0;
+    // Append the passing scores of one tile (bits of pmask) to this lane's query slots.  In a seeded launch an event is
+    // almost always a single score in a single lane, so the accumulator slots are visited under a wave-uniform branch each
+    // (one ballot per slot) and only slots with a passing lane pay for key + ds_add_rtn + store.  A position past the slot
+    // means "full": the compaction this triggers frees room and the score is retried.
     u32 d_slow = 0, d_rounds = 0, d_comp = 0, d_app = 0;
-    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_all = a.dbg ? clock64() : 0;
-    auto slow_path = [&](const Acc& p, int64_t rbase) {
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_all = DBG ? clock64() : 0;
+    auto slow_path = [&](const Acc* p, int64_t rbase) {
         unsigned long long c0 = 0;
-        if (a.dbg) { ++d_slow; d_app += __builtin_popcount(pmask); c0 = clock64(); }
-        u32 todo = pmask;
+        if (DBG) {
+            ++d_slow;
+#pragma unroll
+            for (int g = 0; g < G; ++g) d_app += __builtin_popcount(pmask[g]);
+            c0 = clock64();
+        }
+        u32 todo[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) todo[g] = pmask[g];
+        bool again;
         do {
-            u32 left = 0;
             bool nearly_full = false;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool has = (todo >> r) & 1u;
-                if (__any(has)) {                                   // wave-uniform: most slots are skipped
-                    if (a.dbg) ++d_rounds;
-                    const u64 key = rmu_make_key(score(p, r) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(res_pos) : "v"(cnt_addr), "v"(has ? 1u : 0u) : "memory");
-                    const bool fits = has && res_pos < (u32)C::CAP;
-                    lds_store_b64_nofence(fits ? cand_addr + res_pos * 8u : trash_addr, key);
-                    nearly_full |= has && res_pos >= (u32)(C::CAP - C::A);
-                    left |= (has && !fits) ? (1u << r) : 0u;
+            for (int g = 0; g < G; ++g) {
+                // wave-uniform union of the lanes' bit masks: one ballot, then one v_readlane per lane with work (usually one)
+                u32 uni = 0;
+                for (u64 bl = __ballot(todo[g] != 0); bl; bl &= bl - 1)
+                    uni |= (u32)__builtin_amdgcn_readlane((int)todo[g], __builtin_ctzll(bl));
+                u32 left = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((uni >> r) & 1u) {                              // scalar test: most slots are skipped
+                        const bool has = (todo[g] >> r) & 1u;
+                        if (DBG) ++d_rounds;
+                        const u64 key = rmu_make_key(score(p[g], r) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(res_pos) : "v"(cnt_addr[g]), "v"(has ? 1u : 0u) : "memory");
+                        const bool fits = has && res_pos < (u32)C::CAP;
+                        lds_store_b64_nofence(fits ? cand_addr[g] + res_pos * 8u : trash_addr, key);
+                        nearly_full |= has && res_pos >= (u32)(C::CAP - C::A);
+                        left |= (has && !fits) ? (1u << r) : 0u;
+                    }
                 }
+                todo[g] = left;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (__any(nearly_full)) {                               // some slot is (nearly) full: compact, then retry what did not fit
                 check_compact();
-                if (a.dbg) ++d_comp;
+                if (DBG) ++d_comp;
             }
-            todo = left;
-        } while (__any(todo != 0));
-        if (a.dbg) d_clk_slow += clock64() - c0;
+            again = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) again |= todo[g] != 0;
+        } while (__any(again));
+        if (DBG) d_clk_slow += clock64() - c0;
     };
 
-    int tt = 0;
-    // one tile: 24 MFMAs into `acc`; the previous tile's 16 scores per lane are filtered in the first gaps (slot r behind
-    // MFMA r+1), then ONE branch (see scan_topk.hip for why).  Fragments run S_PRE steps ahead of the MFMA that eats them.
-    auto tile_body = [&](Acc& acc, Acc& prev, int64_t prev_rbase) {
+    int cc = 0;
+    // one tile = two chunks of 12 steps, G MFMAs per step into acc[g]; the previous tile's 16 scores per lane and group are
+    // filtered in the first gaps (slot r behind step r+1), then ONE branch (see scan_topk.hip for why).  Fragments run
+    // S_PRE steps ahead of the MFMAs that eat them, across the chunk boundary.
+    auto tile_body = [&](Acc* acc, Acc* prev, int64_t prev_rbase) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc.a[r] = 0.f;
-        pmask = 0;
-        unsigned long long cb = 0;
-        if (a.dbg) cb = clock64();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
-        __builtin_amdgcn_s_barrier();
-        if (a.dbg) d_clk_bar += clock64() - cb;
-        {
-            const u32 go = gt_lds[j];
-            thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
-            thr = fmaxf(thr_loc, thr_g);
-            thr_s = thr * 4096.0f;
-        }
-        refresh_gthr();
-        issue_tile(tt + S_RING - 1);
-        const int cur_off = (tt % S_RING) * S_SLOT, nxt_off = ((tt + 1) % S_RING) * S_SLOT;
+        for (int g = 0; g < G; ++g) {
 #pragma unroll
-        for (int t = 0; t < S_TS; ++t) {
-            if (t == 18 && __builtin_expect(__any(pmask != 0), 0) && !(a.share_thr & 2)) slow_path(prev, prev_rbase);
-            frag_wait(fr[t % S_PRE]);
-            acc.a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t % S_PRE], qh[t], acc.a, 0, 0, 0);
-            if (t >= 1 && t <= 16) mask_slot(prev, t - 1);
-            if (t + S_PRE < S_TS) read_frag(fr[t % S_PRE], cur_off, t + S_PRE);
-            else read_frag(fr[t % S_PRE], nxt_off, t + S_PRE - S_TS);
+            for (int r = 0; r < 16; ++r) acc[g].a[r] = 0.f;
+            pmask[g] = 0;
         }
-        ++tt;
+#pragma unroll
+        for (int c = 0; c < 2; ++c, ++cc) {
+            unsigned long long cb = 0;
+            if (DBG) cb = clock64();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (DBG) d_clk_bar += clock64() - cb;
+            if (c == 0) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const u32 go = gt_lds[32 * g + j];
+                    thr_g[g] = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
+                }
+                set_thr();
+            } else {
+                refresh_gthr();
+            }
+            issue_chunk(cc + C::NR - 1);
+            const int cur_off = (cc % C::NR) * S_SLOT, nxt_off = ((cc + 1) % C::NR) * S_SLOT;
+#pragma unroll
+            for (int t = 0; t < S_CS; ++t) {
+                const int gs = c * S_CS + t;
+                if (gs == 18 && !(a.share_thr & 2)) {
+                    bool any_pass = false;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) any_pass |= pmask[g] != 0;
+                    if (__builtin_expect(__any(any_pass), 0)) slow_path(prev, prev_rbase);
+                }
+                frag_wait(fr[gs % S_PRE]);
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    acc[g].a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[g][gs], acc[g].a, 0, 0, 0);
+                if (gs >= 1 && gs <= 16) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) pmask[g] |= (prev[g].a[gs - 1] > thr_s[g]) ? (1u << (gs - 1)) : 0u;
+                }
+                if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], cur_off, t + S_PRE);
+                else read_frag(fr[gs % S_PRE], nxt_off, t + S_PRE - S_CS);
+            }
+        }
     };
 
     if (ntiles > 0) {
         refresh_gthr();                                    // oldest VMEM op: seeded / already published thresholds
 #pragma unroll
-        for (int c0 = 0; c0 < S_RING - 1; ++c0) issue_tile(c0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP * (S_RING - 2)) : "memory");
+        for (int c0 = 0; c0 < C::NR - 1; ++c0) issue_chunk(c0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP * (C::NR - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int m = 0; m < S_PRE; ++m) read_frag(fr[m], 0, m);
-        Acc accA, accB;
+        Acc accA[G], accB[G];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accB.a[r] = -INFINITY;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[g].a[r] = -INFINITY;
         const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
         auto rb = [&](int t) { return lane_r0 + (int64_t)t * S_RT; };
         const bool last_in_a = ((ntiles - 1) & 1) == 0;   // even tiles accumulate in A
@@ -307,27 +374,31 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
             tile_body(accA, accB, rb(tl - 1));              // (tile -1 = the -inf accumulators: nothing passes)
             if (tl + 1 < ntiles) tile_body(accB, accA, rb(tl));
         }
-        // the fragment reads issued for a tile that does not exist are still in flight: their registers must stay
+        // the fragment reads issued for a chunk that does not exist are still in flight: their registers must stay
         // allocated until the data has landed (the compiler sees dead values and would reuse the registers under them)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int m = 0; m < S_PRE; ++m) asm volatile("" : "+v"(fr[m]));
         {
-            Acc last;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) last.a[r] = last_in_a ? accA.a[r] : accB.a[r];
+            Acc last[G];
             const int64_t rbl = rb(ntiles - 1);
             const int64_t row_end = a.row0 + a.n_rows;
-            pmask = 0;
+            bool any_pass = false;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                mask_slot(last, r);
-                if (rbl + (r & 3) + 8 * (r >> 2) >= row_end) pmask &= ~(1u << r);
+            for (int g = 0; g < G; ++g) {
+                pmask[g] = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    last[g].a[r] = last_in_a ? accA[g].a[r] : accB[g].a[r];
+                    const bool in_range = rbl + (r & 3) + 8 * (r >> 2) < row_end;
+                    pmask[g] |= (in_range && last[g].a[r] > thr_s[g]) ? (1u << r) : 0u;
+                }
+                any_pass |= pmask[g] != 0;
             }
-            if (__any(pmask != 0)) slow_path(last, rbl);
+            if (__any(any_pass)) slow_path(last, rbl);
         }
     }
-    if (a.dbg) {
+    if (DBG) {
         u32 app = d_app;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) app += __shfl_xor(app, o);
@@ -344,8 +415,8 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     }
     // ---- emit: best K' approximate candidates of this (chunk, query), sorted ---------------------------------------------
     const int part = s_idx;
-    for (int jj = 0; jj < 32; ++jj) {
-        const int qq = (qt * 4 + w) * 32 + jj;
+    for (int jj = 0; jj < C::QW; ++jj) {
+        const int qq = q_base + jj;
         if (qq >= a.nq) break;
         const u32 n = cnt_w[jj];
         u64 key[1];
@@ -434,31 +505,65 @@ int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStrea
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-template <int EXP, int PRE = 4>
+template <int G, int EXP = 0, int PRE = 4>
 static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)scan_screen_kernel<EXP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                ScreenCfg::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)scan_screen_kernel<G, EXP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ScreenCfg<G>::LDS_BYTES) != hipSuccess)
             return RMU_E_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((scan_screen_kernel<EXP, PRE>), dim3(p->grid), dim3(256), ScreenCfg::LDS_BYTES, s, *p);
+    hipLaunchKernelGGL((scan_screen_kernel<G, EXP, PRE>), dim3(p->grid), dim3(256), ScreenCfg<G>::LDS_BYTES, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-int rmu_screen_lds_bytes() { return ScreenCfg::LDS_BYTES; }
+int rmu_screen_lds_bytes(int qg) { return qg == 2 ? ScreenCfg<2>::LDS_BYTES : ScreenCfg<1>::LDS_BYTES; }
+
+// geometry of one screening launch: p->qg 32-query groups per wave (2 when the batch fills 256-query workgroups),
+// S row chunks (a multiple of 8 for the XCD-aware block map) so that grid = S * nqt fills the 256 CUs evenly
+int rmu_screen_plan(ScanLaunch* p) {
+    if (p->k < 1 || p->k > 32 || p->nq < 1 || p->n_rows < 0 || p->dpad != SD) return RMU_E_INVALID;
+    static const int force_g = getenv("RMU_SCREEN_G") ? atoi(getenv("RMU_SCREEN_G")) : 0;
+    p->qg = force_g == 1 || force_g == 2 ? force_g : (p->nq > 128 ? 2 : 1);
+    p->wq = 4; p->kv = 0;
+    const int qwg = 128 * p->qg;
+    p->nqt = (p->nq + qwg - 1) / qwg;
+    const int64_t tiles_total = (p->n_rows + S_RT - 1) / S_RT;
+    int best_s = 8;
+    double best_eff = -1.0;
+    for (int s = 8; s <= 256; s += 8) {
+        const int64_t total = (int64_t)s * p->nqt;
+        const double eff = (double)total / (double)(((total + 255) / 256) * 256);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best_s = s; }
+        if (total >= 256 && eff > 0.999) break;
+    }
+    int s = best_s;
+    if (tiles_total < s) s = tiles_total > 0 ? (int)tiles_total : 1;
+    p->tiles_per_chunk = (int)((tiles_total + s - 1) / s);
+    if (p->tiles_per_chunk < 1) p->tiles_per_chunk = 1;
+    const int64_t used = (tiles_total + p->tiles_per_chunk - 1) / p->tiles_per_chunk;
+    if (used > 0 && used < s) s = (int)used;
+    p->s_chunks = s;
+    p->grid = s * p->nqt;
+    p->parts = s;
+    p->lds_bytes = rmu_screen_lds_bytes(p->qg);
+    return RMU_OK;
+}
 
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;   // timing ablations, wrong results
-    if (ex == 1) return screen_launch_cfg<1>(p, s);
-    if (ex == 2) return screen_launch_cfg<2>(p, s);
-    if (ex == 3) return screen_launch_cfg<3>(p, s);
     static const int pre = getenv("RMU_SCREEN_SPRE") ? atoi(getenv("RMU_SCREEN_SPRE")) : 4;
-    if (pre == 6) return screen_launch_cfg<0, 6>(p, s);
-    if (pre == 8) return screen_launch_cfg<0, 8>(p, s);
-    if (pre == 3) return screen_launch_cfg<0, 3>(p, s);
-    return screen_launch_cfg<0>(p, s);
+    if (p->dbg) return p->qg == 2 ? screen_launch_cfg<2, 4>(p, s) : screen_launch_cfg<1, 4>(p, s);
+    if (p->qg == 2) {
+        if (ex == 1) return screen_launch_cfg<2, 1>(p, s);
+        if (ex == 2) return screen_launch_cfg<2, 2>(p, s);
+        if (ex == 3) return screen_launch_cfg<2, 3>(p, s);
+        if (pre == 6) return screen_launch_cfg<2, 0, 6>(p, s);
+        if (pre == 3) return screen_launch_cfg<2, 0, 3>(p, s);
+        return screen_launch_cfg<2>(p, s);
+    }
+    return screen_launch_cfg<1>(p, s);
 }
 
 int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s) {
