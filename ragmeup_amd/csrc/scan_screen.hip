@@ -46,14 +46,14 @@ constexpr int S_NI = S_RT * S_U16 / 256;  // 3 DMA wave-instructions per wave pe
 // need 4 x 1 KiB per 32-cycle MFMA = all 128 B/clk of the LDS before the DMA writes are counted (ablations in
 // DESIGN.md 4.3).  With G = 2 every A fragment feeds two MFMAs (64 queries per wave, 256 per workgroup), halving LDS
 // and L2 bytes per MFMA; the price is 80 KiB of candidate slots, hence the smaller ring slots and CAP.
-template <int G>
+template <int G, int NRV = 0>
 struct ScreenCfg {
     // K' = 32 candidates per (chunk, query).  Appends reserve their position with ds_add_rtn; a position past the slot
     // is retried after the compaction (back to K' entries) that it triggers, and a slot is compacted early once an
     // append lands in its last A entries.
     static constexpr int QW = 32 * G;                       // queries per wave
     static constexpr int CAP = G == 2 ? 40 : 56, NPL = 1, A = 4;
-    static constexpr int NR = G == 2 ? 6 : 8;               // ring slots
+    static constexpr int NR = NRV ? NRV : (G == 2 ? 6 : 8);   // ring slots (NRV: ring-depth experiments)
     static constexpr int RING_BYTES = NR * S_SLOT;
     static constexpr int CAND_BYTES = 4 * QW * CAP * 8;
     static constexpr int CNT_OFF = RING_BYTES + CAND_BYTES;
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, in
     if (lane == 0) err2[r] = s * 1.0001f;   // summation slack
 }
 
-// EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads; bit 2 = debug counters
+// EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads, bit 3 no filter VALU; bit 2 = debug counters
 // S_PRE = A-fragment prefetch depth in steps
-template <int G, int EXP = 0, int S_PRE = 4>
+template <int G, int EXP = 0, int S_PRE = 4, int NRV = 0>
 __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
-    using C = ScreenCfg<G>;
+    using C = ScreenCfg<G, NRV>;
     constexpr bool DBG = (EXP & 4) != 0;   // cycle / event counters into a.dbg (RMU_SCAN_EXP=7)
     static_assert(S_CS % S_PRE == 0, "fragment register ring must close over a chunk");
     const int lane = threadIdx.x & 63;
@@ -176,16 +176,21 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16);
     }
     const int nchunks = 2 * ntiles;
-    auto issue_chunk = [&](int cc) {
+    // one of the S_NI LDS-DMA instructions of chunk cc.  They are issued one at a time between MFMA steps, not as a burst
+    // behind the barrier: a wave that cannot hand its VMEM instruction to the (busy) address unit cannot issue MFMAs either,
+    // and twelve back-to-back 1-KiB DMA instructions per chunk and workgroup cost ~700 cycles per tile that way.
+    auto issue_part = [&](int cc, int n) {
         if (EXP & 1) return;   // ablation: no corpus DMA at all
         int ce = cc;
         if (ce >= nchunks) ce = nchunks - 1;
         const char* sbase = img + ((t0 + (ce >> 1)) * S_RT) * (int64_t)IMGB + (ce & 1) * S_CKB;
         char* slot = ring + (cc % C::NR) * S_SLOT;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
+                                         (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
+    };
+    auto issue_chunk = [&](int cc) {
 #pragma unroll
-        for (int n = 0; n < S_NI; ++n)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
-                                             (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
+        for (int n = 0; n < S_NI; ++n) issue_part(cc, n);
     };
     // A fragment of (row j, chunk step t): logical unit 2t + h = 8 (t >> 2) + (2 (t & 3) + h); the XOR touches the low three
     // bits only, so four per-lane bases + an immediate (t >> 2) * 128 address a whole chunk
@@ -253,8 +258,16 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     // means "full": the compaction this triggers frees room and the score is retried.
     u32 d_slow = 0, d_rounds = 0, d_comp = 0, d_app = 0;
     unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_all = DBG ? clock64() : 0;
-    auto slow_path = [&](const Acc* p, int64_t rbase) {
+    auto slow_path = [&](const Acc* p, int64_t rbase, bool recompute) {
         unsigned long long c0 = 0;
+        if (recompute) {      // the hot loop only kept a wave-wide "any lane passed" flag (scalar unit): per-lane bits are made here
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                pmask[g] = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pmask[g] |= (p[g].a[r] > thr_s[g]) ? (1u << r) : 0u;
+            }
+        }
         if (DBG) {
             ++d_slow;
 #pragma unroll
@@ -310,8 +323,8 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         for (int g = 0; g < G; ++g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g].a[r] = 0.f;
-            pmask[g] = 0;
         }
+        u64 any_pass = 0;     // OR of the v_cmp lane masks: lives in an SGPR pair, costs one VALU op per score (the compare)
 #pragma unroll
         for (int c = 0; c < 2; ++c, ++cc) {
             unsigned long long cb = 0;
@@ -329,27 +342,22 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
             } else {
                 refresh_gthr();
             }
-            issue_chunk(cc + C::NR - 1);
             const int cur_off = (cc % C::NR) * S_SLOT, nxt_off = ((cc + 1) % C::NR) * S_SLOT;
 #pragma unroll
             for (int t = 0; t < S_CS; ++t) {
                 const int gs = c * S_CS + t;
-                if (gs == 18 && !(a.share_thr & 2)) {
-                    bool any_pass = false;
-#pragma unroll
-                    for (int g = 0; g < G; ++g) any_pass |= pmask[g] != 0;
-                    if (__builtin_expect(__any(any_pass), 0)) slow_path(prev, prev_rbase);
-                }
+                if (gs == 18 && !(a.share_thr & 2) && __builtin_expect(any_pass != 0, 0)) slow_path(prev, prev_rbase, true);
                 frag_wait(fr[gs % S_PRE]);
 #pragma unroll
                 for (int g = 0; g < G; ++g)
                     acc[g].a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[g][gs], acc[g].a, 0, 0, 0);
-                if (gs >= 1 && gs <= 16) {
+                if (gs >= 1 && gs <= 16 && !(EXP & 8)) {
 #pragma unroll
-                    for (int g = 0; g < G; ++g) pmask[g] |= (prev[g].a[gs - 1] > thr_s[g]) ? (1u << (gs - 1)) : 0u;
+                    for (int g = 0; g < G; ++g) any_pass |= __ballot(prev[g].a[gs - 1] > thr_s[g]);
                 }
                 if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], cur_off, t + S_PRE);
                 else read_frag(fr[gs % S_PRE], nxt_off, t + S_PRE - S_CS);
+                if (t % 4 == 1) issue_part(cc + C::NR - 1, t / 4);      // steps 1, 5, 9: the chunk's three DMA instructions
             }
         }
     };
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
                 }
                 any_pass |= pmask[g] != 0;
             }
-            if (__any(any_pass)) slow_path(last, rbl);
+            if (__any(any_pass)) slow_path(last, rbl, false);
         }
     }
     if (DBG) {
@@ -505,16 +513,17 @@ int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStrea
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-template <int G, int EXP = 0, int PRE = 4>
+template <int G, int EXP = 0, int PRE = 4, int NRV = 0>
 static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)scan_screen_kernel<G, EXP, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                ScreenCfg<G>::LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)scan_screen_kernel<G, EXP, PRE, NRV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ScreenCfg<G, NRV>::LDS_BYTES) != hipSuccess)
             return RMU_E_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((scan_screen_kernel<G, EXP, PRE>), dim3(p->grid), dim3(256), ScreenCfg<G>::LDS_BYTES, s, *p);
+    constexpr int lds = ScreenCfg<G, NRV>::LDS_BYTES;
+    hipLaunchKernelGGL((scan_screen_kernel<G, EXP, PRE, NRV>), dim3(p->grid), dim3(256), lds, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
@@ -554,11 +563,24 @@ int rmu_screen_plan(ScanLaunch* p) {
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;   // timing ablations, wrong results
     static const int pre = getenv("RMU_SCREEN_SPRE") ? atoi(getenv("RMU_SCREEN_SPRE")) : 4;
-    if (p->dbg) return p->qg == 2 ? screen_launch_cfg<2, 4>(p, s) : screen_launch_cfg<1, 4>(p, s);
+    if (p->dbg) {
+        if (p->qg == 2 && ex == 8) return screen_launch_cfg<2, 12>(p, s);
+        if (p->qg == 2 && ex == 9) return screen_launch_cfg<2, 13>(p, s);
+        if (p->qg == 2 && ex == 10) return screen_launch_cfg<2, 14>(p, s);
+        if (p->qg == 2 && ex == 11) return screen_launch_cfg<2, 15>(p, s);
+        return p->qg == 2 ? screen_launch_cfg<2, 4>(p, s) : screen_launch_cfg<1, 4>(p, s);
+    }
     if (p->qg == 2) {
         if (ex == 1) return screen_launch_cfg<2, 1>(p, s);
         if (ex == 2) return screen_launch_cfg<2, 2>(p, s);
         if (ex == 3) return screen_launch_cfg<2, 3>(p, s);
+        if (ex == 8) return screen_launch_cfg<2, 8>(p, s);
+        if (ex == 9) return screen_launch_cfg<2, 9>(p, s);
+        if (ex == 10) return screen_launch_cfg<2, 10>(p, s);
+        if (ex == 11) return screen_launch_cfg<2, 11>(p, s);
+        static const int nrv = getenv("RMU_SCREEN_NR") ? atoi(getenv("RMU_SCREEN_NR")) : 0;
+        if (nrv == 4) return screen_launch_cfg<2, 0, 4, 4>(p, s);
+        if (nrv == 5) return screen_launch_cfg<2, 0, 4, 5>(p, s);
         if (pre == 6) return screen_launch_cfg<2, 0, 6>(p, s);
         if (pre == 3) return screen_launch_cfg<2, 0, 3>(p, s);
         return screen_launch_cfg<2>(p, s);

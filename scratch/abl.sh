@@ -12,10 +12,7 @@ except Exception as e:
 PY
 }
 run base
-RMU_SCREEN_RATIO=2 run r2
-RMU_SCREEN_RATIO=4 run r4
-RMU_SCREEN_MINLVL=1024 run m1k
-RMU_SCREEN_G=1 run g1
 RMU_SCREEN_NOFILTER=1 run nofilter
 run base1m "--rows 1000000"
-RMU_SCAN_EXP=7 python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "rmu dbg" | tail -11
+run b512 "--batch 512"
+run b2048 "--batch 2048"
