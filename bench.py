@@ -3,7 +3,9 @@
 
 Metric (BASELINE.json): queries/sec of exact dense top-10 over a 10M x 384 fp32 corpus resident in
 HBM, batch = 1024 queries per step.  A "step" = one pass of the hot path over one query batch:
-local fused scan+top-k -> (N>1: one RCCL all-gather of per-shard top-k) -> merge.
+rmu_index_search (default: fp16 screening ladder -> merges -> exact fp32 re-score of 32 candidates per query, results
+bit-identical to the exact fp32 scan; RMU_SCREEN=0: the exact fp32 fused scan+top-k) -> (N>1: one RCCL all-gather of
+per-shard top-k) -> merge.
 N GPUs: the 10M rows are sharded N ways (strong scaling: total work fixed), one process per GPU.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--batch B] [--k K]
@@ -30,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-SCREEN_TRAFFIC = None   # HBM bytes per step of the screening launches from rocprofv3 PMC (profiles/); None = not re-measured
+SCREEN_TRAFFIC = 1.3675e10   # HBM bytes per 10M x 1024 batch over all screening launches: rocprofv3 PMC, profiles/r01_summary.md
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (the 5 PF figure is 2:1 sparse)
 
 
@@ -168,7 +170,7 @@ def main():
     # exact configuration and committed under profiles/; null for any other configuration.
     traffic = None
     if world == 1 and N == 10_000_000 and D == 384 and K == 10 and B in (1024, 1):
-        traffic = {1024: 2 * 7.881e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
+        traffic = {1024: 2 * 8.027e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
     path = "exact-f32"
     rerun = 0
     if all(v != 0 for v in screened):

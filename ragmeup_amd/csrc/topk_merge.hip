@@ -28,6 +28,33 @@ __device__ __forceinline__ void merge_stream(u64 (&top)[NPL], int64_t m, int lan
     }
 }
 
+// Same fold, visiting the part lists rank slab by rank slab (ranks [4s, 4s+4) of every part): the lists are sorted with
+// their zeros last, so the first slab that holds no key at all ends the merge.  The screening ladder's seeded launches
+// leave one to three candidates per (chunk, query); this reads ~1/4 of the keys a part-major sweep would.
+template <int NPL, class LoadKey>
+__device__ __forceinline__ void merge_stream_slabs(u64 (&top)[NPL], int np, int k, int lane, LoadKey load /* (part, pos) */) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) top[p] = 0ull;
+    for (int s0 = 0; s0 < k; s0 += 4) {
+        bool any = false;
+        const int m = np * 4;
+        for (int b0 = 0; b0 < m; b0 += 64) {
+            u64 bk[1];
+            const int i = b0 + lane;
+            const int pos = s0 + (i & 3);
+            bk[0] = (i < m && pos < k) ? load(i >> 2, pos) : 0ull;
+            if (!__any(bk[0] != 0ull)) continue;
+            any = true;
+            rmu_bitonic_sort_desc<1>(bk, lane);
+            const u64 rev = __shfl(bk[0], 63 - lane);
+            u64& tail = top[NPL - 1];
+            tail = tail > rev ? tail : rev;
+            rmu_bitonic_merge_desc<NPL>(top, lane);
+        }
+        if (!any) break;
+    }
+}
+
 // level-1 of the two-level merge: wave (q, g) folds parts [g*ppg, (g+1)*ppg) into k keys -> scratch[g][q][k]
 template <int NPL>
 __global__ __launch_bounds__(256) void merge_keys_partial_kernel(const u64* __restrict__ partial, int parts, int64_t nq,
@@ -40,9 +67,8 @@ __global__ __launch_bounds__(256) void merge_keys_partial_kernel(const u64* __re
     const int p0 = g * ppg;
     const int np = min(ppg, parts - p0);
     u64 top[NPL];
-    merge_stream<NPL>(top, (int64_t)(np > 0 ? np : 0) * k, lane, [&](int64_t idx) {
-        const int64_t part = p0 + idx / k, pos = idx % k;
-        return partial[(part * nq + q) * k + pos];
+    merge_stream_slabs<NPL>(top, np > 0 ? np : 0, k, lane, [&](int part, int pos) {
+        return partial[((int64_t)(p0 + part) * nq + q) * k + pos];
     });
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {

@@ -1,8 +1,50 @@
-"""Condense profiles/r01_*_stats.csv + r01_pmc_means.csv (made from gpurun_out/<tag> by tools/profile.sh) into
-profiles/r01_summary.md."""
+"""Condense the output of tools/profile.sh (gpurun_out/<tag>/) into tracked files under profiles/:
+  r01_<run>_stats.csv / _bench.json   rocprofv3 --kernel-trace --stats tables and the bench line of the same command
+  r01_pmc_means.csv                   PMC counters: per kernel, mean per dispatch AND sum per bench step
+  r01_summary.md                      the tables + derived HBM traffic / MFMA-busy / clock figures
+usage: python tools/summarize_profiles.py r01d"""
 import collections
 import csv
+import glob
 import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01d"
+src = f"gpurun_out/{tag}"
+STEPS = 12   # tools/profile.sh runs bench.py with --steps 10 --warmup 2
+
+
+def short(n):
+    m = re.search(r'(scan_topk_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
+                  r'merge_lists_kernel|k_gemm<\d, \d, \d+, \d>|k_attention|k_layernorm|k_embed_ln|k_meanpool_l2|k_cls_head)', n)
+    s = m.group(1) if m else n[:40]
+    if s in ('scan_topk_kernel',):
+        c = re.search(r'Cfg<([^>]*)>', n)
+        s += '<Cfg<%s>>' % c.group(1).replace(', ', ';') if c else ''
+    return s
+
+
+rows = []
+for f in sorted(glob.glob(src + '/*_counters.csv')):
+    p = os.path.basename(f).replace('_counters.csv', '')
+    acc = collections.defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(f)):
+        k = (short(r['Kernel_Name']), r['Counter_Name'])
+        acc[k].append(float(r['Counter_Value']))
+        meta[k[0]] = (r['Workgroup_Size'], r['LDS_Block_Size'], r['Scratch_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'])
+    for (kn, cn), v in sorted(acc.items()):
+        rows.append((p, kn, cn, len(v), sum(v) / len(v), sum(v) / STEPS) + meta[kn])
+with open('profiles/r01_pmc_means.csv', 'w') as o:
+    o.write('pass,kernel,counter,dispatches,mean_per_dispatch,sum_per_bench_step,wg,lds_block,scratch,vgpr,agpr,sgpr\n')
+    for r in rows:
+        o.write(','.join(str(x) for x in r) + '\n')
+for t in ['scan', 'exact', 'scan_b1', 'embed']:
+    shutil.copy(f'{src}/{t}_stats.csv', f'profiles/r01_{t}_stats.csv')
+    open(f'profiles/r01_{t}_bench.json', 'w').write(open(f'{src}/{t}_bench.json').read().strip().splitlines()[-1] + '\n')
 
 
 def stats(t, title):
@@ -14,52 +56,59 @@ def stats(t, title):
     if 'roofline' in b:
         rf = b['roofline']
         out.append(f"\nbench line of the same command (`profiles/r01_{t}_bench.json`): value {b['value']} {b['unit']}, ms_per_step {b['ms_per_step']}, "
-                   f"hipEvent kernel_ms {rf['kernel_ms']}, roofline {rf['bound']} {rf['achieved']} / {rf['peak']} {rf['unit']} = {rf['frac']}")
+                   f"hipEvent kernel_ms {rf['kernel_ms']} over {rf['launch']['launches']} launch(es), roofline {rf['bound']} {rf['achieved']} / {rf['peak']} {rf['unit']} = {rf['frac']}")
     else:
         out.append(f"\nbench line (`profiles/r01_{t}_bench.json`): {json.dumps(b)}")
     return "\n".join(out) + "\n"
 
 
 pm = collections.defaultdict(dict)
-for r in csv.DictReader(open('profiles/r01_pmc_means.csv')):
-    d = pm[(r['pass'], r['kernel'])]
-    d[r['counter']] = float(r['mean'])
-    d['_n'] = r['dispatches']
-    d['_meta'] = f"grid {r['grid']} wg {r['wg']} lds {r['lds_block']} scratch {r['scratch']} vgpr {r['vgpr']} agpr {r['agpr']} sgpr {r['sgpr']}"
+for r in rows:
+    d = pm[(r[0], r[1])]
+    d[r[2]] = (r[4], r[5])
+    d['_n'] = r[3]
+    d['_meta'] = f"wg {r[6]} lds {r[7]} scratch {r[8]} vgpr {r[9]} agpr {r[10]} sgpr {r[11]}"
 
 
 def line(p, k):
     d = pm[(p, k)]
-    return f"- `{p}` `{k}` ({d['_n']} dispatches; {d['_meta']}): " + ", ".join(f"{c}={v:.4g}" for c, v in d.items() if not c.startswith('_'))
+    return (f"- `{p}` `{k}` ({d['_n']} dispatches in {STEPS} bench steps; {d['_meta']}), per bench step: "
+            + ", ".join(f"{c}={v[1]:.4g}" for c, v in d.items() if not c.startswith('_')))
 
 
 SK = 'scan_screen_kernel'
 EK = 'scan_topk_kernel<Cfg<384;4;96;4;64;1;0;1>>'
 B1 = 'scan_topk_kernel<Cfg<384;1;48;3;64;1;0;0>>'
-f = lambda p, k, c: pm[(p, k)][c]
+f = lambda p, k, c: pm[(p, k)][c][1]      # per bench step
+sb = json.loads(open('profiles/r01_scan_bench.json').read())
+eb = json.loads(open('profiles/r01_exact_bench.json').read())
+k_ms, e_ms = sb['roofline']['kernel_ms'], eb['roofline']['kernel_ms']
+scr_fetch = f('pmc_b', SK, 'FETCH_SIZE') * 2048
+scr_write = f('pmc_c', SK, 'WRITE_SIZE') * 1024
 hit = f('pmc_c', SK, 'TCC_HIT_sum') / (f('pmc_c', SK, 'TCC_HIT_sum') + f('pmc_c', SK, 'TCC_MISS_sum'))
+clk_s = f('pmc_a', SK, 'GRBM_GUI_ACTIVE') / 8 / (k_ms * 1e-3) / 1e9
+clk_e = f('exact_pmc_a', EK, 'GRBM_GUI_ACTIVE') / 8 / (e_ms * 1e-3) / 1e9
 txt = [
     "# Round 1 rocprofv3 summary (MI355X, gfx950, ROCm 7.2)",
-    "Produced by `tools/profile.sh r01b` on the GPU box, condensed by `tools/summarize_profiles.py`; per-kernel CSVs:",
-    "`r01_*_stats.csv`, counters (mean/min/max per dispatch): `r01_pmc_means.csv`.\n",
-    stats('scan', 'headline bench (10M x 384 fp32, batch 1024, top-10), default path = fp16 hi/lo screening + exact fp32 re-score'),
+    f"Produced by `tools/profile.sh {tag}` on the GPU box, condensed by `tools/summarize_profiles.py {tag}`; per-kernel tables:",
+    "`r01_*_stats.csv`; counters (mean per dispatch and sum per bench step): `r01_pmc_means.csv`.  The screening path launches its",
+    "kernel once per row range of the threshold ladder (7 launches per 10M-row batch), so its counters are summed per bench step.\n",
+    stats('scan', 'headline bench (10M x 384 fp32, batch 1024, top-10), default path = fp16 screening ladder + exact fp32 re-score'),
     stats('exact', 'same workload forced onto the exact fp32 scan (`RMU_SCREEN=0`)'),
     stats('scan_b1', 'HBM-bound regime: batch 1 (exact fp32 scan, WQ=1 geometry)'),
     stats('embed', 'encoder: 4 calls x 8192 chunks x ~128 tokens (BERT-6x384, bf16 MFMA)'),
-    "## PMC passes (separate runs, `--kernel-trace --pmc ...` only), mean per dispatch\n",
+    "## PMC passes (separate runs, `--kernel-trace --pmc ...` only)\n",
     line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', B1),
     "\n## Derived (FETCH_SIZE is in KiB and under-reports by 2x on gfx950 per MI355X_MICROARCH.md -> bytes = FETCH_SIZE x 1024 x 2)\n",
-    f"- screening kernel: HBM fetch {f('pmc_b',SK,'FETCH_SIZE')*2048/1e9:.2f} GB per launch; its input is the fp16 hi/lo image (15.36 GB, same bytes as the "
-    f"fp32 corpus) and each of the 8 query tiles (128 queries) streams it once -> re-reads are absorbed by L2 only while the 8 tiles of a "
-    f"row chunk run close together in time (L2 hit {hit:.3f}); MFMA busy "
-    f"{f('pmc_a',SK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('pmc_a',SK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles "
-    f"(SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 256 CUs x 4 SIMDs)); mean clock over the launch "
-    f"{f('pmc_a',SK,'GRBM_GUI_ACTIVE')/8/25.2e-3/1e9:.2f} GHz (GRBM_GUI_ACTIVE/8 / 25.2 ms) -- the part down-clocks under the combined MFMA + HBM load, "
-    f"so 0.38 of the 2.4 GHz MFMA peak is 0.46 of the cycles it actually had; WRITE {f('pmc_c',SK,'WRITE_SIZE')*1024/1e6:.1f} MB",
+    f"- screening launches, per batch: HBM fetch {scr_fetch/1e9:.2f} GB + write {scr_write/1e6:.1f} MB; the fp16 image is 7.68 GB and each of the 4 "
+    f"query-tile workgroups of a row chunk streams it (L2 hit {hit:.3f}; ideal 0.75), i.e. x{scr_fetch/7.68e9:.2f} the image, x{scr_fetch/15.36e9:.2f} the "
+    f"fp32 corpus the exact scan reads; MFMA busy {f('pmc_a',SK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('pmc_a',SK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles "
+    f"(SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 256 CUs x 4 SIMDs)); mean clock over the launches "
+    f"{clk_s:.2f} GHz (GRBM_GUI_ACTIVE/8 / {k_ms} ms): the part down-clocks from 2.4 GHz under the combined MFMA + LDS + L2 load",
     f"- exact kernel: HBM fetch {f('exact_pmc_b',EK,'FETCH_SIZE')*2048/1e9:.2f} GB per launch vs 15.36 GB algorithmic (x{f('exact_pmc_b',EK,'FETCH_SIZE')*2048/15.36e9:.3f}); "
-    f"MFMA busy {f('exact_pmc_a',EK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('exact_pmc_a',EK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles; "
-    f"mean clock {f('exact_pmc_a',EK,'GRBM_GUI_ACTIVE')/8/56.8e-3/1e9:.2f} GHz",
+    f"MFMA busy {f('exact_pmc_a',EK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('exact_pmc_a',EK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles; mean clock {clk_e:.2f} GHz",
     f"- batch 1: HBM fetch {f('pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
 ]
 open('profiles/r01_summary.md', 'w').write("\n".join(txt) + "\n")
 print("\n".join(txt[-4:]))
+print("SCREEN_TRAFFIC =", scr_fetch + scr_write)
