@@ -317,6 +317,46 @@ def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
     idx.close()
 
 
+@pytest.mark.parametrize("n,nq,k", [(300_000, 384, 10), (262_144 + 17, 129, 16), (700_001, 1024, 5)])
+def test_screened_ladder_matches_oracle_and_exact_path(rmu, n, nq, k):
+    """n >= 262144 rows: the corpus is scanned as a ladder of row ranges whose merged K'-th best seeds the next launch's
+    thresholds (ragged last tiles, partial query tiles, 1- and 2-group wave geometries)."""
+    x = O.make_corpus(n, seed=21)
+    q, planted = O.make_queries(x, nq, seed=22)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    s, r = idx.search(q, k)
+    assert idx.last_screened() != 0, "expected the screening path"
+    assert idx.last_geometry()["launches"] >= 3, "expected a multi-launch ladder"
+    s2, r2 = idx.search(q, 17)                       # exact fp32 scan
+    assert idx.last_screened() == 0
+    assert np.array_equal(r2[:, :k], r) and np.array_equal(s2[:, :k], s)          # bit-identical
+    assert (r[:, 0] == planted).all()
+    sub = slice(0, 96)                               # oracle (fp64 numpy) on a subset of the queries: seconds, not minutes
+    assert_topk_parity(s[sub], r[sub], *O.flat_search(q[sub], x, k + 4))
+    idx.close()
+
+
+def test_screened_ladder_after_deletes_and_reload(rmu, tmp_path):
+    x = O.make_corpus(280_000, seed=23)
+    q, planted = O.make_queries(x, 200, seed=24)
+    idx = rmu.FlatIndex(384)
+    idx.add(x[:150_000]); idx.add(x[150_000:])
+    dead = np.unique(planted[:60])
+    idx.remove_rows(dead)
+    s, r = idx.search(q, 10)
+    assert idx.last_screened() != 0 and not np.isin(r, dead).any()
+    s2, r2 = idx.search(q, 17)
+    assert np.array_equal(r2[:, :10], r) and np.array_equal(s2[:, :10], s)
+    path = str(tmp_path / "big.rmu")
+    idx.save(path)
+    idx2 = rmu.FlatIndex.load(path)
+    s3, r3 = idx2.search(q, 10)
+    assert idx2.last_screened() != 0
+    assert np.array_equal(r3, r) and np.array_equal(s3, s)
+    idx.close(); idx2.close()
+
+
 def test_screened_search_falls_back_on_dense_ties(rmu):
     """More than K' = 32 exact duplicates of the best row: the sufficiency test must flag that query and the exact scan
     must answer it (only it: the other 199 stay on the screened path) -- ids in ascending-row order among the ties."""
