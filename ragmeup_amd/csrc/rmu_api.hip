@@ -565,10 +565,13 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         };
         // ---- screened path: fp16 scan proposes K' = 32 candidates, exact fp32 re-score decides -------------------------
         bool done = false;
-        static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 128;
+        static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
         static const int lvl_min = getenv("RMU_SCREEN_MINLVL") ? atoi(getenv("RMU_SCREEN_MINLVL")) : 256;
-        static const int lvl_ratio = getenv("RMU_SCREEN_RATIO") ? atoi(getenv("RMU_SCREEN_RATIO")) : 3;   // <= 1: single launch
-        if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && k <= 16 && idx->n > 0 &&
+        static const int lvl_ratio_env = getenv("RMU_SCREEN_RATIO") ? atoi(getenv("RMU_SCREEN_RATIO")) : 0;   // <= 1: single launch
+        // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays ~0.35 ms of
+        // launches and merges per batch, which only pays off on a large enough corpus
+        const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || getenv("RMU_SCREEN_MIN_NQ");
+        if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && screen_pays && k <= 24 && idx->n > 0 &&
             idx->xnorm_max > 0.f && idx->xnorm_max < 500.f) {   // fp16(64*x) must not overflow
             const int kp = 32;
             // Threshold ladder: the corpus is scanned in row ranges of geometrically growing size (ratio 3, first >= 2k
@@ -576,6 +579,9 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             // shared per-query thresholds of the next launch.  A cold launch appends K' ln(rows/K') candidates per query
             // and CHUNK, a seeded one only K' (ratio - 1) per query in total, and every append stalls a whole workgroup
             // for ~3k cycles: this cut the filter overhead of the 10M x 1024 scan from 5.2 to ~2 ms.
+            // ratio 3 for full batches; small batches (one query tile, HBM-bound: 7.68 GB image per batch) have few appends to
+            // save and pay for every launch gap and merge, so they climb faster
+            const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
             std::vector<int64_t> bounds{idx->n};
             if (lvl_ratio > 1 && idx->n >= 262144) {
                 int64_t c = idx->n / lvl_ratio / 32 * 32;
