@@ -70,6 +70,16 @@ int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, int6
  * `col.query(expr="pk in [...]", output_fields=[vector])` round trip (RAGHelper.py:497-499). */
 int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, float* out_host);
 
+/* Batched greedy maximal-marginal-relevance selection on the device (fp64, one wave per query): for query i pick k of the
+ * fetch_k candidate rows rows[i, :] (index-local ids as rmu_index_search returned them, -1 = absent): first the candidate
+ * most similar to the query, then repeatedly argmax lambda*cos(q,x) - (1-lambda)*max cos(x, picked), lowest position on
+ * ties.  out_pos [nq, k] int32 = positions in the candidate list (-1 past the number of candidates).
+ * flags: RMU_F_Q_DEVICE (q), RMU_F_OUT_DEVICE (rows and out_pos).  fetch_k <= 64.
+ * Serves: VectorStoreRetriever(search_type="mmr") -> maximal_marginal_relevance (RAGHelper.py:497-499) without the
+ * per-query "fetch 20 vectors by pk" round trip. */
+int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const int64_t* rows, int fetch_k, int k,
+                  double lambda_mult, unsigned flags, int32_t* out_pos);
+
 /* Persist / restore the corpus matrix (flat file: 64-byte header, liveness bytes, fp32 rows; restart = one H2D copy).
  * Serves: the Milvus-Lite `data.db` the reference re-opens when vector_store_initial_load is False
  * (RAGHelper.py:391, :417; .env.template:33,36).  Tombstones survive (poisoned rows are stored as they are). */

@@ -163,6 +163,63 @@ __global__ void k_scatter_results(const float* src_s, const int64_t* src_r, cons
     dst_r[pos[i] * k + threadIdx.x] = src_r[i * k + threadIdx.x];
 }
 
+// Batched greedy MMR (langchain_core `maximal_marginal_relevance`, the reference retriever's search_type="mmr",
+// server/RAGHelper.py:497-499): one wave per query, lane i = candidate i (fetch_k <= 64), fp64 like the numpy original.
+//   first pick = argmax_i cos(q, x_i); then repeatedly argmax_i  lambda*cos(q, x_i) - (1-lambda)*max_{s picked} cos(x_i, x_s),
+//   strict '>' so the lowest index wins ties; cos = dot / (|a||b|), NaN/inf -> 0.
+// rows: [nq, fetch_k] index-local row ids (-1 = absent, as rmu_index_search pads them); out_pos: [nq, k] positions in the
+// candidate list, -1 past the number of candidates.
+__global__ __launch_bounds__(256) void k_mmr(const float* __restrict__ x, int dpad, int dim, int64_t n_rows,
+                                             const float* __restrict__ q, const int64_t* __restrict__ rows, int64_t nq,
+                                             int fetch_k, int k, double lambda, int* __restrict__ out_pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const int64_t row = lane < fetch_k ? rows[qi * fetch_k + lane] : -1;
+    const bool valid = row >= 0 && row < n_rows;
+    const float* xr = x + (valid ? row : 0) * (int64_t)dpad;
+    const float* qv = q + qi * dim;
+    double dq = 0.0, nx = 0.0, nqq = 0.0;
+    for (int c = 0; c < dim; ++c) {
+        const double a = (double)xr[c], b = (double)qv[c];
+        dq = fma(a, b, dq);
+        nx = fma(a, a, nx);
+        nqq = fma(b, b, nqq);
+    }
+    nx = sqrt(nx); nqq = sqrt(nqq);
+    double sim_q = dq / (nx * nqq);
+    if (!(sim_q == sim_q) || isinf(sim_q)) sim_q = 0.0;
+    const int n_valid = __builtin_popcountll(__ballot(valid));
+    const int want = k < n_valid ? k : n_valid;
+    // wave argmax with the lowest lane on ties
+    auto argmax = [&](double v, bool ok) -> int {
+        double m = ok ? v : -INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        const unsigned long long eq = __ballot(ok && v == m);
+        return eq ? __builtin_ctzll(eq) : -1;
+    };
+    bool picked = false;
+    double red = -INFINITY;          // max cosine to the picked set
+    int sel = argmax(sim_q, valid);
+    for (int t = 0; t < want && sel >= 0; ++t) {
+        if (lane == 0) out_pos[qi * k + t] = sel;
+        if (lane == sel) picked = true;
+        if (t + 1 == want) break;
+        // cosine of every candidate to the newly picked one
+        const int64_t srow = __shfl(row, sel);
+        const double ns = __shfl(nx, sel);
+        const float* xs = x + srow * (int64_t)dpad;
+        double d = 0.0;
+        for (int c = 0; c < dim; ++c) d = fma((double)xr[c], (double)xs[c], d);
+        double cs = d / (nx * ns);
+        if (!(cs == cs) || isinf(cs)) cs = 0.0;
+        red = fmax(red, cs);
+        sel = argmax(lambda * sim_q - (1.0 - lambda) * red, valid && !picked);
+    }
+    for (int t = want + lane; t < k; t += 64) out_pos[qi * k + t] = -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------------
@@ -400,6 +457,39 @@ extern "C" int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t
                        (const int64_t*)br.p, n, (float*)bo.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, bo.p, (size_t)n * idx->dim * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const int64_t* rows, int fetch_k, int k,
+                             double lambda_mult, unsigned flags, int32_t* out_pos) {
+    if (!idx || !q || !rows || !out_pos) return fail(RMU_E_INVALID, "rmu_index_mmr: null pointer");
+    if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1) return fail(RMU_E_INVALID, "rmu_index_mmr: nq >= 1, fetch_k in [1, 64], k >= 1");
+    Tls& t = g_tls;
+    int rc = t.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_mmr: stream");
+    hipStream_t s = t.stream;
+    const bool q_dev = flags & RMU_F_Q_DEVICE, io_dev = flags & RMU_F_OUT_DEVICE;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    const float* dq = q;
+    const int64_t* dr = rows;
+    int* dout = (int*)out_pos;
+    if (!q_dev) {
+        if (t.q.ensure((size_t)nq * idx->dim * sizeof(float))) return fail(RMU_E_OOM, "rmu_index_mmr: q workspace");
+        HIP_TRY(hipMemcpyAsync(t.q.p, q, (size_t)nq * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+        dq = (const float*)t.q.p;
+    }
+    if (!io_dev) {
+        if (t.in_r.ensure((size_t)nq * fetch_k * sizeof(int64_t)) || t.out_r.ensure((size_t)nq * k * sizeof(int)))
+            return fail(RMU_E_OOM, "rmu_index_mmr: workspace");
+        HIP_TRY(hipMemcpyAsync(t.in_r.p, rows, (size_t)nq * fetch_k * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        dr = (const int64_t*)t.in_r.p;
+        dout = (int*)t.out_r.p;
+    }
+    hipLaunchKernelGGL(k_mmr, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, idx->x, idx->dpad, idx->dim, idx->n, dq, dr, nq, fetch_k,
+                       k, lambda_mult, dout);
+    HIP_TRY(hipGetLastError());
+    if (!io_dev) HIP_TRY(hipMemcpyAsync(out_pos, dout, (size_t)nq * k * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RMU_OK;
 }

@@ -97,6 +97,22 @@ class FlatIndex:
         N.check(self._lib.rmu_index_get_rows(self._h, r.ctypes.data, r.shape[0], out.ctypes.data), "rmu_index_get_rows")
         return out
 
+    def mmr(self, q, rows, k: int, lambda_mult: float = 0.5) -> np.ndarray:
+        """Batched greedy MMR on the device: q [nq, dim] fp32, rows [nq, fetch_k] int64 candidate row ids (-1 = absent, as
+        `search` pads them; without a row_base) -> positions [nq, k] int32 into each candidate list (-1 = none)."""
+        qq = np.ascontiguousarray(q, dtype=np.float32)
+        if qq.ndim == 1:
+            qq = qq[None]
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        if r.ndim == 1:
+            r = r[None]
+        if r.shape[0] != qq.shape[0] or qq.shape[1] != self.dim:
+            raise ValueError("mmr: q must be [nq, dim] and rows [nq, fetch_k]")
+        out = np.empty((qq.shape[0], int(k)), dtype=np.int32)
+        N.check(self._lib.rmu_index_mmr(self._h, qq.ctypes.data, qq.shape[0], r.ctypes.data, r.shape[1], int(k),
+                                        float(lambda_mult), 0, out.ctypes.data), "rmu_index_mmr")
+        return out
+
     # -- search ------------------------------------------------------------------------------------
     def search(self, q, k: int, row_base: int = 0):
         """Exact top-k.  numpy in -> numpy out; torch CUDA in -> torch CUDA out (same device)."""

@@ -322,8 +322,15 @@ class MI355XVectorStore:
 
     def max_marginal_relevance_search_batch(self, queries: list[str], k: int = 4, fetch_k: int = 20,
                                             lambda_mult: float = 0.5, **kw) -> list[list[Document]]:
+        """One dense search + ONE device-side MMR selection for the whole batch (`rmu_index_mmr`: fp64, same greedy rule and
+        tie order as the single-query path; no per-query vector re-fetch).  fetch_k > 64 falls back to the host loop."""
         qv = self._embed_docs(list(queries))
         s, r = self._search_vecs(qv, fetch_k)
+        if r.shape[1] == 0:
+            return [[] for _ in range(qv.shape[0])]
+        if r.shape[1] <= 64 and hasattr(self._index, "mmr"):
+            pos = self._index.mmr(qv, r, k, lambda_mult)
+            return [[self._doc(int(r[qi, p])) for p in pos[qi] if p >= 0] for qi in range(qv.shape[0])]
         out = []
         for qi in range(qv.shape[0]):
             rows = [int(x) for x in r[qi] if x >= 0]

@@ -431,3 +431,65 @@ def test_save_load_roundtrip(rmu, tmp_path):
     idx2.close()
     with pytest.raises(Exception):
         rmu.FlatIndex.load(str(tmp_path / "missing.rmu"))
+
+
+# ---- batched device-side MMR (rmu_index_mmr) -------------------------------------------------------------------
+@pytest.mark.parametrize("lam", [0.5, 0.0, 1.0, 0.3])
+def test_device_mmr_matches_oracle(rmu, lam):
+    x = O.make_corpus(20_000, seed=31)
+    q, _ = O.make_queries(x, 96, seed=32, noise=0.4)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    s, r = idx.search(q, 20)
+    pos = idx.mmr(q, r, 10, lam)
+    assert pos.shape == (96, 10) and pos.dtype == np.int32
+    for i in range(96):
+        want = O.mmr(q[i], x[r[i]], k=10, lambda_mult=lam)
+        assert list(pos[i]) == want, (i, list(pos[i]), want)
+    idx.close()
+
+
+def test_device_mmr_edges(rmu):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((7, 384)).astype(np.float32)
+    x[5] = x[2]                                        # duplicate candidate: identical scores, lowest position wins
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    q = rng.standard_normal((3, 384)).astype(np.float32)
+    s, r = idx.search(q, 20)                           # only 7 live rows: padded with -1
+    assert (r[:, 7:] == -1).all()
+    pos = idx.mmr(q, r, 10)
+    for i in range(3):
+        want = O.mmr(q[i], x[r[i, :7]], k=10)
+        assert list(pos[i, :7]) == want and (pos[i, 7:] == -1).all()
+    # k = 1 is the nearest neighbour; a query equal to a stored row picks that row first
+    assert (idx.mmr(q, r, 1)[:, 0] == 0).all()
+    pos = idx.mmr(x[3:4], idx.search(x[3:4], 5)[1], 3)
+    assert pos[0, 0] == 0
+    from ragmeup_amd._native import RmuError
+    with pytest.raises(RmuError):
+        idx.mmr(q, np.zeros((3, 65), np.int64), 4)      # fetch_k > 64
+    idx.close()
+
+
+def test_vectorstore_batch_mmr_uses_device_and_matches_single(rmu):
+    from ragmeup_amd.vectorstore import MI355XVectorStore
+    from ragmeup_amd.documents import Document
+
+    class Emb:                                           # deterministic toy embedding: hash -> unit vector
+        def _v(self, t):
+            g = np.random.default_rng(abs(hash(t)) % (2 ** 32))
+            v = g.standard_normal(384).astype(np.float32)
+            return v / np.linalg.norm(v)
+        def embed_documents(self, texts):
+            return [self._v(t).tolist() for t in texts]
+        def embed_query(self, t):
+            return self._v(t).tolist()
+
+    docs = [Document(page_content=f"chunk {i}", metadata={"source": "s", "id": str(i)}) for i in range(500)]
+    st = MI355XVectorStore.from_documents(docs, Emb(), collection_name="mmr")
+    qs = [f"question {i}" for i in range(9)]
+    batch = st.max_marginal_relevance_search_batch(qs, k=5, fetch_k=20)
+    for qtext, got in zip(qs, batch):
+        single = st.max_marginal_relevance_search(qtext, k=5, fetch_k=20)    # host fp64 path of the drop-in
+        assert [d.page_content for d in got] == [d.page_content for d in single]
