@@ -86,7 +86,9 @@ int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const int64_t* r
 int rmu_index_save(rmu_index_t* idx, const char* path);
 int rmu_index_load(rmu_index_t** out, const char* path);
 
-/* Exact top-k of every query against all live rows.
+/* Exact top-k of every query against all live rows (dim 384, k <= 24: fp16 screening + exact fp32 re-score under a
+ * per-query sufficiency test; otherwise, and for every query that fails the test, the exact fp32 fused scan -- the
+ * returned ids and scores are those of the exact scan either way).
  *   q [nq, dim] fp32; out_scores [nq, k] fp32, out_rows [nq, k] int64, best first,
  *   order (score, then lower row id); slots beyond the live row count hold (-inf | +inf for L2SQ, -1).
  *   row_base is added to every returned row id (shard offset).
@@ -106,9 +108,9 @@ float rmu_last_scan_ms(void);
 /* Same for the whole search (scan + merge), and the launch geometry of the last scan. */
 float rmu_last_search_ms(void);
 int rmu_last_scan_geometry(int* grid, int* block, int* lds_bytes, int* passes);
-/* How the calling thread's last rmu_index_search was answered: >0 by the fp16 hi/lo screening pass + exact fp32
- * re-score (results identical to the exact scan), 0 by the exact fp32 scan, <0 = that many queries failed the
- * screening sufficiency test and the batch was re-run on the exact scan. */
+/* How the calling thread's last rmu_index_search was answered: >0 by the fp16 screening ladder + exact fp32 re-score;
+ * <0 the same, with that many queries failing the sufficiency test and re-run on the exact fp32 scan (patched in);
+ * 0 by the exact fp32 scan alone.  Results are identical in all three cases. */
 int rmu_last_screened(void);
 /* Enable (1) / disable (0) the event timing above for the calling thread (off by default). */
 int rmu_set_timing(int on);

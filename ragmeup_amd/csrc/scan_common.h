@@ -1,4 +1,4 @@
-// scan_common.h -- device helpers shared by the exact fp32 scan (scan_topk.hip) and the fp16 hi/lo screening
+// scan_common.h -- device helpers shared by the exact fp32 scan (scan_topk.hip) and the fp16 screening
 // scan (scan_screen.hip): LDS stores that do not drain the LDS-DMA ring, enumeration sort, slot compaction.
 #pragma once
 #include "rmu_common.h"

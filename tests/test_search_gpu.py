@@ -64,6 +64,24 @@ def test_tiny_and_ragged_corpora(rmu, n):
     idx.close()
 
 
+@pytest.mark.parametrize("n", [1, 7, 31, 33, 129, 4097])
+@pytest.mark.parametrize("nq", [130, 300])
+def test_tiny_corpora_on_the_screening_path(rmu, n, nq):
+    """Full query tiles over a handful of rows: one partial tile, fewer rows than K' = 32, padding beyond the live rows."""
+    x = O.make_corpus(n, seed=41)
+    q = O.make_corpus(nq, seed=42)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    for k in (1, 10, 24):
+        s, r = idx.search(q, k)
+        assert idx.last_screened() != 0
+        os_, or_ = O.flat_search(q, x, min(k + 4, max(n, 1)))
+        assert_topk_parity(s[:, :min(k, n)], r[:, :min(k, n)], os_, or_)
+        if n < k:
+            assert (r[:, n:] == -1).all() and np.isneginf(s[:, n:]).all()
+    idx.close()
+
+
 def test_empty_index(rmu):
     idx = rmu.FlatIndex(384)
     s, r = idx.search(np.ones((3, 384), np.float32), 10)

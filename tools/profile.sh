@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 keep() {  # keep only our kernels' rows of a CSV
   f=$(find $OUT/$1 -name "*$2" | head -1)
-  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|merge_keys|merge_lists|k_gemm|k_attention|k_layernorm|k_embed_ln|k_meanpool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
+  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|k_gemm|k_attention|k_layernorm|k_embed_ln|k_meanpool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
 }
 # 1) headline bench (10M x 384, B=1024) on the default path (fp16 hi/lo screening + exact re-score): stats + PMC passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan -o scan -- $B > $OUT/scan_bench.json 2> $OUT/scan.err
@@ -31,14 +31,20 @@ keep exact_pmc_a counter_collection.csv counters
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_b -o b -- $B > $OUT/exact_pmc_b_bench.json 2>> $OUT/scan.err
 keep exact_pmc_b counter_collection.csv counters
 unset RMU_SCREEN
-# 3) HBM-bound regime (B=1): kernel stats + FETCH_SIZE
+# 3) HBM-bound regime (B=1): default path (fp16 image, screening ladder) and the exact fp32 scan; kernel stats + FETCH_SIZE
 B1="python $R/bench.py --batch 1 --steps 10 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b1 -o scan -- $B1 > $OUT/scan_b1_bench.json 2>> $OUT/scan.err
 keep scan_b1 kernel_stats.csv stats
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b1 -o b -- $B1 > $OUT/pmc_b1_bench.json 2>> $OUT/scan.err
 keep pmc_b1 counter_collection.csv counters
+export RMU_SCREEN=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/exact_b1 -o scan -- $B1 > $OUT/exact_b1_bench.json 2>> $OUT/scan.err
+keep exact_b1 kernel_stats.csv stats
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_b1 -o b -- $B1 > $OUT/exact_pmc_b1_bench.json 2>> $OUT/scan.err
+keep exact_pmc_b1 counter_collection.csv counters
+unset RMU_SCREEN
 # 4) encoder (config 3) kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed -o e -- python $R/tools/bench_configs.py embed --chunks 32768 --batch 8192 > $OUT/embed_bench.json 2>> $OUT/scan.err
 keep embed kernel_stats.csv stats
-for d in scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 embed; do rm -rf $OUT/$d; done
+for d in scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 embed; do rm -rf $OUT/$d; done
 ls -la $OUT

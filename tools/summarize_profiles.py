@@ -42,7 +42,7 @@ with open('profiles/r01_pmc_means.csv', 'w') as o:
     o.write('pass,kernel,counter,dispatches,mean_per_dispatch,sum_per_bench_step,wg,lds_block,scratch,vgpr,agpr,sgpr\n')
     for r in rows:
         o.write(','.join(str(x) for x in r) + '\n')
-for t in ['scan', 'exact', 'scan_b1', 'embed']:
+for t in ['scan', 'exact', 'scan_b1', 'exact_b1', 'embed']:
     shutil.copy(f'{src}/{t}_stats.csv', f'profiles/r01_{t}_stats.csv')
     open(f'profiles/r01_{t}_bench.json', 'w').write(open(f'{src}/{t}_bench.json').read().strip().splitlines()[-1] + '\n')
 
@@ -95,10 +95,11 @@ txt = [
     "kernel once per row range of the threshold ladder (7 launches per 10M-row batch), so its counters are summed per bench step.\n",
     stats('scan', 'headline bench (10M x 384 fp32, batch 1024, top-10), default path = fp16 screening ladder + exact fp32 re-score'),
     stats('exact', 'same workload forced onto the exact fp32 scan (`RMU_SCREEN=0`)'),
-    stats('scan_b1', 'HBM-bound regime: batch 1 (exact fp32 scan, WQ=1 geometry)'),
+    stats('scan_b1', 'HBM-bound regime: batch 1, default path (fp16 image, 768 B per row, screening ladder with ratio 8)'),
+    stats('exact_b1', 'batch 1 forced onto the exact fp32 scan (`RMU_SCREEN=0`, WQ=1 geometry)'),
     stats('embed', 'encoder: 4 calls x 8192 chunks x ~128 tokens (BERT-6x384, bf16 MFMA)'),
     "## PMC passes (separate runs, `--kernel-trace --pmc ...` only)\n",
-    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', B1),
+    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK), line('exact_pmc_b1', B1),
     "\n## Derived (FETCH_SIZE is in KiB and under-reports by 2x on gfx950 per MI355X_MICROARCH.md -> bytes = FETCH_SIZE x 1024 x 2)\n",
     f"- screening launches, per batch: HBM fetch {scr_fetch/1e9:.2f} GB + write {scr_write/1e6:.1f} MB; the fp16 image is 7.68 GB and each of the 4 "
     f"query-tile workgroups of a row chunk streams it (L2 hit {hit:.3f}; ideal 0.75), i.e. x{scr_fetch/7.68e9:.2f} the image, x{scr_fetch/15.36e9:.2f} the "
@@ -107,7 +108,8 @@ txt = [
     f"{clk_s:.2f} GHz (GRBM_GUI_ACTIVE/8 / {k_ms} ms): the part down-clocks from 2.4 GHz under the combined MFMA + LDS + L2 load",
     f"- exact kernel: HBM fetch {f('exact_pmc_b',EK,'FETCH_SIZE')*2048/1e9:.2f} GB per launch vs 15.36 GB algorithmic (x{f('exact_pmc_b',EK,'FETCH_SIZE')*2048/15.36e9:.3f}); "
     f"MFMA busy {f('exact_pmc_a',EK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('exact_pmc_a',EK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles; mean clock {clk_e:.2f} GHz",
-    f"- batch 1: HBM fetch {f('pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
+    f"- batch 1, default path: HBM fetch {f('pmc_b1',SK,'FETCH_SIZE')*2048/1e9:.3f} GB per query over all launches vs the 7.680 GB image (x{f('pmc_b1',SK,'FETCH_SIZE')*2048/7.68e9:.4f})",
+    f"- batch 1, exact scan: HBM fetch {f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
 ]
 open('profiles/r01_summary.md', 'w').write("\n".join(txt) + "\n")
 print("\n".join(txt[-4:]))
