@@ -8,8 +8,9 @@
 //   greedy longest-match-first WordPiece ("##" continuations, > 100 chars -> [UNK]); [CLS] a [SEP] (b [SEP]),
 //   token types 0/1, single: keep the first max_len-2 tokens; pair: "longest_first" truncation as the `tokenizers`
 //   backend computes it.
-// Unicode coverage: ASCII exactly; Latin-1 / Latin Extended-A letters are lower-cased and de-accented through a small
-// table; general/CJK punctuation and CJK ideograph ranges as in the original.  Other scripts pass through un-folded.
+// Unicode: the per-codepoint behaviour of the normaliser and pre-tokeniser over the whole code space (deleted characters,
+// spaces, CJK padding, lower-case + NFD + mark removal, punctuation) comes from wordpiece_tables.h, which
+// tools/gen_wordpiece_tables.py records from the `tokenizers` library itself.  Not captured: the Greek final-sigma rule.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -20,6 +21,7 @@
 #include <vector>
 
 #include "../../include/rmu.h"
+#include "wordpiece_tables.h"
 
 extern "C" void rmu_set_error_(const char* msg);
 
@@ -59,54 +61,42 @@ void append_utf8(std::string& s, cp_t c) {
     else if (c < 0x10000) { s += (char)(0xE0 | (c >> 12)); s += (char)(0x80 | ((c >> 6) & 63)); s += (char)(0x80 | (c & 63)); }
     else { s += (char)(0xF0 | (c >> 18)); s += (char)(0x80 | ((c >> 12) & 63)); s += (char)(0x80 | ((c >> 6) & 63)); s += (char)(0x80 | (c & 63)); }
 }
-bool is_ws(cp_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000; }
-bool is_control(cp_t c) {
-    if (c == '\t' || c == '\n' || c == '\r') return false;
-    return c < 0x20 || (c >= 0x7F && c < 0xA0) || c == 0xAD || (c >= 0x200B && c <= 0x200F) || (c >= 0x202A && c <= 0x202E) ||
-           (c >= 0x2060 && c <= 0x2064) || c == 0xFEFF;
-}
-bool is_punct(cp_t c) {
-    if ((c >= 33 && c <= 47) || (c >= 58 && c <= 64) || (c >= 91 && c <= 96) || (c >= 123 && c <= 126)) return true;
-    if (c == 0xA1 || c == 0xA7 || c == 0xAB || c == 0xB6 || c == 0xB7 || c == 0xBB || c == 0xBF) return true;   // Latin-1 P*
-    return (c >= 0x2010 && c <= 0x2027) || (c >= 0x2030 && c <= 0x205E) || (c >= 0x3001 && c <= 0x3003) ||
-           (c >= 0x3008 && c <= 0x3011) || (c >= 0x3014 && c <= 0x301F) || (c >= 0xFF01 && c <= 0xFF0F) ||
-           (c >= 0xFF1A && c <= 0xFF20) || (c >= 0xFF3B && c <= 0xFF40) || (c >= 0xFF5B && c <= 0xFF65);
-}
-bool is_cjk(cp_t c) {
-    return (c >= 0x4E00 && c <= 0x9FFF) || (c >= 0x3400 && c <= 0x4DBF) || (c >= 0x20000 && c <= 0x2A6DF) ||
-           (c >= 0x2A700 && c <= 0x2B73F) || (c >= 0x2B740 && c <= 0x2B81F) || (c >= 0x2B820 && c <= 0x2CEAF) ||
-           (c >= 0xF900 && c <= 0xFAFF) || (c >= 0x2F800 && c <= 0x2FA1F);
-}
-// lower-case + strip accents (NFD, drop Mn) for ASCII, Latin-1 Supplement and Latin Extended-A
-cp_t fold(cp_t c) {
-    if (c < 0x80) return (c >= 'A' && c <= 'Z') ? c + 32 : c;
-    static const char* l1 = "aaaaaa\0ceeeeiiii\0nooooo\0ouuuuy\0\0aaaaaa\0ceeeeiiii\0nooooo\0ouuuuy\0y";   // U+00C0..U+00FF
-    if (c >= 0xC0 && c <= 0xFF) {
-        const char b = l1[c - 0xC0];
-        if (b) return (cp_t)b;
-        if (c == 0xC6) return 0xE6;   // AE -> ae (no decomposition)
-        if (c == 0xD0) return 0xF0;   // ETH
-        if (c == 0xD8) return 0xF8;   // O-stroke
-        if (c == 0xDE) return 0xFE;   // THORN
-        return c;                      // x, /, ss, ae, eth, o-stroke, thorn stay
+bool in_ranges(const uint32_t (*r)[2], int n, cp_t c) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c < r[mid][0]) hi = mid - 1;
+        else if (c > r[mid][1]) lo = mid + 1;
+        else return true;
     }
-    if (c >= 0x100 && c <= 0x17F) {
-        static const char* la =
-            "aaaaaaccccccccddddeeeeeeeeeegggggggghhhhiiiiiiiiii\0\0jjkk\0lllllllllnnnnnn\0\0\0oooooo\0\0rrrrrrssssssssttttttuuuuuuuuuuuuwwyyyzzzzzz\0";
-        const char b = la[c - 0x100];
-        if (b) return (cp_t)b;
-        if (c == 0x132) return 0x133;
-        if (c == 0x141) return 0x142;
-        if (c == 0x14A) return 0x14B;
-        if (c == 0x152) return 0x153;
-        if (c == 0x110 || c == 0x126 || c == 0x166) return c + 1;   // stroked letters: lower-case only
-        return c;
+    return false;
+}
+// lower-case + NFD + mark removal of one codepoint (tables recorded from the `tokenizers` library): appends 0..n codepoints
+void fold_into(cp_t c, std::vector<cp_t>& out) {
+    if (c < 0x80) { out.push_back((c >= 'A' && c <= 'Z') ? c + 32 : c); return; }
+    if (c >= 0xAC00 && c <= 0xD7A3) {                   // Hangul syllable: algorithmic canonical decomposition
+        const cp_t s = c - 0xAC00;
+        out.push_back(0x1100 + s / 588);
+        out.push_back(0x1161 + (s % 588) / 28);
+        if (s % 28) out.push_back(0x11A7 + s % 28);
+        return;
     }
-    return c;
+    int lo = 0, hi = kWpMap_n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c < kWpMap[mid].cp) hi = mid - 1;
+        else if (c > kWpMap[mid].cp) lo = mid + 1;
+        else {
+            for (uint32_t i = 0; i < kWpMap[mid].len; ++i) out.push_back(kWpMapVals[kWpMap[mid].off + i]);
+            return;
+        }
+    }
+    out.push_back(c);
 }
 
+// BertNormalizer (clean text, pad CJK, strip accents, lower-case) + BertPreTokenizer (split on whitespace, isolate punctuation)
 void basic_tokenize(const rmu_tok* tk, const char* text, std::vector<std::string>& out) {
-    std::vector<cp_t> cps;
+    std::vector<cp_t> cps, folded;
     decode_utf8(text, cps);
     std::vector<cp_t> cur;
     auto flush = [&]() {
@@ -117,15 +107,19 @@ void basic_tokenize(const rmu_tok* tk, const char* text, std::vector<std::string
         cur.clear();
     };
     for (cp_t c : cps) {
-        if (c == 0 || c == 0xFFFD || is_control(c)) continue;
-        if (is_ws(c)) { flush(); continue; }
-        if (is_cjk(c)) { flush(); cur.push_back(c); flush(); continue; }
-        if (tk->lower) {
-            if (c >= 0x300 && c <= 0x36F) continue;      // combining marks (Mn) are dropped by strip_accents
-            c = fold(c);
+        if (c == ' ' || in_ranges(kWpSpace, kWpSpace_n, c)) { flush(); continue; }
+        if (tk->lower ? in_ranges(kWpRemoved, kWpRemoved_n, c) : in_ranges(kWpRemovedCased, kWpRemovedCased_n, c)) continue;
+        const bool cjk = in_ranges(kWpCjk, kWpCjk_n, c);   // padded with spaces: a token of its own
+        if (cjk) flush();
+        folded.clear();
+        if (tk->lower) fold_into(c, folded);
+        else folded.push_back(c);
+        for (cp_t f : folded) {
+            if (f == ' ') { flush(); continue; }        // compatibility ideographs decompose to a padded ideograph
+            if (in_ranges(kWpPunct, kWpPunct_n, f)) { flush(); cur.push_back(f); flush(); continue; }
+            cur.push_back(f);
         }
-        if (is_punct(c)) { flush(); cur.push_back(c); flush(); continue; }
-        cur.push_back(c);
+        if (cjk) flush();
     }
     flush();
 }

@@ -88,3 +88,52 @@ def test_hf_style_call_and_errors(pair, vocab, tmp_path):
     bad = tmp_path / "bad.txt"; bad.write_text("only\nwords\n")
     with pytest.raises(RmuError):
         WordPieceTokenizer(str(bad))
+
+
+def test_unicode_normalisation_matches_the_tokenizers_library(tmp_path, librmu):
+    """Whole-code-space behaviour (tables generated from `tokenizers`): every character of every normalised word is in the
+    vocabulary (as 'c' and '##c'), so the id sequences expose the exact normalised text -- nothing hides behind [UNK]."""
+    from tokenizers.normalizers import BertNormalizer
+    from tokenizers.pre_tokenizers import BertPreTokenizer
+    from transformers import BertTokenizer
+    rng = random.Random(7)
+    blocks = [(0x20, 0x7E), (0xA0, 0x17F), (0x180, 0x24F), (0x300, 0x36F), (0x370, 0x3FF), (0x400, 0x4FF), (0x590, 0x5FF),
+              (0x600, 0x6FF), (0x900, 0x97F), (0xE00, 0xE7F), (0x1100, 0x11FF), (0x1E00, 0x1EFF), (0x2000, 0x206F),
+              (0x2070, 0x20CF), (0x2100, 0x214F), (0x3000, 0x303F), (0x3040, 0x30FF), (0x4E00, 0x4E80), (0xAC00, 0xAD00),
+              (0xF900, 0xF960), (0xFB00, 0xFB06), (0xFE50, 0xFE6F), (0xFF00, 0xFF5E), (0x1F600, 0x1F640), (0x1D400, 0x1D430),
+              (0xE000, 0xE010), (0x200B, 0x200F), (0x80, 0x9F)]
+    texts = []
+    for _ in range(600):
+        parts = []
+        for _ in range(rng.randint(1, 12)):
+            lo, hi = rng.choice(blocks)
+            parts.append("".join(chr(rng.randint(lo, hi)) for _ in range(rng.randint(1, 6))))
+        texts.append(rng.choice([" ", "", "  ", "\t"]).join(parts))
+    texts += ["İstanbul ÇAĞRI", "ΑΒΓ δοκιμή Ωμέγα", "ПРИВЕТ мир Ёж", "한국어 테스트", "école Ångström", "ﬁnal ﬂow",
+              "१२३ हिन्दी", "日本語のテキスト", "a­b soft­hyphen", "x﻿y⁠z", "Ǆ ǅ ǆ ß ẞ", "①②③ ½ ™"]
+    nl = BertNormalizer(clean_text=True, handle_chinese_chars=True, strip_accents=True, lowercase=True)
+    pt = BertPreTokenizer()
+    alphabet = set()
+    for t in texts:
+        for w, _ in pt.pre_tokenize_str(nl.normalize_str(t)):
+            alphabet.update(w)
+    toks = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + sorted(alphabet) + ["##" + c for c in sorted(alphabet)]
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(toks) + "\n", encoding="utf-8")
+    mine = WordPieceTokenizer(str(vp))
+    hf = BertTokenizer(vocab={t: i for i, t in enumerate(toks)}, do_lower_case=True)
+    ids, _, lens = mine.encode(texts, max_len=128)
+    bad = 0
+    for i, t in enumerate(texts):
+        want = hf(t, truncation=True, max_length=128, padding=False)["input_ids"]
+        if ids[i, :lens[i]].tolist() != want:
+            bad += 1
+            assert "Σ" in t or "σ" in t or "ς" in t, (t, ids[i, :lens[i]].tolist(), want)    # only the final-sigma rule may differ
+    assert bad <= 3
+    # cased checkpoints: no lower-casing, no accent stripping
+    hfc = BertTokenizer(vocab={t: i for i, t in enumerate(toks)}, do_lower_case=False)
+    minec = WordPieceTokenizer(str(vp), do_lower_case=False)
+    sample = [t for t in texts if t.isascii() is False][:200]
+    ids, _, lens = minec.encode(sample, max_len=128)
+    for i, t in enumerate(sample):
+        assert ids[i, :lens[i]].tolist() == hfc(t, truncation=True, max_length=128, padding=False)["input_ids"], t
