@@ -719,8 +719,8 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                     cursor += S.parts;
                     if (g_dbg) { u64 h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg range %d: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu\n", l, (long long)S.n_rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); (void)hipMemset(g_dbg, 0, 128); }
                     u64* merged = l + 1 < nl ? base + (size_t)cursor * part_keys : (u64*)t.ckeys.p;
-                    rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, kp, merged, s);
-                    if (!rc && l + 1 < nl) rc = rmu_seed_thr_launch(merged, kp, nb, (u32*)t.gthr.p, s);
+                    rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, kp, merged,
+                                                  l + 1 < nl ? (u32*)t.gthr.p : nullptr, s);   // merge + seed in one launch
                     if (rc) return fail(rc, "rmu_index_search: screening merge / threshold seeding");
                 }
                 // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip)

@@ -117,11 +117,11 @@ int rmu_merge_keys_launch(const u64* partial, int parts, int64_t nq, int k, int6
 int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out,
                            const float* qnorm2, float* out_scores, int64_t* out_rows, u64* scratch, int64_t scratch_keys,
                            hipStream_t s);
-int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, hipStream_t s);
+int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr /* or null */,
+                             hipStream_t s);
 // fp16 screening path (scan_screen.hip)
 #define RMU_IMG_ROW_BYTES 768                          /* fp16(64 x) image of a 384-d row */
 int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> fp16 image
-int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStream_t s); // K'-th best of a pre-pass -> gthr
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s);                             // x/q = split images, k = K'
 int rmu_screen_lds_bytes(int qg);
 int rmu_screen_plan(ScanLaunch* p);                      // geometry of one screening launch (k = K' <= 32)

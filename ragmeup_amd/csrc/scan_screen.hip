@@ -77,14 +77,6 @@ __global__ void k_split_rows(const float* __restrict__ src, char* __restrict__ d
     *(f16x8*)(dst + gidx * 16) = hi;
 }
 
-// gthr[q] <- the K'-th best approximate score of a finished pre-pass (a lower bound of the final K'-th best)
-__global__ void k_seed_thr(const u64* __restrict__ keys, int kp, int64_t nq, u32* __restrict__ gthr) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const u64 kk = keys[q * kp + kp - 1];
-    if (kk) atomicMax(gthr + q, (u32)(kk >> 32));
-}
-
 // err2[r] = |x_r - h_r / 64|^2: the measured rounding error of the screening image, one wave per row
 __global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, int64_t n, float* __restrict__ err2) {
     const int lane = threadIdx.x & 63;
@@ -505,11 +497,6 @@ int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s)
     const int64_t groups = n_rows * (SD / 8);
     if (groups <= 0) return RMU_OK;
     hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, (char*)dst, groups);
-    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
-}
-
-int rmu_seed_thr_launch(const u64* keys, int kp, int64_t nq, u32* gthr, hipStream_t s) {
-    hipLaunchKernelGGL(k_seed_thr, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, keys, kp, nq, gthr);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 

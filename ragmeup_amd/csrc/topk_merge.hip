@@ -58,7 +58,8 @@ __device__ __forceinline__ void merge_stream_slabs(u64 (&top)[NPL], int np, int 
 // level-1 of the two-level merge: wave (q, g) folds parts [g*ppg, (g+1)*ppg) into k keys -> scratch[g][q][k]
 template <int NPL>
 __global__ __launch_bounds__(256) void merge_keys_partial_kernel(const u64* __restrict__ partial, int parts, int64_t nq,
-                                                                 int k, int groups, int ppg, u64* __restrict__ scratch) {
+                                                                 int k, int groups, int ppg, u64* __restrict__ scratch,
+                                                                 u32* __restrict__ seed_thr /* optional: [nq] <- max(k-th best) */) {
     const int lane = threadIdx.x & 63;
     const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= nq * groups) return;
@@ -74,6 +75,8 @@ __global__ __launch_bounds__(256) void merge_keys_partial_kernel(const u64* __re
     for (int p = 0; p < NPL; ++p) {
         const int e = lane + 64 * p;
         if (e < k) scratch[((int64_t)g * nq + q) * k + e] = top[p];
+        // screening ladder: the merged K'-th best is a lower bound of the final K'-th best -> next launch's shared threshold
+        if (seed_thr && e == k - 1 && top[p]) atomicMax(seed_thr + q, (u32)(top[p] >> 32));
     }
 }
 
@@ -174,8 +177,8 @@ int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int
         groups = (parts + ppg - 1) / ppg;
         if (groups > 1 && (int64_t)groups * nq * k <= scratch_keys) {
             const dim3 g1((unsigned)((nq * groups + 3) / 4));
-            if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch);
-            else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch);
+            if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
+            else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
             src = scratch;
             src_parts = groups;
         }
@@ -190,11 +193,11 @@ int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, hipStream_t s) {
+int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr, hipStream_t s) {
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
     const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
-    if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys);
-    else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys);
+    if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys, seed_thr);
+    else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys, seed_thr);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 

@@ -102,3 +102,33 @@ def test_embeddings_object_and_reranker_pipeline(bi, cross):
     sc = [d.metadata["relevance_score"] for d in out]
     assert sc == sorted(sc, reverse=True)
     idx.close()
+
+
+def test_text_pipeline_with_the_native_tokenizer(bi, cross, tmp_path):
+    """Text in, vectors / logits out, every stage behind the C-ABI: rmu_tok_encode -> rmu_bert_encode (modes 0 and 1).  The
+    native tokenizer must feed the encoder exactly what transformers' BertTokenizer would (same ids -> bit-equal outputs)."""
+    import random
+    from transformers import BertTokenizer
+    from ragmeup_amd.embeddings import MI355XCrossEncoder, MI355XEmbeddings
+    from ragmeup_amd.tokenizer import WordPieceTokenizer
+    words = ["retrieval", "augment", "##ed", "##ation", "gener", "vector", "store", "query", "docu", "##ment", "rank", "re", "##rank",
+             "chunk", "##s", "the", "a", "of", "and", "cafe", "naive", ",", ".", "?", "(", ")", "mi", "##35", "##5", "##x", "gpu", "中", "文"]
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(toks) + "\n", encoding="utf-8")
+    native = WordPieceTokenizer(str(vp))
+    hf = BertTokenizer(vocab={t: i for i, t in enumerate(toks)}, do_lower_case=True)
+    rng = random.Random(3)
+    surface = ["Retrieval", "augmented", "augmentation", "generation", "vector", "stores", "query", "documents", "rerank", "chunks",
+               "the", "a", "of", "and", "café", "naïve", "MI355X", "GPU", "(rank)", "re-rank?", "中文", "unknownword", "store,", "query."]
+    texts = [" ".join(rng.choice(surface) for _ in range(rng.randint(3, 60))) for _ in range(64)]
+    emb_n = MI355XEmbeddings(encoder=bi[0], tokenizer=native, max_seq_length=48)
+    emb_h = MI355XEmbeddings(encoder=bi[0], tokenizer=hf, max_seq_length=48)
+    a, b = emb_n.embed_documents_array(texts), emb_h.embed_documents_array(texts)
+    assert a.shape == (64, 384) and np.array_equal(a, b)
+    assert np.allclose(np.linalg.norm(a, axis=1), 1.0, atol=1e-3)
+    assert emb_n.embed_query(texts[0]) == emb_h.embed_query(texts[0])
+    pairs = [(texts[i][:40], texts[(i * 7 + 1) % 64]) for i in range(32)]
+    ce_n = MI355XCrossEncoder(encoder=cross[0], tokenizer=native, max_seq_length=64)
+    ce_h = MI355XCrossEncoder(encoder=cross[0], tokenizer=hf, max_seq_length=64)
+    assert ce_n.score(pairs) == ce_h.score(pairs)
