@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-SCREEN_TRAFFIC = 1.3675e10   # HBM bytes per 10M x 1024 batch over all screening launches: rocprofv3 PMC, profiles/r01_summary.md
+SCREEN_TRAFFIC = {1024: 1.3632e10, 1: 7.683e9}   # HBM bytes per 10M-row batch over all screening launches: rocprofv3 PMC, profiles/r01_summary.md
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (the 5 PF figure is 2:1 sparse)
 
 
@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-identity-check", action="store_true",
+                    help="skip the post-run comparison with the exact fp32 scan (keeps rocprofv3 per-kernel statistics to the timed launches)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="diagnostic: no hipEvents around the scan launches (roofline fields become meaningless)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,7 +119,7 @@ def main():
     torch.cuda.empty_cache()
 
     searcher = ShardedSearcher(index, row_base=lo)
-    index.set_timing(True)
+    index.set_timing(not args.no_kernel_timing)
 
     def step():
         return searcher.search(q, K)
@@ -151,12 +155,14 @@ def main():
     # + fp32 re-score) must return the exact fp32 scan's ids AND scores bit for bit.  k = 25 > 24 always takes the exact scan.
     nchk = min(B, 256)
     index.set_timing(False)
-    s_def, r_def = index.search(q[:nchk], K)
-    path_chk = index.last_screened()
-    s_ex, r_ex = index.search(q[:nchk], max(K, 25))
-    identical = bool(torch.equal(torch.as_tensor(r_def), torch.as_tensor(r_ex)[:, :K]) and
-                     torch.equal(torch.as_tensor(s_def), torch.as_tensor(s_ex)[:, :K]))
-    if world > 1:
+    identical, path_chk = None, 0
+    if not args.no_identity_check:
+        s_def, r_def = index.search(q[:nchk], K)
+        path_chk = index.last_screened()
+        s_ex, r_ex = index.search(q[:nchk], max(K, 25))
+        identical = bool(torch.equal(torch.as_tensor(r_def), torch.as_tensor(r_ex)[:, :K]) and
+                         torch.equal(torch.as_tensor(s_def), torch.as_tensor(s_ex)[:, :K]))
+    if world > 1 and identical is not None:
         t = torch.tensor([1.0 if identical else 0.0], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         identical = bool(t.item() > 0.5)
@@ -184,7 +190,7 @@ def main():
     # exact configuration and committed under profiles/; null for any other configuration.
     traffic = None
     if world == 1 and N == 10_000_000 and D == 384 and K == 10 and B in (1024, 1):
-        traffic = {1024: 2 * 8.027e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
+        traffic = {1024: 2 * 7.876e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
     path = "exact-f32"
     rerun = 0
     if all(v != 0 for v in screened):
@@ -196,7 +202,7 @@ def main():
         kname = (f"scan_screen_kernel<G={2 if B > 128 else 1}> (D=384, {256 if B > 128 else 128} queries/WG, 32-row tiles as two 12-KiB half-k chunks, "
                  f"{6 if B > 128 else 8}-slot LDS-DMA ring), one launch per row range of the threshold ladder")
         f_mfma = ach_tf / PEAK_F16_MFMA_TFLOPS
-        traffic = SCREEN_TRAFFIC if (world == 1 and N == 10_000_000 and B == 1024) else None
+        traffic = SCREEN_TRAFFIC.get(B) if (world == 1 and N == 10_000_000 and K == 10) else None
         # the screen streams the fp16 image (768 B per row), not the fp32 rows: its HBM roof is priced on those bytes
         img_gbs = n_local * 768 / (scan_avg_ms * 1e-3) / 1e9
         if f_mfma >= img_gbs / PEAK_HBM_GBS:

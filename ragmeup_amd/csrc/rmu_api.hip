@@ -704,6 +704,9 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                 HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
                 rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
                 if (rc) return fail(rc, "rmu_index_search: query conversion");
+                // small batches: two-level merges (17 groups of 16 parts per query) need [groups, nb, K'] keys of scratch
+                const int64_t mscratch_keys = nb <= 256 ? (int64_t)20 * nb * kp : 0;
+                if (mscratch_keys && t.mscratch.ensure((size_t)mscratch_keys * sizeof(u64))) return fail(RMU_E_OOM, "rmu_index_search: merge scratch");
                 u64* base = (u64*)t.partial.p;
                 int cursor = 0;     // slot index: [merged keys of the ranges so far][this range's parts] ...
                 for (int l = 0; l < nl; ++l) {
@@ -720,7 +723,8 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                     if (g_dbg) { u64 h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg range %d: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu\n", l, (long long)S.n_rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); (void)hipMemset(g_dbg, 0, 128); }
                     u64* merged = l + 1 < nl ? base + (size_t)cursor * part_keys : (u64*)t.ckeys.p;
                     rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, kp, merged,
-                                                  l + 1 < nl ? (u32*)t.gthr.p : nullptr, s);   // merge + seed in one launch
+                                                  l + 1 < nl ? (u32*)t.gthr.p : nullptr,          // merge + seed in one launch
+                                                  (u64*)t.mscratch.p, mscratch_keys, s);
                     if (rc) return fail(rc, "rmu_index_search: screening merge / threshold seeding");
                 }
                 // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip)

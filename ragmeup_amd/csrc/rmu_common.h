@@ -118,7 +118,7 @@ int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int
                            const float* qnorm2, float* out_scores, int64_t* out_rows, u64* scratch, int64_t scratch_keys,
                            hipStream_t s);
 int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr /* or null */,
-                             hipStream_t s);
+                             u64* scratch /* or null */, int64_t scratch_keys, hipStream_t s);
 // fp16 screening path (scan_screen.hip)
 #define RMU_IMG_ROW_BYTES 768                          /* fp16(64 x) image of a 384-d row */
 int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> fp16 image

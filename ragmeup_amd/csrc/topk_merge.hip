@@ -193,11 +193,27 @@ int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr, hipStream_t s) {
+int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr, u64* scratch,
+                             int64_t scratch_keys, hipStream_t s) {
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
-    const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
-    if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys, seed_thr);
-    else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, grid, block, 0, s, partial, parts, nq, k, 1, parts, out_keys, seed_thr);
+    const dim3 block(256);
+    const u64* src = partial;
+    int src_parts = parts;
+    // few queries x many parts (one query tile scans 256 row chunks): one wave per query would fold thousands of keys
+    // serially (58 us per merge at nq = 1); fold groups of 16 parts in parallel first
+    if (scratch && nq <= 256 && parts >= 32) {
+        const int ppg = 16, groups = (parts + ppg - 1) / ppg;
+        if ((int64_t)groups * nq * k <= scratch_keys) {
+            const dim3 g1((unsigned)((nq * groups + 3) / 4));
+            if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
+            else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
+            src = scratch;
+            src_parts = groups;
+        }
+    }
+    const dim3 grid((unsigned)((nq + 3) / 4));
+    if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, grid, block, 0, s, src, src_parts, nq, k, 1, src_parts, out_keys, seed_thr);
+    else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, grid, block, 0, s, src, src_parts, nq, k, 1, src_parts, out_keys, seed_thr);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-identity-check"
 keep() {  # keep only our kernels' rows of a CSV
   f=$(find $OUT/$1 -name "*$2" | head -1)
   if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|k_gemm|k_attention|k_layernorm|k_embed_ln|k_meanpool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
@@ -32,7 +32,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_
 keep exact_pmc_b counter_collection.csv counters
 unset RMU_SCREEN
 # 3) HBM-bound regime (B=1): default path (fp16 image, screening ladder) and the exact fp32 scan; kernel stats + FETCH_SIZE
-B1="python $R/bench.py --batch 1 --steps 10 --warmup 2 --no-cpu-baseline"
+B1="python $R/bench.py --batch 1 --steps 10 --warmup 2 --no-cpu-baseline --no-identity-check"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b1 -o scan -- $B1 > $OUT/scan_b1_bench.json 2>> $OUT/scan.err
 keep scan_b1 kernel_stats.csv stats
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b1 -o b -- $B1 > $OUT/pmc_b1_bench.json 2>> $OUT/scan.err
