@@ -165,6 +165,22 @@ def test_cosine_metric_on_unnormalised_rows(rmu):
     idx.close()
 
 
+def test_cosine_metric_on_the_screening_path(rmu):
+    """COSINE index (what the vector store creates): rows stored normalised, queries normalised per call, full query tiles."""
+    from ragmeup_amd import _native as N
+    rng = np.random.default_rng(19)
+    x = (rng.standard_normal((40_000, 384)) * rng.uniform(0.2, 5.0, (40_000, 1))).astype(np.float32)
+    q = (x[rng.permutation(40_000)[:300]] + 0.3 * rng.standard_normal((300, 384))).astype(np.float32) * 2.5
+    idx = rmu.FlatIndex(384, metric=N.METRIC_COSINE)
+    idx.add(x)
+    s, r = idx.search(q, 10)
+    assert idx.last_screened() != 0
+    assert_topk_parity(s, r, *O.flat_search(q, x, 14, O.METRIC_COSINE))
+    s2, r2 = idx.search(q, 25)
+    assert idx.last_screened() == 0 and np.array_equal(r2[:, :10], r) and np.array_equal(s2[:, :10], s)
+    idx.close()
+
+
 def test_device_pointers_and_row_base(rmu, corpus50k):
     import torch
     x, q, _ = corpus50k
