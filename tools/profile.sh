@@ -2,6 +2,9 @@
 # Round profiles: run ON THE GPU BOX through gpurun:  gpurun -- 'bash tools/profile.sh r01'
 # Produces gpurun_out/<tag>/*.csv|json; copy the summaries into profiles/ (tracked).
 # PMC passes are separate runs with --kernel-trace only (gpurun refuses --pmc together with other trace domains).
+# Every rocprofv3 call runs under `timeout`: a PMC pass over the ENCODER benchmark (tools/bench_configs.py embed) aborted inside
+# rocprofv3 (signal 6) and then hung in its finalisation until the box's limit -- 15 GPU-minutes lost.  The encoder is profiled
+# with --kernel-trace --stats only.
 set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -14,37 +17,37 @@ keep() {  # keep only our kernels' rows of a CSV
   if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|k_gemm|k_attention|k_layernorm|k_embed_ln|k_meanpool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
 }
 # 1) headline bench (10M x 384, B=1024) on the default path (fp16 hi/lo screening + exact re-score): stats + PMC passes
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan -o scan -- $B > $OUT/scan_bench.json 2> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan -o scan -- $B > $OUT/scan_bench.json 2> $OUT/scan.err
 keep scan kernel_stats.csv stats
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/pmc_a -o a -- $B > $OUT/pmc_a_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/pmc_a -o a -- $B > $OUT/pmc_a_bench.json 2>> $OUT/scan.err
 keep pmc_a counter_collection.csv counters
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b -o b -- $B > $OUT/pmc_b_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b -o b -- $B > $OUT/pmc_b_bench.json 2>> $OUT/scan.err
 keep pmc_b counter_collection.csv counters
-rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_c -o c -- $B > $OUT/pmc_c_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_c -o c -- $B > $OUT/pmc_c_bench.json 2>> $OUT/scan.err
 keep pmc_c counter_collection.csv counters
 # 2) the same workload forced onto the exact fp32 scan (RMU_SCREEN=0): stats + MFMA-busy + FETCH_SIZE
 export RMU_SCREEN=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/exact -o scan -- $B > $OUT/exact_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/exact -o scan -- $B > $OUT/exact_bench.json 2>> $OUT/scan.err
 keep exact kernel_stats.csv stats
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/exact_pmc_a -o a -- $B > $OUT/exact_pmc_a_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/exact_pmc_a -o a -- $B > $OUT/exact_pmc_a_bench.json 2>> $OUT/scan.err
 keep exact_pmc_a counter_collection.csv counters
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_b -o b -- $B > $OUT/exact_pmc_b_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_b -o b -- $B > $OUT/exact_pmc_b_bench.json 2>> $OUT/scan.err
 keep exact_pmc_b counter_collection.csv counters
 unset RMU_SCREEN
 # 3) HBM-bound regime (B=1): default path (fp16 image, screening ladder) and the exact fp32 scan; kernel stats + FETCH_SIZE
 B1="python $R/bench.py --batch 1 --steps 10 --warmup 2 --no-cpu-baseline --no-identity-check"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b1 -o scan -- $B1 > $OUT/scan_b1_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b1 -o scan -- $B1 > $OUT/scan_b1_bench.json 2>> $OUT/scan.err
 keep scan_b1 kernel_stats.csv stats
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b1 -o b -- $B1 > $OUT/pmc_b1_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b1 -o b -- $B1 > $OUT/pmc_b1_bench.json 2>> $OUT/scan.err
 keep pmc_b1 counter_collection.csv counters
 export RMU_SCREEN=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/exact_b1 -o scan -- $B1 > $OUT/exact_b1_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/exact_b1 -o scan -- $B1 > $OUT/exact_b1_bench.json 2>> $OUT/scan.err
 keep exact_b1 kernel_stats.csv stats
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_b1 -o b -- $B1 > $OUT/exact_pmc_b1_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_b1 -o b -- $B1 > $OUT/exact_pmc_b1_bench.json 2>> $OUT/scan.err
 keep exact_pmc_b1 counter_collection.csv counters
 unset RMU_SCREEN
 # 4) encoder (config 3) kernel stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed -o e -- python $R/tools/bench_configs.py embed --chunks 32768 --batch 8192 > $OUT/embed_bench.json 2>> $OUT/scan.err
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed -o e -- python $R/tools/bench_configs.py embed --chunks 32768 --batch 8192 > $OUT/embed_bench.json 2>> $OUT/scan.err
 keep embed kernel_stats.csv stats
 for d in scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 embed; do rm -rf $OUT/$d; done
 ls -la $OUT
