@@ -664,11 +664,11 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && screen_pays && k <= 24 && idx->n > 0 &&
             idx->xnorm_max > 0.f && idx->xnorm_max < 500.f) {   // fp16(64*x) must not overflow
             const int kp = 32;
-            // Threshold ladder: the corpus is scanned in row ranges of geometrically growing size (ratio 3, first >= 2k
-            // rows); after each range its candidates are merged with the running top-K' and the K'-th best seeds the
+            // Threshold ladder: the corpus is scanned in row ranges of geometrically growing size (256 rows, x8 up to 64k,
+            // then x3); after each range its candidates are merged with the running top-K' and the K'-th best seeds the
             // shared per-query thresholds of the next launch.  A cold launch appends K' ln(rows/K') candidates per query
             // and CHUNK, a seeded one only K' (ratio - 1) per query in total, and every append stalls a whole workgroup
-            // for ~3k cycles: this cut the filter overhead of the 10M x 1024 scan from 5.2 to ~2 ms.
+            // for ~1-3k cycles: this cut the filter overhead of the 10M x 1024 scan from 5.2 to ~1.5 ms.
             // ratio 3 for full batches; small batches (one query tile, HBM-bound: 7.68 GB image per batch) have few appends to
             // save and pay for every launch gap and merge, so they climb faster
             const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
