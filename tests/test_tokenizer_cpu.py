@@ -137,3 +137,15 @@ def test_unicode_normalisation_matches_the_tokenizers_library(tmp_path, librmu):
     ids, _, lens = minec.encode(sample, max_len=128)
     for i, t in enumerate(sample):
         assert ids[i, :lens[i]].tolist() == hfc(t, truncation=True, max_length=128, padding=False)["input_ids"], t
+
+
+def test_committed_unicode_tables_are_what_the_generator_produces(tmp_path):
+    """csrc/wordpiece_tables.h is generated from the `tokenizers` library; a stale or hand-edited header fails here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "tables.h"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wordpiece_tables.py"), str(out)], check=True,
+                   capture_output=True, timeout=600)
+    assert out.read_text() == open(os.path.join(root, "ragmeup_amd", "csrc", "wordpiece_tables.h")).read()
