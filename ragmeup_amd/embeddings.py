@@ -84,6 +84,10 @@ class _EncoderBase:
 class MI355XEmbeddings(_EncoderBase):
     """Drop-in for langchain_huggingface.HuggingFaceEmbeddings on the reference's call sites."""
 
+    #: texts per pipeline block: while the GPU encodes block i the host tokenises block i+1 (SURVEY.md 8f-4).  Both the
+    #: tokenizer (rmu_tok_encode) and the encoder (rmu_bert_encode) run in librmu.so with the GIL released.
+    pipeline_block = 8192
+
     def _tokenize(self, texts: list[str]) -> list[list[int]]:
         if self.tokenizer is None:
             raise RuntimeError("no tokenizer: give model_dir/tokenizer, or call embed_ids with token ids")
@@ -97,7 +101,22 @@ class MI355XEmbeddings(_EncoderBase):
         return self._run(seqs, None, mode=0)
 
     def embed_documents_array(self, texts: list[str]) -> np.ndarray:
-        return self.embed_ids(self._tokenize(list(texts))).cpu().numpy()
+        texts = list(texts)
+        blk = max(1, int(self.pipeline_block))
+        if len(texts) <= blk:
+            return self.embed_ids(self._tokenize(texts)).cpu().numpy()
+        # two-stage pipeline over blocks of texts: a worker thread tokenises the next block while this thread encodes
+        from concurrent.futures import ThreadPoolExecutor
+        out = np.empty((len(texts), 384), dtype=np.float32)
+        starts = list(range(0, len(texts), blk))
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(self._tokenize, texts[starts[0]:starts[0] + blk])
+            for i, lo in enumerate(starts):
+                seqs = fut.result()
+                if i + 1 < len(starts):
+                    fut = pool.submit(self._tokenize, texts[starts[i + 1]:starts[i + 1] + blk])
+                out[lo:lo + len(seqs)] = self.embed_ids(seqs).cpu().numpy()
+        return out
 
     def embed_documents(self, texts: list[str]) -> list[list[float]]:
         return self.embed_documents_array(texts).tolist()

@@ -235,3 +235,38 @@ def test_weighted_rrf_matches_oracle_and_dedupes():
     assert [d.page_content for d in ens.invoke("q")] == [d.page_content for d in fused]
     with pytest.raises(ValueError):
         weighted_reciprocal_rank([sparse], [0.5, 0.5])
+
+
+def test_embeddings_pipeline_blocks_equal_single_pass(tmp_path, librmu):
+    """embed_documents over more texts than one pipeline block (tokenise block i+1 while block i is encoded) returns what
+    a single pass returns, in the input order.  The encoder is a CPU stand-in with the BertEncoder call surface."""
+    import torch
+    from ragmeup_amd.embeddings import MI355XEmbeddings
+    from ragmeup_amd.tokenizer import WordPieceTokenizer
+    words = ["alpha", "beta", "gamma", "delta", "##s", "##ing", "the", "of", ".", ","]
+    toks = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + words
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(toks) + "\n")
+
+    class FakeEncoder:                                   # call surface of ragmeup_amd.bert.BertEncoder that _run uses
+        device = torch.device("cpu")
+        max_pos = 512
+        has_head = False
+        calls = 0
+
+        def encode_ids(self, ids, lens, tt=None, mode=0):
+            FakeEncoder.calls += 1
+            ids = torch.as_tensor(np.asarray(ids), dtype=torch.float32)
+            feat = torch.stack([ids.sum(1), (ids * torch.arange(1, ids.shape[1] + 1)).sum(1), torch.as_tensor(np.asarray(lens), dtype=torch.float32)], 1)
+            return feat.repeat(1, 128)                   # [n, 384], a deterministic function of the token ids
+
+    rng = np.random.default_rng(0)
+    surface = ["alpha", "betas", "gamma", "deltaing", "the", "of", "unknown", "alpha,", "beta."]
+    texts = [" ".join(rng.choice(surface, size=rng.integers(1, 30))) for _ in range(2500)]
+    emb = MI355XEmbeddings(encoder=FakeEncoder(), tokenizer=WordPieceTokenizer(str(vp)), max_seq_length=32)
+    emb.pipeline_block = 10 ** 9
+    one = emb.embed_documents_array(texts)
+    emb.pipeline_block = 300                               # 9 blocks, the last one partial
+    many = emb.embed_documents_array(texts)
+    assert one.shape == (2500, 384) and np.array_equal(one, many)
+    assert emb.embed_documents(texts[:3]) == one[:3].tolist() and emb.embed_query(texts[7]) == one[7].tolist()
