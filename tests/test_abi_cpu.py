@@ -50,3 +50,25 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt and "oracle/" not in txt.replace("the oracle/", ""), f
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path, librmu):
+    """include/rmu.h must be consumable by a C compiler (the boundary is a C ABI, not a C++ one), and a plain-C program
+    must link against librmu.so with nothing but -lrmu (no execution here: the library needs a GPU)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the build image"
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "rmu.h"\nint main(void) { return rmu_version() == 0; }\n')
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(probe)],
+                   check=True, capture_output=True)
+    libdir = os.path.join(root, "ragmeup_amd", "lib")
+    exe = tmp_path / "flat_search"
+    r = subprocess.run([gcc, "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "examples", "flat_search.c"), "-L", libdir, "-lrmu", "-Wl,-rpath," + libdir,
+                        "-Wl,--allow-shlib-undefined", "-lm", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert exe.exists()
