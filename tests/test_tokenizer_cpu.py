@@ -149,3 +149,20 @@ def test_committed_unicode_tables_are_what_the_generator_produces(tmp_path):
     subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wordpiece_tables.py"), str(out)], check=True,
                    capture_output=True, timeout=600)
     assert out.read_text() == open(os.path.join(root, "ragmeup_amd", "csrc", "wordpiece_tables.h")).read()
+
+
+def test_committed_golden_from_transformers(tmp_path, librmu):
+    """tests/golden/tokenizer_golden.json was produced by transformers.BertTokenizer (script beside it): singles and pairs,
+    several max lengths, lower-cased and cased -- checked without transformers at test time."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_golden.json"), encoding="utf-8"))
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(g["vocab"]) + "\n", encoding="utf-8")
+    tok = {True: WordPieceTokenizer(str(vp), do_lower_case=True), False: WordPieceTokenizer(str(vp), do_lower_case=False)}
+    assert len(g["cases"]) == 300
+    for c in g["cases"]:
+        ids, tt, lens = tok[c["lower"]].encode([c["a"]], None if c["b"] is None else [c["b"]], max_len=c["max_len"])
+        assert ids[0, :lens[0]].tolist() == c["ids"], c
+        if c["b"] is not None:
+            assert tt[0, :lens[0]].tolist() == c["type_ids"], c
