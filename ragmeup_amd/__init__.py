@@ -8,8 +8,11 @@ from .documents import Document  # noqa: F401
 from .reranker import ScoredCrossEncoderReranker  # noqa: F401
 from .vectorstore import MI355XVectorStore  # noqa: F401
 
-__all__ = ["FlatIndex", "topk_merge", "Document", "ScoredCrossEncoderReranker", "MI355XVectorStore",
-           "BertEncoder", "MI355XEmbeddings", "MI355XCrossEncoder"]
+from .vectorstore import MI355XRetriever  # noqa: F401
+from . import factory  # noqa: F401
+
+__all__ = ["FlatIndex", "topk_merge", "Document", "ScoredCrossEncoderReranker", "MI355XVectorStore", "MI355XRetriever",
+           "BertEncoder", "MI355XEmbeddings", "MI355XCrossEncoder", "factory"]
 
 
 def __getattr__(name):   # torch-dependent classes are imported lazily

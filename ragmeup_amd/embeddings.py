@@ -20,6 +20,7 @@ from typing import Any, Sequence
 
 import numpy as np
 
+from ._lc import CROSS_ENCODER_BASES, Embeddings
 from .bert import BertEncoder
 
 
@@ -81,8 +82,10 @@ class _EncoderBase:
         return out
 
 
-class MI355XEmbeddings(_EncoderBase):
-    """Drop-in for langchain_huggingface.HuggingFaceEmbeddings on the reference's call sites."""
+class MI355XEmbeddings(_EncoderBase, Embeddings):
+    """Drop-in for langchain_huggingface.HuggingFaceEmbeddings on the reference's call sites; an instance of
+    langchain_core's `Embeddings` when LangChain is installed (SemanticChunker(self.embeddings, ...),
+    server/RAGHelper.py:336-341, and the vector stores type-check it)."""
 
     #: texts per pipeline block: while the GPU encodes block i the host tokenises block i+1 (SURVEY.md 8f-4).  Both the
     #: tokenizer (rmu_tok_encode) and the encoder (rmu_bert_encode) run in librmu.so with the GIL released.
@@ -100,14 +103,17 @@ class MI355XEmbeddings(_EncoderBase):
         seqs = [list(s)[:self.max_seq_length] for s in seqs]
         return self._run(seqs, None, mode=0)
 
-    def embed_documents_array(self, texts: list[str]) -> np.ndarray:
+    def embed_documents_device(self, texts: list[str]):
+        """texts -> torch CUDA [n, 384] unit-norm fp32, rows in text order.  The vector store appends this tensor to
+        the HBM-resident corpus device-to-device (`rmu_index_add(is_device=1)`): embeddings never visit the host."""
+        import torch
         texts = list(texts)
         blk = max(1, int(self.pipeline_block))
         if len(texts) <= blk:
-            return self.embed_ids(self._tokenize(texts)).cpu().numpy()
+            return self.embed_ids(self._tokenize(texts))
         # two-stage pipeline over blocks of texts: a worker thread tokenises the next block while this thread encodes
         from concurrent.futures import ThreadPoolExecutor
-        out = np.empty((len(texts), 384), dtype=np.float32)
+        out = torch.empty((len(texts), 384), dtype=torch.float32, device=self.encoder.device)
         starts = list(range(0, len(texts), blk))
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(self._tokenize, texts[starts[0]:starts[0] + blk])
@@ -115,8 +121,11 @@ class MI355XEmbeddings(_EncoderBase):
                 seqs = fut.result()
                 if i + 1 < len(starts):
                     fut = pool.submit(self._tokenize, texts[starts[i + 1]:starts[i + 1] + blk])
-                out[lo:lo + len(seqs)] = self.embed_ids(seqs).cpu().numpy()
+                out[lo:lo + len(seqs)] = self.embed_ids(seqs)
         return out
+
+    def embed_documents_array(self, texts: list[str]) -> np.ndarray:
+        return self.embed_documents_device(texts).cpu().numpy()
 
     def embed_documents(self, texts: list[str]) -> list[list[float]]:
         return self.embed_documents_array(texts).tolist()
@@ -125,8 +134,9 @@ class MI355XEmbeddings(_EncoderBase):
         return self.embed_documents([text])[0]
 
 
-class MI355XCrossEncoder(_EncoderBase):
-    """Drop-in for langchain_community.cross_encoders.HuggingFaceCrossEncoder: `.score(text_pairs)`."""
+class MI355XCrossEncoder(_EncoderBase, *CROSS_ENCODER_BASES):
+    """Drop-in for langchain_community.cross_encoders.HuggingFaceCrossEncoder: `.score(text_pairs)`; an instance of every
+    importable `BaseCrossEncoder` (the type of the reranker's `model` field, server/ScoredCrossEncoderReranker.py:15)."""
 
     def __init__(self, *a, max_seq_length: int = 512, **kw):
         super().__init__(*a, max_seq_length=max_seq_length, **kw)

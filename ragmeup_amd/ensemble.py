@@ -5,9 +5,9 @@ code so the hybrid retriever works with our dense retriever when langchain is no
 reference's own EnsembleRetriever accepts our retriever unchanged (it only calls ``invoke``)."""
 from __future__ import annotations
 
-from typing import Any, Sequence
+from typing import Any, List, Sequence
 
-from .documents import Document, RunnableShim
+from ._lc import BaseRetriever, Document
 
 
 def weighted_reciprocal_rank(doc_lists: Sequence[Sequence[Document]], weights: Sequence[float], c: int = 60) -> list[Document]:
@@ -27,12 +27,22 @@ def weighted_reciprocal_rank(doc_lists: Sequence[Sequence[Document]], weights: S
     return sorted(first.values(), key=lambda d: score[d.page_content], reverse=True)
 
 
-class MI355XEnsembleRetriever(RunnableShim):
-    def __init__(self, retrievers: Sequence[Any], weights: Sequence[float] | None = None, c: int = 60):
-        self.retrievers = list(retrievers)
-        self.weights = list(weights) if weights is not None else [1.0 / len(self.retrievers)] * len(self.retrievers)
-        self.c = int(c)
+class MI355XEnsembleRetriever(BaseRetriever):
+    """`EnsembleRetriever(retrievers=[...], weights=[...])` with the same fields and fusion; a LangChain `BaseRetriever`
+    when LangChain is installed.  `batch_invoke` runs every member once per batch where the member supports it."""
 
-    def invoke(self, query: str, config: Any = None, **kw) -> list[Document]:
+    retrievers: List[Any]
+    weights: List[float] = []
+    c: int = 60
+
+    def _weights(self) -> list[float]:
+        return list(self.weights) if self.weights else [1.0 / len(self.retrievers)] * len(self.retrievers)
+
+    def _get_relevant_documents(self, query: str, *, run_manager: Any = None, **kw) -> list[Document]:
         lists = [r.invoke(query) if hasattr(r, "invoke") else r.get_relevant_documents(query) for r in self.retrievers]
-        return weighted_reciprocal_rank(lists, self.weights, self.c)
+        return weighted_reciprocal_rank(lists, self._weights(), self.c)
+
+    def batch_invoke(self, queries: list[str]) -> list[list[Document]]:
+        per = [r.batch_invoke(queries) if hasattr(r, "batch_invoke") else [r.invoke(q) for q in queries]
+               for r in self.retrievers]
+        return [weighted_reciprocal_rank([m[i] for m in per], self._weights(), self.c) for i in range(len(queries))]

@@ -12,24 +12,31 @@ Surface actually touched by the reference, all provided here:
   * returned ``Document.metadata`` carries ``source``, ``id`` and ``pk`` (server.py:278-281);
   * ``delete(...)`` incl. the ``source == "<path>"`` expression server.py:373-377 sends to Milvus.
 
-Scores: the index ranks by inner product (embeddings are unit-norm, as sentence-transformers' Normalize
-module makes them).  ``score_mode`` converts to what the replaced store would report:
-"l2" -> 2 - 2*ip (Milvus metric_type "L2", smaller = better), "cosine_distance" -> 1 - ip (pgvector `<=>`),
-"ip" -> raw.  MMR restates langchain_core's maximal_marginal_relevance (fetch_k=20, lambda_mult=0.5,
+Scores: by default (``metric="ip"``) the index ranks by inner product (embeddings are unit-norm, as
+sentence-transformers' Normalize module makes them) and ``score_mode`` converts to what the replaced store would
+report: "l2" -> 2 - 2*ip (Milvus metric_type "L2", smaller = better), "cosine_distance" -> 1 - ip (pgvector `<=>`),
+"ip" -> raw.  For embedding models that do NOT normalise, ``metric="l2"`` ranks by the native squared-L2 distance
+(`RMU_METRIC_L2SQ`, Milvus' default metric on raw vectors) and ``metric="cosine"`` by cosine (pgvector `<=>`).
+
+The class derives from LangChain's `VectorStore` and its retriever from `VectorStoreRetriever` whenever LangChain is
+installed (ragmeup_amd._lc), so `EnsembleRetriever(retrievers=[bm25, retriever])` (server/RAGHelper.py:501-503) and
+LCEL dict coercion (server/RAGHelper_local.py:254-258) accept them.  MMR restates langchain_core's maximal_marginal_relevance (fetch_k=20, lambda_mult=0.5,
 strict '>' so the lowest index wins ties) on the fetch_k vectors gathered from HBM.
 """
 from __future__ import annotations
 
+import atexit
+import json
 import os
-import pickle
 import re
 import threading
+import weakref
 from typing import Any, Iterable, Optional
 
 import numpy as np
 
 from . import _native as N
-from .documents import Document, RunnableShim
+from ._lc import Document, VectorStore, VectorStoreRetriever
 from .index import FlatIndex
 
 
@@ -74,17 +81,11 @@ def maximal_marginal_relevance(query_vec: np.ndarray, cand: np.ndarray, k: int =
     return picked
 
 
-class MI355XRetriever(RunnableShim):
-    """What ``as_retriever`` returns: ``invoke(query) -> list[Document]``."""
+class MI355XRetriever(VectorStoreRetriever):
+    """What ``as_retriever`` returns: ``invoke(query) -> list[Document]`` (a LangChain `VectorStoreRetriever` with the
+    fields ``vectorstore``, ``search_type``, ``search_kwargs``), plus ``batch_invoke``."""
 
-    def __init__(self, store: "MI355XVectorStore", search_type: str = "similarity", search_kwargs: dict | None = None):
-        if search_type not in ("similarity", "mmr", "similarity_score_threshold"):
-            raise ValueError(f"search_type of {search_type} not allowed.")
-        self.vectorstore = store
-        self.search_type = search_type
-        self.search_kwargs = dict(search_kwargs or {})
-
-    def invoke(self, query: str, config: Any = None, **kw) -> list[Document]:
+    def _get_relevant_documents(self, query: str, *, run_manager: Any = None, **kw) -> list[Document]:
         if self.search_type == "mmr":
             return self.vectorstore.max_marginal_relevance_search(query, **self.search_kwargs)
         if self.search_type == "similarity_score_threshold":
@@ -102,25 +103,37 @@ class MI355XRetriever(RunnableShim):
         return [[d for d, _ in row] for row in self.vectorstore.similarity_search_with_score_batch(queries, k=k)]
 
 
-class MI355XVectorStore:
-    _collections: dict[str, "MI355XVectorStore"] = {}   # drop_old=False re-attaches to a live collection
+_METRICS = {"ip": N.METRIC_IP, "cosine": N.METRIC_COSINE, "l2": N.METRIC_L2SQ}
+
+
+class MI355XVectorStore(VectorStore):
+    # drop_old=False re-attaches to a live collection; weak values: the registry does not keep a 15 GB index alive
+    _collections: "weakref.WeakValueDictionary[str, MI355XVectorStore]" = weakref.WeakValueDictionary()
     _collections_lock = threading.Lock()
 
     def __init__(self, embeddings: Any = None, collection_name: str = "LangChainCollection", connection: Any = None,
                  use_jsonb: bool = True, *, embedding_function: Any = None, connection_args: dict | None = None,
-                 drop_old: bool = False, score_mode: str = "l2", dim: int | None = None, device: int | None = None,
-                 auto_persist: bool = False):
-        self.embeddings = embeddings if embeddings is not None else embedding_function
-        if self.embeddings is None:
+                 drop_old: bool = False, score_mode: str | None = None, metric: str = "ip", dim: int | None = None,
+                 device: int | None = None, auto_persist: bool | str = "atexit"):
+        self._embeddings = embeddings if embeddings is not None else embedding_function
+        if self._embeddings is None:
             raise ValueError("an Embeddings object is required")
         self.collection_name = collection_name
         self.connection = connection if connection is not None else (connection_args or {}).get("uri")
-        if score_mode not in ("l2", "cosine_distance", "ip"):
-            raise ValueError("score_mode must be 'l2', 'cosine_distance' or 'ip'")
+        if metric not in _METRICS:
+            raise ValueError("metric must be 'ip', 'cosine' or 'l2'")
+        self.metric = metric
+        if score_mode is None:   # native metrics report their own number; IP on unit vectors imitates Milvus "L2"
+            score_mode = {"ip": "l2", "cosine": "cosine_distance", "l2": "raw"}[metric]
+        if score_mode not in ("l2", "cosine_distance", "ip", "raw"):
+            raise ValueError("score_mode must be 'l2', 'cosine_distance', 'ip' or 'raw'")
         self.score_mode = score_mode
         self._device = device
         self._dim = dim
-        self.auto_persist = bool(auto_persist)   # Milvus-Lite writes through to its file; opt in to the same
+        # Milvus-Lite writes through to its file.  True: rewrite the files after every add/delete (O(N) each);
+        # "atexit" (default): write once at interpreter exit if anything changed; False: only on persist()
+        self.auto_persist = auto_persist
+        self._dirty = False
         self._index: FlatIndex | None = None
         self._lock = threading.RLock()       # writer lock (add/delete); searches take the C-side shared lock
         self._texts: list[str] = []
@@ -128,6 +141,16 @@ class MI355XVectorStore:
         self._pks: list[str] = []
         self._alive: list[bool] = []
         self._pk_to_row: dict[str, int] = {}
+        if drop_old:
+            self._remove_persisted()
+        if auto_persist == "atexit" and self._persist_paths():
+            ref = weakref.ref(self)
+            atexit.register(lambda: (lambda s: s is not None and s._dirty and s._persist_quietly())(ref()))
+
+    @property
+    def embeddings(self):
+        """The `Embeddings` object (a read-only property on LangChain's VectorStore)."""
+        return self._embeddings
 
     # ---- construction as the reference does it (RAGHelper.py:388-394) --------------------------------
     @classmethod
@@ -138,7 +161,8 @@ class MI355XVectorStore:
         with cls._collections_lock:
             store = None if drop_old else cls._collections.get(key)
             if store is None:
-                store = cls(embeddings=embedding, collection_name=collection_name, connection_args=connection_args, **kw)
+                store = cls(embeddings=embedding, collection_name=collection_name, connection_args=connection_args,
+                            drop_old=drop_old, **kw)
                 cls._collections[key] = store
                 # vector_store_initial_load=False: re-open what an earlier run persisted (RAGHelper.py:391, :417)
                 if not drop_old and store._persist_paths() and all(os.path.exists(p) for p in store._persist_paths()):
@@ -147,36 +171,72 @@ class MI355XVectorStore:
             store.add_documents(documents, ids=ids)
         return store
 
-    # ---- persistence: <uri>.<collection>.rmu (corpus matrix) + .meta.pkl (texts, metadata, pks) -------------
+    @classmethod
+    def from_texts(cls, texts: list[str], embedding: Any, metadatas: Optional[list[dict]] = None,
+                   ids: Optional[list[str]] = None, **kw) -> "MI355XVectorStore":
+        store = cls.from_documents([], embedding, **kw)
+        if texts:
+            store.add_texts(texts, metadatas, ids=ids)
+        return store
+
+    # ---- persistence: <uri>.<collection>.rmu (corpus matrix) + .meta.json (texts, metadata, pks) ------------
     def _persist_paths(self) -> tuple[str, str] | None:
         if not self.connection or not isinstance(self.connection, str) or "://" in self.connection:
             return None
         base = f"{self.connection}.{self.collection_name}"
-        return base + ".rmu", base + ".meta.pkl"
+        return base + ".rmu", base + ".meta.json"
+
+    def _remove_persisted(self):
+        for p in self._persist_paths() or ():
+            for q in (p, p + ".tmp"):
+                if os.path.exists(q):
+                    os.remove(q)
 
     def persist(self) -> bool:
+        """Both files are written to temporaries and renamed into place (a crash leaves the previous pair)."""
         paths = self._persist_paths()
         if paths is None or self._index is None:
             return False
         with self._lock:
-            self._index.save(paths[0])
-            with open(paths[1], "wb") as f:
-                pickle.dump({"texts": self._texts, "metas": self._metas, "pks": self._pks, "alive": self._alive,
-                             "dim": self._dim, "score_mode": self.score_mode}, f)
+            self._index.save(paths[0] + ".tmp")
+            with open(paths[1] + ".tmp", "w", encoding="utf-8") as f:
+                json.dump({"format": 1, "n": len(self._texts), "dim": self._dim, "metric": self.metric,
+                           "score_mode": self.score_mode, "texts": self._texts, "metas": self._metas, "pks": self._pks,
+                           "alive": [1 if a else 0 for a in self._alive]}, f)
+            os.replace(paths[0] + ".tmp", paths[0])
+            os.replace(paths[1] + ".tmp", paths[1])
+            self._dirty = False
         return True
+
+    def _persist_quietly(self):
+        try:
+            self.persist()
+        except Exception:   # noqa: BLE001 - interpreter shutdown: nothing useful to do with it
+            pass
 
     def load(self) -> bool:
         paths = self._persist_paths()
         if paths is None:
             return False
         with self._lock:
-            with open(paths[1], "rb") as f:
-                m = pickle.load(f)
+            with open(paths[1], "r", encoding="utf-8") as f:
+                m = json.load(f)
             factory = type(self)._index_factory
-            self._index = factory.load(paths[0]) if factory is not None and hasattr(factory, "load") else FlatIndex.load(paths[0], device=self._device)
-            self._texts, self._metas, self._pks, self._alive = m["texts"], m["metas"], m["pks"], m["alive"]
+            index = factory.load(paths[0]) if factory is not None and hasattr(factory, "load") else FlatIndex.load(paths[0], device=self._device)
+            n = len(m["texts"])
+            if not (len(m["metas"]) == len(m["pks"]) == len(m["alive"]) == n == int(m.get("n", n)) == len(index)):
+                raise ValueError(f"{paths[1]} does not describe {paths[0]} ({n} records vs {len(index)} rows)")
+            want = _METRICS[m.get("metric", "ip")]
+            if getattr(index, "metric", want) != want:
+                raise ValueError(f"{paths[0]}: metric differs from {paths[1]}")
+            self._index = index
+            self._texts, self._metas, self._pks = m["texts"], m["metas"], m["pks"]
+            self._alive = [bool(a) for a in m["alive"]]
             self._dim = m["dim"]
+            self.metric = m.get("metric", "ip")
+            self.score_mode = m.get("score_mode", self.score_mode)
             self._pk_to_row = {pk: r for r, pk in enumerate(self._pks) if self._alive[r]}
+            self._dirty = False
         return True
 
     # ---- helpers ----------------------------------------------------------------------------------------
@@ -185,30 +245,37 @@ class MI355XVectorStore:
     def _ensure_index(self, dim: int):
         if self._index is None:
             self._dim = dim
-            factory = type(self)._index_factory or (lambda d: FlatIndex(d, N.METRIC_IP, device=self._device))
+            factory = type(self)._index_factory or (lambda d: FlatIndex(d, _METRICS[self.metric], device=self._device))
             self._index = factory(dim)
         elif dim != self._dim:
             raise ValueError(f"embedding dimension changed: {self._dim} -> {dim}")
 
+    def _embed_docs_for_index(self, texts: list[str]):
+        """Embeddings for insertion: a torch CUDA tensor when the Embeddings object can produce one (ours: the rows go
+        device-to-device into the corpus, no host round trip), else a numpy array."""
+        if hasattr(self._embeddings, "embed_documents_device") and type(self)._index_factory is None:
+            return self._embeddings.embed_documents_device(texts)
+        return self._embed_docs(texts)
+
     def _embed_docs(self, texts: list[str]) -> np.ndarray:
-        if hasattr(self.embeddings, "embed_documents_array"):     # our Embeddings: no Python float lists
-            return np.asarray(self.embeddings.embed_documents_array(texts), dtype=np.float32)
-        return np.asarray(self.embeddings.embed_documents(texts), dtype=np.float32)
+        if hasattr(self._embeddings, "embed_documents_array"):     # our Embeddings: no Python float lists
+            return np.asarray(self._embeddings.embed_documents_array(texts), dtype=np.float32)
+        return np.asarray(self._embeddings.embed_documents(texts), dtype=np.float32)
 
     def _embed_query(self, text: str) -> np.ndarray:
-        return np.asarray(self.embeddings.embed_query(text), dtype=np.float32)
+        return np.asarray(self._embeddings.embed_query(text), dtype=np.float32)
 
     def _doc(self, row: int) -> Document:
         md = dict(self._metas[row])
         md["pk"] = self._pks[row]
         return Document(page_content=self._texts[row], metadata=md)
 
-    def _convert(self, ip: float) -> float:
+    def _convert(self, s: float) -> float:
         if self.score_mode == "l2":
-            return float(2.0 - 2.0 * ip)
+            return float(2.0 - 2.0 * s)
         if self.score_mode == "cosine_distance":
-            return float(1.0 - ip)
-        return float(ip)
+            return float(1.0 - s)
+        return float(s)
 
     def __len__(self) -> int:
         return sum(self._alive)
@@ -223,25 +290,40 @@ class MI355XVectorStore:
         if ids is None:
             import uuid
             ids = [str(uuid.uuid4()) for _ in texts]
+        ids = [str(i) for i in ids]
         if len(ids) != len(texts) or len(metadatas) != len(texts):
             raise ValueError("texts, metadatas and ids must have equal lengths")
-        vecs = self._embed_docs(texts)
+        # upsert semantics of the replaced stores: one row per pk -- inside a batch the LAST occurrence wins
+        last = {pk: i for i, pk in enumerate(ids)}
+        keep = sorted(last.values())
+        vecs = self._embed_docs_for_index([texts[i] for i in keep])
         with self._lock:
             self._ensure_index(int(vecs.shape[1]))
-            # upsert semantics of the replaced stores: an existing pk is replaced
-            stale = [self._pk_to_row[i] for i in ids if i in self._pk_to_row and self._alive[self._pk_to_row[i]]]
+            n0 = len(self._texts)
+            # host records FIRST: a concurrent search may return a new row the moment index.add publishes it
+            for i in keep:
+                self._texts.append(texts[i])
+                self._metas.append(dict(metadatas[i]))
+                self._pks.append(ids[i])
+                self._alive.append(True)
+            try:
+                first = self._index.add(vecs)
+                if first != n0:
+                    raise RuntimeError(f"index rows ({first}) and host records ({n0}) out of step")
+            except Exception:
+                del self._texts[n0:], self._metas[n0:], self._pks[n0:], self._alive[n0:]
+                raise
+            # the new copies are in: only now retire the rows they replace (a failed add loses nothing)
+            stale = [self._pk_to_row[ids[i]] for i in keep
+                     if ids[i] in self._pk_to_row and self._alive[self._pk_to_row[ids[i]]]]
             if stale:
                 self._index.remove_rows(stale)
                 for r in stale:
                     self._alive[r] = False
-            first = self._index.add(vecs)
-            for off, (t, m, i) in enumerate(zip(texts, metadatas, ids)):
-                self._texts.append(t)
-                self._metas.append(dict(m))
-                self._pks.append(str(i))
-                self._alive.append(True)
-                self._pk_to_row[str(i)] = first + off
-            if self.auto_persist:
+            for off, i in enumerate(keep):
+                self._pk_to_row[ids[i]] = n0 + off
+            self._dirty = True
+            if self.auto_persist is True:
                 self.persist()
         return list(ids)
 
@@ -274,8 +356,10 @@ class MI355XVectorStore:
                 self._index.remove_rows(rows)
             for r in rows:
                 self._alive[r] = False
-            if rows and self.auto_persist:
-                self.persist()
+            if rows:
+                self._dirty = True
+                if self.auto_persist is True:
+                    self.persist()
         return _DeleteResult(len(rows))
 
     # ---- search ---------------------------------------------------------------------------------------------
@@ -342,7 +426,10 @@ class MI355XVectorStore:
         return out
 
     def as_retriever(self, search_type: str = "similarity", search_kwargs: dict | None = None, **kw) -> MI355XRetriever:
-        return MI355XRetriever(self, search_type=search_type, search_kwargs=search_kwargs)
+        """`db.as_retriever(search_type="mmr", search_kwargs={"k": K})` (server/RAGHelper.py:497-499, :533-535)."""
+        tags = list(kw.pop("tags", None) or []) + [type(self).__name__]
+        return MI355XRetriever(vectorstore=self, search_type=search_type, search_kwargs=dict(search_kwargs or {}),
+                               tags=tags, **kw)
 
 
 class _DeleteResult(int):

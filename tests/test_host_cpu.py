@@ -41,12 +41,12 @@ class FakeIndex:
         return s.astype(np.float32), r
 
     def save(self, path):
-        np.savez(path + ".npz", x=self.x, alive=self.alive)
-        open(path, "wb").close()
+        with open(path, "wb") as f:
+            np.savez(f, x=self.x, alive=self.alive)
 
     @classmethod
     def load(cls, path):
-        z = np.load(path + ".npz")
+        z = np.load(path)
         self = cls(z["x"].shape[1]); self.x, self.alive = z["x"], z["alive"]
         return self
 
@@ -211,11 +211,52 @@ def test_persist_and_reopen(tmp_path):
         hit = b.similarity_search("chunk number 33 of a.pdf", k=1)[0]
         assert hit.page_content == "chunk number 33 of a.pdf" and hit.metadata["pk"] == _chunks(60)[33].metadata["id"]
         assert all(d.page_content != "chunk number 7 of a.pdf" for d in b.similarity_search("chunk number 7 of a.pdf", k=5))
+        # the metadata is JSON (no pickle), written atomically, and must describe the matrix file
+        import json as _json
+        meta = _json.load(open(uri + ".c.meta.json"))
+        assert meta["n"] == 60 and meta["metric"] == "ip" and not os.path.exists(uri + ".c.meta.json.tmp")
+        meta["texts"].pop()
+        _json.dump(meta, open(uri + ".c.meta.json", "w"))
+        del b
+        MI355XVectorStore._collections.clear()
+        with pytest.raises(ValueError, match="does not describe"):
+            MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False, connection_args={"uri": uri}, collection_name="c")
+        MI355XVectorStore._collections.clear()
         c = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=True,
                                              connection_args={"uri": uri}, collection_name="c")
-        assert len(c) == 0                                          # drop_old ignores the files
+        assert len(c) == 0                                          # drop_old ignores the files ...
+        assert not os.path.exists(uri + ".c.rmu") and not os.path.exists(uri + ".c.meta.json")   # ... and removes them
     finally:
         MI355XVectorStore._index_factory = None
+
+
+def test_add_texts_upsert_duplicates_and_failed_add(store):
+    """duplicate ids inside one batch leave ONE live row (the last wins); a failing index.add loses nothing and
+    leaves host records and index in step; host records exist before the rows become searchable."""
+    docs = _chunks(5)
+    ids = ["k0", "k1", "k0", "k2", "k1"]
+    store.add_documents(docs, ids=ids)
+    assert len(store) == 3 and len(store._index) == 3
+    by_pk = {d.metadata["pk"]: d.page_content for d in store.similarity_search("chunk", k=10)}
+    assert by_pk == {"k0": docs[2].page_content, "k1": docs[4].page_content, "k2": docs[3].page_content}
+
+    real_add = store._index.add
+    def boom(v):
+        raise RuntimeError("device lost")
+    store._index.add = boom
+    with pytest.raises(RuntimeError, match="device lost"):
+        store.add_documents(_chunks(2, "b.pdf"), ids=["k0", "new"])     # k0 would have been replaced
+    store._index.add = real_add
+    assert len(store) == 3 and len(store._texts) == len(store._index) == 3
+    assert {d.metadata["pk"] for d in store.similarity_search("chunk", k=10)} == {"k0", "k1", "k2"}
+
+    seen = []
+    def spy(v):
+        seen.append(len(store._texts))                                   # host records are already appended
+        return real_add(v)
+    store._index.add = spy
+    store.add_documents(_chunks(2, "c.pdf"), ids=["k0", "k9"])
+    assert seen == [5] and len(store) == 4
 
 
 def test_weighted_rrf_matches_oracle_and_dedupes():
@@ -231,7 +272,7 @@ def test_weighted_rrf_matches_oracle_and_dedupes():
     class R:
         def __init__(self, docs): self.docs = docs
         def invoke(self, q): return self.docs
-    ens = MI355XEnsembleRetriever([R(sparse), R(dense)], weights=[0.5, 0.5])   # RAGHelper.py:501-503
+    ens = MI355XEnsembleRetriever(retrievers=[R(sparse), R(dense)], weights=[0.5, 0.5])   # RAGHelper.py:501-503
     assert [d.page_content for d in ens.invoke("q")] == [d.page_content for d in fused]
     with pytest.raises(ValueError):
         weighted_reciprocal_rank([sparse], [0.5, 0.5])
