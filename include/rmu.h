@@ -28,21 +28,28 @@ extern "C" {
 #define RMU_E_INVALID (-1) /* bad argument / unsupported shape */
 #define RMU_E_HIP (-2)     /* HIP runtime error */
 #define RMU_E_OOM (-3)     /* device or host allocation failed */
-#define RMU_E_RCCL (-4)    /* reserved: collective error */
+#define RMU_E_RCCL (-4)    /* RCCL error (librccl.so missing, communicator or collective failure) */
 
 #define RMU_METRIC_IP 0     /* larger = better */
 #define RMU_METRIC_COSINE 1 /* rows are stored L2-normalised, queries normalised per call */
-#define RMU_METRIC_L2SQ 2   /* reported as squared distance, smaller = better (Milvus "L2") */
+#define RMU_METRIC_L2SQ 2   /* squared L2 distance on the stored (un-normalised) rows, smaller = better (Milvus "L2");
+                             * dim <= 767 (rows carry -|x|^2 in one pad column: 384-d rows are stored 768 wide) */
 
 /* flags for rmu_index_search / rmu_topk_merge */
 #define RMU_F_Q_DEVICE 1u   /* query pointer is a device address */
 #define RMU_F_OUT_DEVICE 2u /* output pointers are device addresses */
+#define RMU_F_SMALLER_BETTER 4u /* rmu_topk_merge / rmu_shard_allgather_topk: the scores are distances (RMU_METRIC_L2SQ lists) */
+
+/* options for rmu_index_set_option */
+#define RMU_OPT_SCREEN 1    /* 1 (default): searches may take the fp16 screening path; 0: always the exact fp32 scan.
+                             * Results are identical either way (bench.py times both through this switch). */
 
 #define RMU_MAX_K 112       /* largest k the fused scan keeps in LDS */
 #define RMU_MAX_DIM 768
 
 typedef struct rmu_index rmu_index_t;
 typedef struct rmu_bert rmu_bert_t;
+typedef struct rmu_comm rmu_comm_t;
 
 /* ---- runtime ------------------------------------------------------------------------------- */
 /* hipSetDevice(device_ordinal); idempotent.  Serves: RAGHelper_local.py:107-117 (device choice). */
@@ -57,6 +64,8 @@ int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t capacity_hi
 int rmu_index_free(rmu_index_t* idx);
 int rmu_index_size(rmu_index_t* idx, int64_t* n_rows);
 int rmu_index_dim(rmu_index_t* idx, int* dim);
+int rmu_index_metric(rmu_index_t* idx, int* metric);
+int rmu_index_set_option(rmu_index_t* idx, int option, int64_t value);
 
 /* Append n rows ([n, dim] fp32 row-major, host or device).  *first_row = row id of vecs[0].
  * Serves: RAGHelper.py:431, :525 (db.add_documents -> add_texts -> insert). */
@@ -88,7 +97,9 @@ int rmu_index_load(rmu_index_t** out, const char* path);
 
 /* Exact top-k of every query against all live rows (dim 384, k <= 24: fp16 screening + exact fp32 re-score under a
  * per-query sufficiency test; otherwise, and for every query that fails the test, the exact fp32 fused scan -- the
- * returned ids and scores are those of the exact scan either way).
+ * returned ids and scores are those of the exact scan either way; the failing queries are re-run by launches that are
+ * predicated on the device, so the call never waits on the host for a decision and, given a caller stream with device
+ * buffers and nq <= 8192, returns without synchronising it).
  *   q [nq, dim] fp32; out_scores [nq, k] fp32, out_rows [nq, k] int64, best first,
  *   order (score, then lower row id); slots beyond the live row count hold (-inf | +inf for L2SQ, -1).
  *   row_base is added to every returned row id (shard offset).
@@ -96,11 +107,33 @@ int rmu_index_load(rmu_index_t** out, const char* path);
 int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, int k, unsigned flags,
                      int64_t row_base, float* out_scores, int64_t* out_rows, uint64_t hip_stream);
 
-/* Merge `parts` per-shard top-k lists ([parts, nq, k] each, best first, larger score = better)
- * into one [nq, k].  Ties: lower part index first (give shards in ascending row order).
+/* Merge `parts` per-shard top-k lists ([parts, nq, k] each, best first; larger score = better unless
+ * RMU_F_SMALLER_BETTER) into one [nq, k].  Ties: lower part index first (give shards in ascending row order).
  * Serves: the 8-GPU shard merge after the RCCL all-gather; no reference counterpart. */
 int rmu_topk_merge(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
                    unsigned flags, float* out_scores, int64_t* out_rows, uint64_t hip_stream);
+
+/* ---- multi-GPU: the one exchange step of the row-sharded search -----------------------------------------
+ * One process per GPU.  Rank 0 calls rmu_comm_unique_id and hands the 128 bytes to the other ranks by any side channel
+ * (a file, a socket, torch.distributed's store); every rank then calls rmu_comm_init on ITS device (rmu_init first).
+ * RCCL is bound at run time (dlopen of librccl.so; RMU_E_RCCL if absent).  No reference counterpart. */
+#define RMU_COMM_ID_BYTES 128
+int rmu_comm_unique_id(void* id_out /* RMU_COMM_ID_BYTES */);
+int rmu_comm_init(rmu_comm_t** out, const void* id, int world, int rank);
+int rmu_comm_free(rmu_comm_t* comm);
+int rmu_comm_world(rmu_comm_t* comm, int* world, int* rank);
+/* Every rank passes its local [nq, k] lists (what rmu_index_search returned with row_base = the shard's first row):
+ * ONE RCCL all-gather of nq*k*12 bytes per rank over xGMI, then the W lists are merged on the device; every rank ends
+ * with the same global [nq, k].  flags: RMU_F_Q_DEVICE (inputs), RMU_F_OUT_DEVICE (outputs), RMU_F_SMALLER_BETTER. */
+int rmu_shard_allgather_topk(rmu_comm_t* comm, const float* scores, const int64_t* rows, int64_t nq, int k, unsigned flags,
+                             float* out_scores, int64_t* out_rows, uint64_t hip_stream);
+
+/* Test hook (tests/test_search_gpu.py), not a product entry point: the screening pass's K' = 32 candidates of each of nq
+ * host queries -- approximate scores, row ids, the exact fp32 score of the same rows, and the error bound EPS(q) of the
+ * sufficiency test -- so |approx - exact| <= EPS can be checked on the hardware.  All outputs are host arrays
+ * ([nq, 32] x 3 and [nq]); absent candidates are (-inf, -1, -inf). */
+int rmu_index_screen_candidates(rmu_index_t* idx, const float* q_host, int64_t nq, float* out_approx, int64_t* out_rows,
+                                float* out_exact, float* out_eps);
 
 /* Timing hook for bench.py: duration in ms of the last fused scan kernel launched by the calling
  * thread, measured with hipEvents on the stream the kernel ran on; <0 if none. */
@@ -109,7 +142,8 @@ float rmu_last_scan_ms(void);
 float rmu_last_search_ms(void);
 int rmu_last_scan_geometry(int* grid, int* block, int* lds_bytes, int* passes);
 /* How the calling thread's last rmu_index_search was answered: >0 by the fp16 screening ladder + exact fp32 re-score;
- * <0 the same, with that many queries failing the sufficiency test and re-run on the exact fp32 scan (patched in);
+ * <0 the same, with that many queries failing the sufficiency test and re-run on the exact fp32 scan (patched in; the
+ * count is known only when the call itself drained the stream, i.e. not for an un-synchronised caller stream);
  * 0 by the exact fp32 scan alone.  Results are identical in all three cases. */
 int rmu_last_screened(void);
 /* Enable (1) / disable (0) the event timing above for the calling thread (off by default). */

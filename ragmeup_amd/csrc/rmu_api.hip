@@ -55,9 +55,18 @@ extern "C" int rmu_init(int device_ordinal) {
 // ------------------------------------------------------------------------------------------------
 // per-thread context: stream, events, grow-only workspace
 // ------------------------------------------------------------------------------------------------
+// Set once the process starts tearing the HIP runtime down (static destructors / atexit): thread-local destructors
+// that run after that point must not call into HIP any more.
+static bool g_runtime_down = false;
+namespace { struct RuntimeGuard { ~RuntimeGuard() { g_runtime_down = true; } } g_runtime_guard; }
+
 struct Buf {
     void* p = nullptr;
     size_t cap = 0;
+    void release() {
+        if (p && !g_runtime_down) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
     int ensure(size_t bytes) {
         if (bytes <= cap) return RMU_OK;
         if (p) (void)hipFree(p);
@@ -81,6 +90,7 @@ struct Tls {
         }
         return RMU_OK;
     }
+    int* hflag = nullptr;          // pinned landing word of the screening path's re-run count
     bool timing = false;
     float scan_ms = -1.f, search_ms = -1.f;
     int grid = 0, block = 0, lds = 0, passes = 0, screened = 0;
@@ -93,6 +103,21 @@ struct Tls {
                 if (hipEventCreate(&e) != hipSuccess) return RMU_E_HIP;
         }
         return RMU_OK;
+    }
+    // A server that spawns a thread per request (Flask's threaded dev server, server/server.py:394) creates one of
+    // these per request: everything it owns goes back when the thread exits.
+    ~Tls() {
+        if (g_runtime_down) return;
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (Buf* b : {&q, &partial, &out_s, &out_r, &in_s, &in_r, &qn, &gthr, &mscratch, &qsplit, &ckeys, &flag, &nrm, &fbq, &fb_s,
+                       &fb_r, &fb_i})
+            b->release();
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : lev) (void)hipEventDestroy(e);
+        if (hflag) (void)hipHostFree(hflag);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
     }
 };
 static thread_local Tls g_tls;
@@ -137,6 +162,33 @@ __global__ void k_row_norm(float* x, int dpad, int64_t n, int normalise, float* 
     }
 }
 
+// RMU_METRIC_L2SQ: the scan ranks by inner product, and argmin |q - x|^2 = argmax (2 q.x - |x|^2).  Rows carry -|x|^2 in
+// the first pad column (column `dim`; the L2 index pads dim + 1), queries are stored as (2q, 1): the scan's inner product
+// is then 2 q.x - |x|^2 and the merge reports |q|^2 minus it.  One wave per row.
+__global__ void k_l2_aug_rows(float* x, int dpad, int dim, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float* row = x + r * (int64_t)dpad;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) s = fmaf(row[c], row[c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) row[dim] = -s;
+}
+// queries (already copied into the dpad-wide buffer): qn2[r] = |q|^2, q <- 2q, column dim <- 1
+__global__ void k_l2_aug_queries(float* q, int dpad, int dim, int64_t n, float* qn2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float* row = q + r * (int64_t)dpad;
+    float s = 0.f;
+    for (int c = lane; c < dim; c += 64) { const float v = row[c]; s = fmaf(v, v, s); row[c] = 2.0f * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) { qn2[r] = s; row[dim] = 1.0f; }
+}
+
 // max over rows of |x|^2 (non-negative floats order like their bit patterns)
 __global__ void k_max_norm2(const float* __restrict__ norm2, int64_t n, unsigned* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,13 +206,13 @@ __global__ void k_gather_rows(const float* x, int dpad, int dim, const int64_t* 
     for (int c = threadIdx.x; c < dim; c += blockDim.x) out[r * dim + c] = row[c];
 }
 
-// results of the re-run queries back into the batch outputs: dst[(pos[i]) * k + c] = src[i * k + c]
-__global__ void k_scatter_results(const float* src_s, const int64_t* src_r, const int64_t* pos, int64_t n, int k,
-                                  float* dst_s, int64_t* dst_r) {
-    const int64_t i = blockIdx.x;
-    if (i >= n || (int)threadIdx.x >= k) return;
-    dst_s[pos[i] * k + threadIdx.x] = src_s[i * k + threadIdx.x];
-    dst_r[pos[i] * k + threadIdx.x] = src_r[i * k + threadIdx.x];
+// the queries the screening path flagged (list `pos`, count *count) -> a dense [count, dpad] block for the exact re-run
+__global__ void k_gather_flagged(const float* __restrict__ q, int dpad, const int64_t* __restrict__ pos, const int* __restrict__ count,
+                                 float* __restrict__ out) {
+    const int64_t r = blockIdx.x;
+    if (r >= *count) return;
+    const float* row = q + pos[r] * (int64_t)dpad;
+    for (int c = threadIdx.x; c < dpad; c += blockDim.x) out[r * dpad + c] = row[c];
 }
 
 // Batched greedy MMR (langchain_core `maximal_marginal_relevance`, the reference retriever's search_type="mmr",
@@ -230,6 +282,7 @@ struct rmu_index {
     char* split = nullptr;          // fp16(64 x) image of x (screening pass), 768 B per row; nullptr = disabled
     float xnorm_max = 0.f;          // max row norm (bounds the screening error)
     float dx_max = 0.f;             // max row norm of (x - screening image): the measured rounding error
+    bool screen_enabled = true;     // RMU_OPT_SCREEN: searches may take the screening path (when `split` exists)
     std::vector<uint8_t> alive;
     std::shared_mutex mu;
 };
@@ -237,19 +290,22 @@ struct rmu_index {
 // the scan's LDS-DMA reads whole 128-row tiles: keep that many allocated rows past the last one
 static const int64_t kSlackRows = 128;
 static int pad_dim(int d) { return d <= 192 ? 192 : (d <= 384 ? 384 : (d <= 768 ? 768 : -1)); }
+// L2SQ rows carry -|x|^2 in one extra column (see k_l2_aug_rows)
+static int pad_dim_metric(int d, int metric) { return pad_dim(metric == RMU_METRIC_L2SQ ? d + 1 : d); }
 
 extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t capacity_hint) {
     if (!out) return fail(RMU_E_INVALID, "rmu_index_create: out is null");
     if (dim < 1 || dim > RMU_MAX_DIM) return fail(RMU_E_INVALID, "rmu_index_create: dim must be in [1, 768]");
-    if (metric != RMU_METRIC_IP && metric != RMU_METRIC_COSINE)
-        return fail(RMU_E_INVALID, "rmu_index_create: metric must be RMU_METRIC_IP or RMU_METRIC_COSINE in this build "
-                                   "(L2SQ on unit-norm rows = 2 - 2*IP is applied by the host adapter)");
+    if (metric != RMU_METRIC_IP && metric != RMU_METRIC_COSINE && metric != RMU_METRIC_L2SQ)
+        return fail(RMU_E_INVALID, "rmu_index_create: metric must be RMU_METRIC_IP, RMU_METRIC_COSINE or RMU_METRIC_L2SQ");
+    if (pad_dim_metric(dim, metric) < 0)
+        return fail(RMU_E_INVALID, "rmu_index_create: RMU_METRIC_L2SQ needs one spare column: dim must be <= 767");
     int rc = g_tls.ensure_stream();
     if (rc) return fail(rc, "rmu_index_create: stream");
     auto* idx = new (std::nothrow) rmu_index();
     if (!idx) return fail(RMU_E_OOM, "rmu_index_create: host alloc");
     idx->dim = dim;
-    idx->dpad = pad_dim(dim);
+    idx->dpad = pad_dim_metric(dim, metric);
     idx->metric = metric;
     int64_t cap = capacity_hint > 0 ? capacity_hint : 4096;
     hipError_t e = hipMalloc((void**)&idx->x, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float));
@@ -265,7 +321,7 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
     idx->cap = cap;
     // screening image (+50% corpus memory): 384-wide rows only; RMU_SCREEN=0 disables
     static const bool screen_on = !(getenv("RMU_SCREEN") && atoi(getenv("RMU_SCREEN")) == 0);
-    if (screen_on && idx->dpad == 384) {
+    if (screen_on && idx->dpad == 384 && dim == 384) {
         if (hipMalloc((void**)&idx->split, (size_t)(cap + kSlackRows) * RMU_IMG_ROW_BYTES) != hipSuccess) {
             idx->split = nullptr;   // not fatal: exact path only
             (void)hipGetLastError();
@@ -394,6 +450,10 @@ extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int
         const int wpb = 4;
         hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, dst, idx->dpad, n, 1,
                            (float*)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    if (idx->metric == RMU_METRIC_L2SQ) {
+        hipLaunchKernelGGL(k_l2_aug_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dst, idx->dpad, idx->dim, n);
         HIP_TRY(hipGetLastError());
     }
     if (idx->split) {
@@ -539,7 +599,7 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
     if (!f) return fail(RMU_E_INVALID, std::string("rmu_index_load: cannot open ") + path);
     RmuFileHeader h{};
     if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RMUIDX01", 8) != 0 || h.n < 0 || h.dim < 1 ||
-        h.dpad != pad_dim(h.dim)) {
+        h.dpad != pad_dim_metric(h.dim, h.metric)) {
         fclose(f);
         return fail(RMU_E_INVALID, std::string("rmu_index_load: not an RMUIDX01 file: ") + path);
     }
@@ -572,6 +632,109 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
 // search
 // ------------------------------------------------------------------------------------------------
 static const int64_t kMaxQueriesPerLaunch = 8192;
+static const int kScreenKp = 32;     // K': candidates the screening pass keeps per query
+
+static u64* g_dbg = nullptr;         // RMU_SCAN_EXP=7: cycle / event counters of the scan kernels (diagnostics only)
+static u64* dbg_buffer() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("RMU_SCAN_EXP") && atoi(getenv("RMU_SCAN_EXP")) == 7) (void)hipMalloc((void**)&g_dbg, 128);
+    });
+    return g_dbg;
+}
+static void dbg_dump(const char* what, int64_t rows, hipStream_t s) {
+    u64 h[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[rmu dbg %s: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu\n",
+            what, (long long)rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    (void)hipMemset(g_dbg, 0, 128);
+}
+
+// row ranges of the threshold ladder over n rows (see the comment in screen_enqueue)
+static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb) {
+    static const int lvl_min = getenv("RMU_SCREEN_MINLVL") ? atoi(getenv("RMU_SCREEN_MINLVL")) : 256;
+    static const int lvl_ratio_env = getenv("RMU_SCREEN_RATIO") ? atoi(getenv("RMU_SCREEN_RATIO")) : 0;   // <= 1: single launch
+    // ratio 3 for full batches; small batches (one query tile, HBM-bound: 7.68 GB image per batch) have few appends to
+    // save and pay for every launch gap and merge, so they climb faster
+    const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
+    std::vector<int64_t> bounds{n};
+    if (lvl_ratio > 1 && n >= 262144) {
+        int64_t c = n / lvl_ratio / 32 * 32;
+        for (; c >= 65536 && bounds.size() < 24; c = c / lvl_ratio / 32 * 32) bounds.insert(bounds.begin(), c);
+        // below 64k rows a range is a handful of tiles per workgroup and its appends cost next to nothing: ratio 8, down
+        // to a first range so small (<= lvl_min rows) that its cold start -- every score is appended -- does not matter
+        for (c = bounds.front() / 8 / 32 * 32; c >= lvl_min && bounds.size() < 24; c = c / 8 / 32 * 32) bounds.insert(bounds.begin(), c);
+    }
+    return bounds;
+}
+
+// Enqueue the screening ladder for `nb` device queries (fp32, [nb, 384]): on return (stream order) t.ckeys holds the best
+// K' approximate candidates per query, sorted.  No host synchronisation.  scan_ms_events: record per-launch events.
+// Threshold ladder: the corpus is scanned in row ranges of geometrically growing size (256 rows, x8 up to 64k, then x3);
+// after each range its candidates are merged with the running top-K' and the K'-th best seeds the shared per-query
+// thresholds of the next launch.  A cold launch appends K' ln(rows/K') candidates per query and CHUNK, a seeded one only
+// K' (ratio - 1) per query in total, and every append stalls a whole workgroup for ~1-3k cycles: this cut
+// the filter overhead of the 10M x 1024 scan from 5.2 to ~1.5 ms.
+static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb, hipStream_t s, bool timed, int* n_launches,
+                          ScanLaunch* last_geom) {
+    const int kp = kScreenKp;
+    const int dpad = idx->dpad;
+    static const int share = getenv("RMU_NO_SHARED_THR") ? 0 : 1;
+    const std::vector<int64_t> bounds = ladder_bounds(idx->n, nb);
+    const int nl = (int)bounds.size();
+    std::vector<ScanLaunch> lv((size_t)nl);
+    int slots = nl - 1;
+    for (int l = 0; l < nl; ++l) {
+        ScanLaunch& S = lv[(size_t)l];
+        S = ScanLaunch{};
+        S.x = (const float*)idx->split; S.row0 = l ? bounds[(size_t)l - 1] : 0; S.n_rows = bounds[(size_t)l] - S.row0;
+        S.dpad = dpad; S.nq = (int)nb; S.k = kp;
+        if (rmu_screen_plan(&S) != RMU_OK) return fail(RMU_E_INVALID, "rmu_index_search: screening geometry");
+        slots += S.parts;
+    }
+    const size_t part_keys = (size_t)nb * kp;
+    const size_t gbytes = (size_t)((nb + 255) / 256 * 256 + 64) * sizeof(u32);
+    if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
+        t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.ensure_events(2 * nl))
+        return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
+    const int sflags = share | ((getenv("RMU_SCREEN_NOFILTER") != nullptr) ? 2 : 0);
+    HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
+    int rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
+    if (rc) return fail(rc, "rmu_index_search: query conversion");
+    u64* base = (u64*)t.partial.p;
+    int cursor = 0;     // slot index: [merged keys of the ranges so far][this range's parts] ...
+    for (int l = 0; l < nl; ++l) {
+        ScanLaunch& S = lv[(size_t)l];
+        const int first = cursor;               // slot of the running top-K' (l > 0), else of this range's first part
+        if (l > 0) cursor += 1;
+        S.partial = base + (size_t)cursor * part_keys;
+        S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = g_dbg; S.q = (const float*)t.qsplit.p;
+        if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l)], s));
+        rc = rmu_screen_launch(&S, s);
+        if (rc) return fail(rc, "rmu_index_search: screening launch");
+        if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l + 1)], s));
+        cursor += S.parts;
+        if (g_dbg) dbg_dump("screen range", S.n_rows, s);
+        u64* merged = l + 1 < nl ? base + (size_t)cursor * part_keys : (u64*)t.ckeys.p;
+        rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, kp, merged,
+                                      l + 1 < nl ? (u32*)t.gthr.p : nullptr /* merge + seed in one launch */, s);
+        if (rc) return fail(rc, "rmu_index_search: screening merge / threshold seeding");
+    }
+    *n_launches = nl;
+    if (last_geom) *last_geom = lv.back();
+    return RMU_OK;
+}
+
+static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
+    static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
+    // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays for the
+    // ladder's launches and merges per batch, which only pays off on a large enough corpus
+    const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || getenv("RMU_SCREEN_MIN_NQ");
+    return idx->split && idx->screen_enabled && idx->dpad == 384 && idx->dim == 384 && idx->metric != RMU_METRIC_L2SQ &&
+           nb >= screen_min_nq && screen_pays && k <= 24 && idx->n > 0 && idx->xnorm_max > 0.f &&
+           idx->xnorm_max < 500.f;   // fp16(64*x) must not overflow
+}
 
 extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, int k, unsigned flags, int64_t row_base,
                                 float* out_scores, int64_t* out_rows, uint64_t hip_stream) {
@@ -584,16 +747,21 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : t.stream;
     const bool q_dev = flags & RMU_F_Q_DEVICE, out_dev = flags & RMU_F_OUT_DEVICE;
     const bool timed = t.timing && !hip_stream;
+    (void)dbg_buffer();
 
     std::shared_lock<std::shared_mutex> lk(idx->mu);
     const int dpad = idx->dpad, dim = idx->dim;
+    const bool l2 = idx->metric == RMU_METRIC_L2SQ;     // dpad > dim by construction: queries are always copied and augmented
     t.scan_ms = -1.f; t.search_ms = -1.f; t.passes = 0; t.screened = 0;
     float scan_total = 0.f;
+    bool any_screened = false;
+    int rerun_total = 0;
     if (timed) HIP_TRY(hipEventRecord(t.ev[0], s));
+    if (!t.hflag && hipHostMalloc((void**)&t.hflag, sizeof(int)) != hipSuccess) return fail(RMU_E_OOM, "rmu_index_search: pinned flag");
 
     for (int64_t q0 = 0; q0 < nq; q0 += kMaxQueriesPerLaunch) {
         const int64_t nb = (nq - q0) < kMaxQueriesPerLaunch ? (nq - q0) : kMaxQueriesPerLaunch;
-        // ---- queries -> device, padded to dpad, normalised for COSINE -----------------------------
+        // ---- queries -> device, padded to dpad, normalised for COSINE, augmented for L2SQ -----------------------------
         const float* qsrc = q + q0 * dim;
         const float* qdev = qsrc;
         const bool need_copy = !q_dev || dpad != dim || idx->metric == RMU_METRIC_COSINE;
@@ -608,6 +776,12 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                                    (float*)nullptr);
                 HIP_TRY(hipGetLastError());
             }
+            if (l2) {
+                if (t.qn.ensure((size_t)nb * sizeof(float))) return fail(RMU_E_OOM, "rmu_index_search: |q|^2 workspace");
+                hipLaunchKernelGGL(k_l2_aug_queries, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, (float*)t.q.p, dpad, dim, nb,
+                                   (float*)t.qn.p);
+                HIP_TRY(hipGetLastError());
+            }
             qdev = (const float*)t.q.p;
         }
         float* d_s = out_scores + q0 * k;
@@ -618,171 +792,117 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             d_s = (float*)t.out_s.p;
             d_r = (int64_t*)t.out_r.p;
         }
-        static u64* g_dbg = nullptr;
-        if (getenv("RMU_SCAN_EXP") && atoi(getenv("RMU_SCAN_EXP")) == 7 && !g_dbg) { (void)hipMalloc((void**)&g_dbg, 128); }
-        if (g_dbg) (void)hipMemsetAsync(g_dbg, 0, 128, s);
         static const int share = getenv("RMU_NO_SHARED_THR") ? 0 : 1;
         bool exact_timed = false;
-        // ---- the exact fp32 fused scan + merge of `nqq` device queries into (os, orr) --------------------------------
-        auto exact_scan = [&](const float* qd, int64_t nqq, float* os, int64_t* orr) -> int {
-            ScanLaunch L{};
-            L.x = idx->x; L.n_rows = idx->n; L.dpad = dpad; L.q = qd; L.nq = (int)nqq; L.k = k; L.dbg = g_dbg;
-            int rc2 = rmu_scan_plan(&L);
+        // ---- the exact fp32 fused scan + merge of `nqq` device queries.  plan first (all workspace is sized before anything
+        // is enqueued: a grow-only buffer must not be re-allocated under work already in flight), then run.  `cond`
+        // (optional) makes both launches conditional on the device-side count of flagged queries; `scatter` redirects
+        // result row i to batch row scatter[i]. ------------------------------------------------------------------------
+        size_t need_partial = 0, need_gthr = 0;
+        auto plan_exact = [&](const float* qd, int64_t nqq, const RmuCond* cond, ScanLaunch* L) -> int {
+            *L = ScanLaunch{};
+            L->x = idx->x; L->n_rows = idx->n; L->dpad = dpad; L->q = qd; L->nq = (int)nqq; L->k = k; L->dbg = g_dbg;
+            if (cond) L->cond = *cond;
+            const int rc2 = rmu_scan_plan(L);
             if (rc2) return fail(rc2, "rmu_index_search: no scan geometry for this (dim, k)");
-            const size_t pbytes = (size_t)L.parts * nqq * k * sizeof(u64);
-            if (t.partial.ensure(pbytes)) return fail(RMU_E_OOM, "rmu_index_search: partial workspace");
-            L.partial = (u64*)t.partial.p;
+            need_partial = std::max(need_partial, (size_t)L->parts * nqq * k * sizeof(u64));
             // shared per-query thresholds: padded to whole 128-query tiles, zero = no bound yet
-            const size_t gbytes = (size_t)((nqq + 127) / 128 * 128 + 64) * sizeof(u32);
-            if (t.gthr.ensure(gbytes)) return fail(RMU_E_OOM, "rmu_index_search: threshold workspace");
-            HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
+            need_gthr = std::max(need_gthr, (size_t)((nqq + 127) / 128 * 128 + 64) * sizeof(u32));
+            return RMU_OK;
+        };
+        auto run_exact = [&](ScanLaunch& L, float* os, int64_t* orr, const int64_t* scatter, bool time_it) -> int {
+            const bool has_cond = L.cond.p != nullptr;
+            const size_t pbytes = (size_t)L.parts * L.nq * k * sizeof(u64);
+            const size_t gbytes = (size_t)((L.nq + 127) / 128 * 128 + 64) * sizeof(u32);
+            L.partial = (u64*)t.partial.p;
             L.gthr = (u32*)t.gthr.p;
             L.share_thr = share;
+            HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
+            int rc2;
             if (idx->n > 0) {
-                if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
+                if (time_it) HIP_TRY(hipEventRecord(t.ev[2], s));
                 rc2 = rmu_scan_launch(&L, s);
                 if (rc2) return fail(rc2, std::string("rmu_index_search: scan launch: ") + hipGetErrorString(hipGetLastError()));
-                if (timed) { HIP_TRY(hipEventRecord(t.ev[3], s)); exact_timed = true; }
-                t.grid = L.grid; t.block = 256; t.lds = L.lds_bytes; t.passes += 1;
+                if (time_it) { HIP_TRY(hipEventRecord(t.ev[3], s)); exact_timed = true; }
+                if (!has_cond) { t.grid = L.grid; t.block = 256; t.lds = L.lds_bytes; t.passes += 1; }
             } else {
                 HIP_TRY(hipMemsetAsync(L.partial, 0, pbytes, s));
             }
-            const int64_t skeys = (int64_t)32 * nqq * k;
-            u64* scratch = (L.parts >= 64 && nqq <= 1024 && !t.mscratch.ensure((size_t)skeys * sizeof(u64))) ? (u64*)t.mscratch.p : nullptr;
-            rc2 = rmu_merge_keys_launch2(L.partial, L.parts, nqq, k, row_base, 0, nullptr, os, orr, scratch, skeys, s);
+            rc2 = rmu_merge_final_launch(L.partial, L.parts, L.nq, k, row_base, l2 ? 1 : 0, l2 ? (const float*)t.qn.p : nullptr, os, orr,
+                                         scatter, has_cond ? &L.cond : nullptr, s);
             if (rc2) return fail(rc2, "rmu_index_search: merge launch");
+            if (g_dbg && !has_cond) dbg_dump("exact", idx->n, s);
             return RMU_OK;
         };
-        // ---- screened path: fp16 scan proposes K' = 32 candidates, exact fp32 re-score decides -------------------------
-        bool done = false;
-        static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
-        static const int lvl_min = getenv("RMU_SCREEN_MINLVL") ? atoi(getenv("RMU_SCREEN_MINLVL")) : 256;
-        static const int lvl_ratio_env = getenv("RMU_SCREEN_RATIO") ? atoi(getenv("RMU_SCREEN_RATIO")) : 0;   // <= 1: single launch
-        // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays ~0.35 ms of
-        // launches and merges per batch, which only pays off on a large enough corpus
-        const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || getenv("RMU_SCREEN_MIN_NQ");
-        if (idx->split && dpad == 384 && dim == 384 && nb >= screen_min_nq && screen_pays && k <= 24 && idx->n > 0 &&
-            idx->xnorm_max > 0.f && idx->xnorm_max < 500.f) {   // fp16(64*x) must not overflow
-            const int kp = 32;
-            // Threshold ladder: the corpus is scanned in row ranges of geometrically growing size (256 rows, x8 up to 64k,
-            // then x3); after each range its candidates are merged with the running top-K' and the K'-th best seeds the
-            // shared per-query thresholds of the next launch.  A cold launch appends K' ln(rows/K') candidates per query
-            // and CHUNK, a seeded one only K' (ratio - 1) per query in total, and every append stalls a whole workgroup
-            // for ~1-3k cycles: this cut the filter overhead of the 10M x 1024 scan from 5.2 to ~1.5 ms.
-            // ratio 3 for full batches; small batches (one query tile, HBM-bound: 7.68 GB image per batch) have few appends to
-            // save and pay for every launch gap and merge, so they climb faster
-            const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
-            std::vector<int64_t> bounds{idx->n};
-            if (lvl_ratio > 1 && idx->n >= 262144) {
-                int64_t c = idx->n / lvl_ratio / 32 * 32;
-                for (; c >= 65536 && bounds.size() < 24; c = c / lvl_ratio / 32 * 32) bounds.insert(bounds.begin(), c);
-                // below 64k rows a range is a handful of tiles per workgroup and its appends cost next to nothing: ratio 8, down
-                // to a first range so small (<= lvl_min rows) that its cold start -- every score is appended -- does not matter
-                for (c = bounds.front() / 8 / 32 * 32; c >= lvl_min && bounds.size() < 24; c = c / 8 / 32 * 32) bounds.insert(bounds.begin(), c);
-            }
-            const int nl = (int)bounds.size();
-            std::vector<ScanLaunch> lv((size_t)nl);
-            int slots = nl - 1;
-            bool plan_ok = true;
-            for (int l = 0; l < nl && plan_ok; ++l) {
-                ScanLaunch& S = lv[(size_t)l];
-                S = ScanLaunch{};
-                S.x = (const float*)idx->split; S.row0 = l ? bounds[(size_t)l - 1] : 0; S.n_rows = bounds[(size_t)l] - S.row0;
-                S.dpad = dpad; S.nq = (int)nb; S.k = kp;
-                plan_ok = rmu_screen_plan(&S) == RMU_OK;
-                slots += S.parts;
-            }
-            if (plan_ok) {
-                const size_t part_keys = (size_t)nb * kp;
-                const size_t gbytes = (size_t)((nb + 255) / 256 * 256 + 64) * sizeof(u32);
-                if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
-                    t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.flag.ensure((size_t)(nb + 1) * sizeof(int)) ||
-                    t.ensure_events(2 * nl))
-                    return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
-                const int sflags = share | ((getenv("RMU_SCREEN_NOFILTER") != nullptr) ? 2 : 0);
-                HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
-                HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
-                rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
-                if (rc) return fail(rc, "rmu_index_search: query conversion");
-                // small batches: two-level merges (17 groups of 16 parts per query) need [groups, nb, K'] keys of scratch
-                const int64_t mscratch_keys = nb <= 256 ? (int64_t)20 * nb * kp : 0;
-                if (mscratch_keys && t.mscratch.ensure((size_t)mscratch_keys * sizeof(u64))) return fail(RMU_E_OOM, "rmu_index_search: merge scratch");
-                u64* base = (u64*)t.partial.p;
-                int cursor = 0;     // slot index: [merged keys of the ranges so far][this range's parts] ...
-                for (int l = 0; l < nl; ++l) {
-                    ScanLaunch& S = lv[(size_t)l];
-                    const int first = cursor;               // slot of the running top-K' (l > 0), else of this range's first part
-                    if (l > 0) cursor += 1;
-                    S.partial = base + (size_t)cursor * part_keys;
-                    S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = g_dbg; S.q = (const float*)t.qsplit.p;
-                    if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l)], s));
-                    rc = rmu_screen_launch(&S, s);
-                    if (rc) return fail(rc, "rmu_index_search: screening launch");
-                    if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l + 1)], s));
-                    cursor += S.parts;
-                    if (g_dbg) { u64 h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg range %d: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu\n", l, (long long)S.n_rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); (void)hipMemset(g_dbg, 0, 128); }
-                    u64* merged = l + 1 < nl ? base + (size_t)cursor * part_keys : (u64*)t.ckeys.p;
-                    rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, kp, merged,
-                                                  l + 1 < nl ? (u32*)t.gthr.p : nullptr,          // merge + seed in one launch
-                                                  (u64*)t.mscratch.p, mscratch_keys, s);
-                    if (rc) return fail(rc, "rmu_index_search: screening merge / threshold seeding");
-                }
-                // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip)
-                rc = rmu_rescore_launch((const u64*)t.ckeys.p, kp, idx->x, qdev, nb, k, idx->xnorm_max, idx->dx_max, row_base, d_s, d_r,
-                                        (int*)t.flag.p, s);
-                if (rc) return fail(rc, "rmu_index_search: re-score launch");
-                int hflag = 0;
-                HIP_TRY(hipMemcpyAsync(&hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                t.grid = lv.back().grid; t.block = 256; t.lds = lv.back().lds_bytes; t.passes += nl;
-                t.screened = hflag == 0 ? 1 : -hflag;   // >0: answered by the screen; <0: that many queries were re-run exactly
-                if (timed)
-                    for (int l = 0; l < nl; ++l) {
-                        float ms = 0.f;
-                        if (hipEventElapsedTime(&ms, t.lev[(size_t)(2 * l)], t.lev[(size_t)(2 * l + 1)]) == hipSuccess) scan_total += ms;
-                    }
-                done = hflag == 0;
-                if (!done && hflag <= nb / 8) {
-                    // few queries failed the sufficiency test: re-run only those on the exact scan and patch their rows in
-                    std::vector<int> hf((size_t)nb);
-                    HIP_TRY(hipMemcpy(hf.data(), (const int*)t.flag.p + 1, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost));
-                    std::vector<int64_t> pos;
-                    for (int64_t i = 0; i < nb; ++i) if (hf[(size_t)i]) pos.push_back(i);
-                    const int64_t nf = (int64_t)pos.size();
-                    if (t.fb_i.ensure((size_t)nf * sizeof(int64_t)) || t.fbq.ensure((size_t)nf * dpad * sizeof(float)) ||
-                        t.fb_s.ensure((size_t)nf * k * sizeof(float)) || t.fb_r.ensure((size_t)nf * k * sizeof(int64_t)))
-                        return fail(RMU_E_OOM, "rmu_index_search: re-run workspace");
-                    HIP_TRY(hipMemcpyAsync(t.fb_i.p, pos.data(), (size_t)nf * sizeof(int64_t), hipMemcpyHostToDevice, s));
-                    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)nf), dim3(128), 0, s, qdev, dpad, dpad, (const int64_t*)t.fb_i.p, nf,
-                                       (float*)t.fbq.p);
-                    HIP_TRY(hipGetLastError());
-                    rc = exact_scan((const float*)t.fbq.p, nf, (float*)t.fb_s.p, (int64_t*)t.fb_r.p);
-                    if (rc) return rc;
-                    hipLaunchKernelGGL(k_scatter_results, dim3((unsigned)nf), dim3(128), 0, s, (const float*)t.fb_s.p,
-                                       (const int64_t*)t.fb_r.p, (const int64_t*)t.fb_i.p, nf, k, d_s, d_r);
-                    HIP_TRY(hipGetLastError());
-                    HIP_TRY(hipStreamSynchronize(s));   // pos[] (host) and the fb_* buffers are reused by the next block
-                    done = true;
-                }
-            }
-        }
-        if (!done) {
-            rc = exact_scan(qdev, nb, d_s, d_r);
+        const bool screened = screen_applies(idx, nb, k);
+        if (screened) {
+            // ---- screened path: fp16 scan proposes K' = 32 candidates, exact fp32 re-score decides --------------------------
+            // Flagged queries -> exact scan, decided ON THE DEVICE: three mutually exclusive conditional launches
+            //   1..32 flagged: the 32-query HBM-bound geometry; 33..nb/8: a batch of nb/8; more: the whole batch.
+            // With nothing flagged (the normal case) each costs one empty grid (~2 us); no host round trip either way, so
+            // the whole search is asynchronous on the stream it was given.
+            const int small_n = (int)(nb < 32 ? nb : 32), mid_n = (int)(nb / 8);
+            const int gather_n = mid_n > small_n ? mid_n : small_n;
+            const int lim_small = mid_n > small_n ? small_n : mid_n;    // no mid launch: the small one covers 1..nb/8
+            if (t.flag.ensure(2 * sizeof(int)) || t.fb_i.ensure((size_t)nb * sizeof(int64_t)) ||
+                t.fbq.ensure((size_t)gather_n * dpad * sizeof(float)))
+                return fail(RMU_E_OOM, "rmu_index_search: re-run workspace");
+            const int* cnt = (const int*)t.flag.p;
+            const RmuCond c1{cnt, 1, lim_small, 1}, c2{cnt, small_n + 1, mid_n, 1}, c3{cnt, mid_n + 1, 0x7fffffff, 0};
+            ScanLaunch L1{}, L2{}, L3{};
+            if (lim_small > 0 && (rc = plan_exact((const float*)t.fbq.p, small_n, &c1, &L1))) return rc;
+            if (mid_n > small_n && (rc = plan_exact((const float*)t.fbq.p, mid_n, &c2, &L2))) return rc;
+            if ((rc = plan_exact(qdev, nb, &c3, &L3))) return rc;
+            if (t.partial.ensure(need_partial) || t.gthr.ensure(need_gthr)) return fail(RMU_E_OOM, "rmu_index_search: re-run partials");
+            int nl = 0;
+            ScanLaunch lastg{};
+            HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
+            rc = screen_enqueue(idx, t, qdev, nb, s, timed, &nl, &lastg);
             if (rc) return rc;
+            // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip); queries failing the
+            // sufficiency test are appended to the list fb_i (count in flag[0])
+            rc = rmu_rescore_launch((const u64*)t.ckeys.p, kScreenKp, idx->x, qdev, nb, k, idx->xnorm_max, idx->dx_max, row_base, d_s, d_r,
+                                    (int*)t.flag.p, (int64_t*)t.fb_i.p, nullptr, s);
+            if (rc) return fail(rc, "rmu_index_search: re-score launch");
+            t.grid = lastg.grid; t.block = 256; t.lds = lastg.lds_bytes; t.passes += nl;
+            hipLaunchKernelGGL(k_gather_flagged, dim3((unsigned)gather_n), dim3(128), 0, s, qdev, dpad, (const int64_t*)t.fb_i.p, cnt,
+                               (float*)t.fbq.p);
+            HIP_TRY(hipGetLastError());
+            if (lim_small > 0 && (rc = run_exact(L1, d_s, d_r, (const int64_t*)t.fb_i.p, false))) return rc;
+            if (mid_n > small_n && (rc = run_exact(L2, d_s, d_r, (const int64_t*)t.fb_i.p, false))) return rc;
+            if ((rc = run_exact(L3, d_s, d_r, nullptr, false))) return rc;
+            HIP_TRY(hipMemcpyAsync(t.hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            if (timed)
+                for (int l = 0; l < nl; ++l) {
+                    HIP_TRY(hipEventSynchronize(t.lev[(size_t)(2 * l + 1)]));
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, t.lev[(size_t)(2 * l)], t.lev[(size_t)(2 * l + 1)]) == hipSuccess) scan_total += ms;
+                }
+        } else {
+            ScanLaunch L{};
+            if ((rc = plan_exact(qdev, nb, nullptr, &L))) return rc;
+            if (t.partial.ensure(need_partial) || t.gthr.ensure(need_gthr)) return fail(RMU_E_OOM, "rmu_index_search: partial workspace");
+            if ((rc = run_exact(L, d_s, d_r, nullptr, timed))) return rc;
         }
         if (!out_dev) {
             HIP_TRY(hipMemcpyAsync(out_scores + q0 * k, d_s, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_rows + q0 * k, d_r, (size_t)nb * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         }
-        // workspace is reused by the next query block (and host outputs must land): drain per block
-        if (!hip_stream || q0 + nb < nq || !out_dev) HIP_TRY(hipStreamSynchronize(s));
-        if (g_dbg) { u64 h[16]; (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost); fprintf(stderr, "[rmu dbg] slow_tiles=%llu compactions=%llu appends=%llu tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]); }
+        // workspace is reused by the next query block (and host outputs must land): drain per block.  With a caller stream,
+        // device outputs and a single block nothing here waits: the work is merely ordered on that stream.
+        const bool drained = !hip_stream || q0 + nb < nq || !out_dev;
+        if (drained) HIP_TRY(hipStreamSynchronize(s));
+        if (screened) {   // the count of re-run queries is unknown while a caller's stream still runs: reported as 0 then
+            any_screened = true;
+            if (drained) rerun_total += *t.hflag;
+        }
         if (exact_timed) {
             HIP_TRY(hipEventSynchronize(t.ev[3]));
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, t.ev[2], t.ev[3]) == hipSuccess) scan_total += ms;
         }
     }
+    t.screened = any_screened ? (rerun_total ? -rerun_total : 1) : 0;
     if (timed) {
         HIP_TRY(hipEventRecord(t.ev[1], s));
         HIP_TRY(hipEventSynchronize(t.ev[1]));
@@ -790,6 +910,69 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         if (hipEventElapsedTime(&ms, t.ev[0], t.ev[1]) == hipSuccess) t.search_ms = ms;
         t.scan_ms = scan_total;
     }
+    return RMU_OK;
+}
+
+// Test hook (not a product entry point): the screening pass's candidate set for each query -- approximate scores s~,
+// row ids, and the per-query error bound EPS(q) the sufficiency test uses -- so the bound |s~ - s_fp32| <= EPS can be
+// checked ON THE HARDWARE against fp32 scores computed independently (tests/test_search_gpu.py).
+extern "C" int rmu_index_screen_candidates(rmu_index_t* idx, const float* q_host, int64_t nq, float* out_approx, int64_t* out_rows,
+                                           float* out_exact, float* out_eps) {
+    if (!idx || !q_host || !out_approx || !out_rows || !out_exact || !out_eps) return fail(RMU_E_INVALID, "rmu_index_screen_candidates: null pointer");
+    if (nq < 1 || nq > kMaxQueriesPerLaunch) return fail(RMU_E_INVALID, "rmu_index_screen_candidates: 1 <= nq <= 8192");
+    Tls& t = g_tls;
+    int rc = t.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_screen_candidates: stream");
+    hipStream_t s = t.stream;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    if (!idx->split || idx->dim != 384 || idx->n <= 0) return fail(RMU_E_INVALID, "rmu_index_screen_candidates: index has no screening image");
+    const int kp = kScreenKp;
+    if (t.q.ensure((size_t)nq * 384 * sizeof(float)) || t.flag.ensure((size_t)(nq + 1) * sizeof(int)) || t.fb_i.ensure((size_t)nq * sizeof(int64_t)) ||
+        t.out_s.ensure((size_t)nq * kp * sizeof(float)) || t.out_r.ensure((size_t)nq * kp * sizeof(int64_t)) || t.nrm.ensure((size_t)nq * sizeof(float)))
+        return fail(RMU_E_OOM, "rmu_index_screen_candidates: workspace");
+    HIP_TRY(hipMemcpyAsync(t.q.p, q_host, (size_t)nq * 384 * sizeof(float), hipMemcpyHostToDevice, s));
+    if (idx->metric == RMU_METRIC_COSINE) hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, (float*)t.q.p, 384, nq, 1, (float*)nullptr);
+    HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
+    int nl = 0;
+    rc = screen_enqueue(idx, t, (const float*)t.q.p, nq, s, false, &nl, nullptr);
+    if (rc) return rc;
+    // k = K': the re-score kernel writes the exact fp32 score of EVERY candidate (rank order) and EPS(q)
+    rc = rmu_rescore_launch((const u64*)t.ckeys.p, kp, idx->x, (const float*)t.q.p, nq, kp, idx->xnorm_max, idx->dx_max, 0, (float*)t.out_s.p,
+                            (int64_t*)t.out_r.p, (int*)t.flag.p, (int64_t*)t.fb_i.p, (float*)t.nrm.p, s);
+    if (rc) return fail(rc, "rmu_index_screen_candidates: re-score");
+    std::vector<u64> keys((size_t)nq * kp);
+    std::vector<float> ex((size_t)nq * kp);
+    std::vector<int64_t> er((size_t)nq * kp);
+    HIP_TRY(hipMemcpyAsync(keys.data(), t.ckeys.p, keys.size() * sizeof(u64), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ex.data(), t.out_s.p, ex.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(er.data(), t.out_r.p, er.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_eps, t.nrm.p, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < nq; ++i)
+        for (int c = 0; c < kp; ++c) {
+            const u64 key = keys[(size_t)(i * kp + c)];
+            out_approx[i * kp + c] = key ? rmu_key_score(key) : -INFINITY;
+            out_rows[i * kp + c] = key ? (int64_t)rmu_key_row(key) : -1;
+            // exact fp32 score of that same row: look it up in the re-scored (exact-rank-ordered) list
+            float e = -INFINITY;
+            for (int c2 = 0; c2 < kp && key; ++c2)
+                if (er[(size_t)(i * kp + c2)] == (int64_t)rmu_key_row(key)) { e = ex[(size_t)(i * kp + c2)]; break; }
+            out_exact[i * kp + c] = e;
+        }
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_set_option(rmu_index_t* idx, int option, int64_t value) {
+    if (!idx) return fail(RMU_E_INVALID, "rmu_index_set_option: null index");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    switch (option) {
+        case RMU_OPT_SCREEN: idx->screen_enabled = value != 0; return RMU_OK;
+        default: return fail(RMU_E_INVALID, "rmu_index_set_option: unknown option");
+    }
+}
+extern "C" int rmu_index_metric(rmu_index_t* idx, int* metric) {
+    if (!idx || !metric) return fail(RMU_E_INVALID, "rmu_index_metric: null");
+    *metric = idx->metric;
     return RMU_OK;
 }
 
@@ -821,7 +1004,7 @@ extern "C" int rmu_topk_merge(const float* scores, const int64_t* rows, int part
         os = (float*)t.out_s.p;
         orr = (int64_t*)t.out_r.p;
     }
-    rc = rmu_merge_lists_launch(ds, dr, parts, nq, k, os, orr, nullptr, s);
+    rc = rmu_merge_lists_launch(ds, dr, parts, nq * k, nq * k, nq, k, (flags & RMU_F_SMALLER_BETTER) ? 1 : 0, os, orr, s);
     if (rc) return fail(rc, "rmu_topk_merge: launch");
     if (!out_dev) {
         HIP_TRY(hipMemcpyAsync(out_scores, os, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -91,6 +91,16 @@ __device__ __forceinline__ void rmu_bitonic_merge_desc(u64 (&key)[NPL], int lane
 }
 
 // ---- launch descriptors shared between rmu_api.hip and the kernel translation units -------------
+// Device-side launch predicate.  The screening path decides per query ON THE DEVICE whether the exact scan has to re-run
+// it; the re-run launches are enqueued unconditionally and every workgroup of a launch whose predicate is false returns
+// at once, so a search never needs a host round trip (and honours a caller-supplied stream).
+//   p == null: always run.  Otherwise c = *p (number of flagged queries): run iff lo <= c <= hi; clamp != 0: only the first
+//   min(nq, c) queries of the launch exist.
+struct RmuCond {
+    const int* p;
+    int lo, hi, clamp;
+};
+
 struct ScanLaunch {
     const float* x;        // [n_rows, dpad] fp32 row-major, HBM resident
     int64_t n_rows;
@@ -107,18 +117,17 @@ struct ScanLaunch {
     // filled by rmu_scan_plan
     int wq, kv, s_chunks, nqt, tiles_per_chunk, grid, lds_bytes;
     int qg;                // screening scan only: 32-query groups per wave (rmu_screen_plan)
+    int nt;                // 1 = stream the corpus with non-temporal loads (every byte is read by exactly one workgroup)
+    RmuCond cond;          // exact scan only: device-side launch predicate (zero-initialised = always)
 };
 
 int rmu_scan_plan(ScanLaunch* p);                        // chooses geometry; returns 0 or RMU_E_INVALID
 int rmu_scan_launch(const ScanLaunch* p, hipStream_t s); // launches the fused scan
-int rmu_merge_keys_launch(const u64* partial, int parts, int64_t nq, int k, int64_t row_base,
-                          int l2_out, const float* qnorm2, float* out_scores, int64_t* out_rows,
-                          hipStream_t s);
-int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out,
-                           const float* qnorm2, float* out_scores, int64_t* out_rows, u64* scratch, int64_t scratch_keys,
+int rmu_merge_final_launch(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out, const float* qnorm2,
+                           float* out_scores, int64_t* out_rows, const int64_t* scatter /* or null */, const RmuCond* cond /* or null */,
                            hipStream_t s);
 int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr /* or null */,
-                             u64* scratch /* or null */, int64_t scratch_keys, hipStream_t s);
+                             hipStream_t s);
 // fp16 screening path (scan_screen.hip)
 #define RMU_IMG_ROW_BYTES 768                          /* fp16(64 x) image of a 384-d row */
 int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> fp16 image
@@ -127,6 +136,9 @@ int rmu_screen_lds_bytes(int qg);
 int rmu_screen_plan(ScanLaunch* p);                      // geometry of one screening launch (k = K' <= 32)
 int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s);       // |x - image|^2 per row
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
-                       int64_t row_base, float* out_s, int64_t* out_r, int* flagged, hipStream_t s);
-int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
-                           float* out_scores, int64_t* out_rows, u64* scratch_keys, hipStream_t s);
+                       int64_t row_base, float* out_s, int64_t* out_r, int* flagged /* [0] = count */, int64_t* flagged_list,
+                       float* eps_out /* or null */, hipStream_t s);
+// shard lists [parts][nq, k]: part p's scores start at scores + p * stride_s (floats), rows at rows + p * stride_r (int64);
+// smaller_better: distances (RMU_METRIC_L2SQ) instead of similarities
+int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t stride_s, int64_t stride_r, int64_t nq, int k,
+                           int smaller_better, float* out_scores, int64_t* out_rows, hipStream_t s);

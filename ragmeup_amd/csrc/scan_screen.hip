@@ -22,6 +22,7 @@
 // (An earlier hi/lo split variant, 3 MFMAs per 16 k with EPS = 1e-4, ran at 25 ms for the 10M x 1024 headline; its
 // ablations showed the LDS/L2 path, not the MFMA pipe, setting the time, which is what halving the bytes attacks.)
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "rmu_common.h"
 #include "scan_common.h"
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, in
 
 // EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads, bit 3 no filter VALU; bit 2 = debug counters
 // S_PRE = A-fragment prefetch depth in steps
-template <int G, int EXP = 0, int S_PRE = 4, int NRV = 0>
+template <int G, int EXP = 0, int S_PRE = 4, int NRV = 0, int NT = 0>
 __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     using C = ScreenCfg<G, NRV>;
     constexpr bool DBG = (EXP & 4) != 0;   // cycle / event counters into a.dbg (RMU_SCAN_EXP=7)
@@ -177,8 +178,12 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
         if (ce >= nchunks) ce = nchunks - 1;
         const char* sbase = img + ((t0 + (ce >> 1)) * S_RT) * (int64_t)IMGB + (ce & 1) * S_CKB;
         char* slot = ring + (cc % C::NR) * S_SLOT;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
-                                         (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
+        if (NT)       // literal aux operands only (see scan_topk.hip)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
+                                             (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
+                                             (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
     };
     auto issue_chunk = [&](int cc) {
 #pragma unroll
@@ -438,7 +443,9 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
 __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, int kp, const float* __restrict__ x,
                                                  const float* __restrict__ q, int64_t nq, int k, float xnorm_max, float dx_max,
                                                  int64_t row_base, float* __restrict__ out_s, int64_t* __restrict__ out_r,
-                                                 int* __restrict__ flagged /* [0] = count, [1 + q] = 1 if query q failed */) {
+                                                 int* __restrict__ flagged /* [0] = number of queries that failed the test */,
+                                                 int64_t* __restrict__ flagged_list /* their indices, in arrival order */,
+                                                 float* __restrict__ eps_out /* optional [nq]: EPS(q) */) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
@@ -471,10 +478,12 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
     const float qn = sqrtf(qn2) * 1.0001f, dq = sqrtf(dq2) * 1.0001f;
     const float eps = dx_max * qn + xnorm_max * dq + dx_max * dq + 5.0e-5f * xnorm_max * qn;   // see the header
     const bool complete = nvalid < kp;                           // every live row was a candidate
-    const bool ok = complete || (smin < tau - 2.0f * eps);
+    // eps must be finite: a query with |q_i| >= ~1000 overflows fp16(64 q), its approximate scores are inf/NaN and rows
+    // scoring NaN are never appended (so even `complete` proves nothing) -- such a query always goes to the exact scan
+    const bool ok = __builtin_isfinite(eps) && (complete || (smin < tau - 2.0f * eps));
     if (lane == 0) {
-        flagged[1 + qi] = ok ? 0 : 1;
-        if (!ok) atomicAdd(flagged, 1);
+        if (!ok) flagged_list[atomicAdd(flagged, 1)] = qi;
+        if (eps_out) eps_out[qi] = eps;
     }
     u64 key[1];
     u32 rank[1];
@@ -500,17 +509,14 @@ int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s)
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-template <int G, int EXP = 0, int PRE = 4, int NRV = 0>
+template <int G, int EXP = 0, int PRE = 4, int NRV = 0, int NT = 0>
 static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)scan_screen_kernel<G, EXP, PRE, NRV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                ScreenCfg<G, NRV>::LDS_BYTES) != hipSuccess)
-            return RMU_E_HIP;
-        attr = true;
-    }
+    // function-local static: initialised exactly once, thread-safe (C++11)
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_kernel<G, EXP, PRE, NRV, NT>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, ScreenCfg<G, NRV>::LDS_BYTES);
+    if (attr_rc != hipSuccess) return RMU_E_HIP;
     constexpr int lds = ScreenCfg<G, NRV>::LDS_BYTES;
-    hipLaunchKernelGGL((scan_screen_kernel<G, EXP, PRE, NRV>), dim3(p->grid), dim3(256), lds, s, *p);
+    hipLaunchKernelGGL((scan_screen_kernel<G, EXP, PRE, NRV, NT>), dim3(p->grid), dim3(256), lds, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
@@ -543,6 +549,8 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->s_chunks = s;
     p->grid = s * p->nqt;
     p->parts = s;
+    static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
+    p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
     p->lds_bytes = rmu_screen_lds_bytes(p->qg);
     return RMU_OK;
 }
@@ -572,7 +580,7 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
         if (pre == 3) return screen_launch_cfg<2, 0, 3>(p, s);
         return screen_launch_cfg<2>(p, s);
     }
-    return screen_launch_cfg<1>(p, s);
+    return p->nt ? screen_launch_cfg<1, 0, 4, 0, 1>(p, s) : screen_launch_cfg<1>(p, s);
 }
 
 int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s) {
@@ -582,9 +590,9 @@ int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t 
 }
 
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
-                       int64_t row_base, float* out_s, int64_t* out_r, int* flagged, hipStream_t s) {
+                       int64_t row_base, float* out_s, int64_t* out_r, int* flagged, int64_t* flagged_list, float* eps_out, hipStream_t s) {
     if (kp < k || kp > 64) return RMU_E_INVALID;
     hipLaunchKernelGGL(k_rescore, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
-                       out_s, out_r, flagged);
+                       out_s, out_r, flagged, flagged_list, eps_out);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }

@@ -27,14 +27,16 @@
 // 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte bank slots.  LDS-DMA writes
 // lane-linear, so the swizzle is applied to the per-lane GLOBAL source address (guide rule 21).
 #include <cstdlib>
+#include <mutex>
 #include "rmu_common.h"
 #include "scan_common.h"
 #include "../../include/rmu.h"
 
 namespace {
 
-template <int D_, int WQ_, int CKF_, int RING_, int CAP_, int NCHECK_, int EXP_ = 0, int LA_ = 1>
+template <int D_, int WQ_, int CKF_, int RING_, int CAP_, int NCHECK_, int EXP_ = 0, int LA_ = 1, int NT_ = 0>
 struct Cfg {
+    static constexpr bool NT = NT_ != 0;       // LDS-DMA cache policy of the corpus stream: nt (aux = 2) for read-once data
     static constexpr bool LA_ON = LA_ != 0;    // one-chunk look-ahead (costs one ring slot of in-flight data)
     static constexpr int EXP = EXP_;        // 0 = product; 1..3 = timing ablations (wrong results)
     static constexpr int D = D_;            // padded row length (floats)
@@ -71,6 +73,13 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 
 template <class C>
 __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
+    // device-side launch predicate (conditional re-runs behind the screening path): uniform over the grid
+    int nq_eff = a.nq;
+    if (a.cond.p) {
+        const int c = *a.cond.p;
+        if (c < a.cond.lo || c > a.cond.hi) return;
+        if (a.cond.clamp && c < nq_eff) nq_eff = c;
+    }
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = w % C::WQ;   // query group of this wave
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
     float* thr_w = (float*)(smem + C::RING_BYTES + C::CAND_BYTES + 4 * 32 * 4) + w * 32;
 
     const int q_idx = (qt * C::WQ + g) * 32 + j;
-    const bool q_ok = q_idx < a.nq;
+    const bool q_ok = q_idx < nq_eff;
     ((u32*)(smem + C::GT_OFF))[w * 64 + lane] = 0u;   // landing zone of the shared thresholds: 0 = no bound
     if (lane < 32) {
         cnt_w[lane] = 0;
@@ -146,9 +155,13 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
         char* slot = ring + (cc % C::RING) * C::SLOT_BYTES;
 #pragma unroll
         for (int n = 0; n < C::NI; ++n) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
-                                             (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024),
-                                             16, 0, 0);
+            // (the aux operand must be a literal: a dependent constant here silently drops the kernel's host-side handle)
+            if (C::NT)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
+                                                 (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
+                                                 (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
         }
     };
 
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
     const int part = s_idx * C::RP + rp;
     for (int jj = 0; jj < 32; ++jj) {
         const int qq = (qt * C::WQ + g) * 32 + jj;
-        if (qq >= a.nq) break;
+        if (qq >= nq_eff) break;
         const u32 n = cnt_w[jj];
         u64 key[C::NPL];
         u32 rank[C::NPL];
@@ -410,13 +423,10 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
 
 template <class C>
 int launch_cfg(const ScanLaunch* p, hipStream_t s) {
-    static bool attr_done = false;   // benign race: idempotent
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)scan_topk_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS_BYTES) != hipSuccess)
-            return RMU_E_HIP;
-        attr_done = true;
-    }
+    // function-local static: initialised exactly once, thread-safe (C++11)
+    static const hipError_t attr_rc =
+        hipFuncSetAttribute((const void*)scan_topk_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (attr_rc != hipSuccess) return RMU_E_HIP;
     hipLaunchKernelGGL(scan_topk_kernel<C>, dim3(p->grid), dim3(256), C::LDS_BYTES, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
@@ -428,6 +438,9 @@ template <int D> using C_w4_k1 = Cfg<D, 4, 96, 2, 128, 2>;   // 24 KiB ring + 12
 template <int D> using C_w2_k0 = Cfg<D, 2, 96, 3, 64, 1, 0, 0>;   // 72 KiB ring, no look-ahead (2 chunks in flight)
 template <int D> using C_w2_k1 = Cfg<D, 2, 48, 2, 128, 2>;   // 24 KiB ring
 template <int D> using C_w1_k0 = Cfg<D, 1, 48, 3, 64, 1, 0, 0>;   // 72 KiB ring; HBM-bound: no look-ahead -> 2 chunks in flight (5.0 -> 5.8 TB/s)
+// one query tile (<= 64 queries): every corpus byte is read by exactly one workgroup -> non-temporal stream
+template <int D> using C_w2_k0_nt = Cfg<D, 2, 96, 3, 64, 1, 0, 0, 1>;
+template <int D> using C_w1_k0_nt = Cfg<D, 1, 48, 3, 64, 1, 0, 0, 1>;
 
 template <int D>
 int launch_d(const ScanLaunch* p, hipStream_t s) {
@@ -444,9 +457,9 @@ int launch_d(const ScanLaunch* p, hipStream_t s) {
             return launch_cfg<C_w4_k0<D>>(p, s);
         }
         case 9: return launch_cfg<C_w4_k1<D>>(p, s);
-        case 4: return launch_cfg<C_w2_k0<D>>(p, s);
+        case 4: return p->nt ? launch_cfg<C_w2_k0_nt<D>>(p, s) : launch_cfg<C_w2_k0<D>>(p, s);
         case 5: return launch_cfg<C_w2_k1<D>>(p, s);
-        case 2: return launch_cfg<C_w1_k0<D>>(p, s);
+        case 2: return p->nt ? launch_cfg<C_w1_k0_nt<D>>(p, s) : launch_cfg<C_w1_k0<D>>(p, s);
         default: return RMU_E_INVALID;
     }
 }
@@ -493,6 +506,8 @@ int rmu_scan_plan(ScanLaunch* p) {
     p->s_chunks = s;
     p->grid = s * p->nqt;
     p->parts = s * (4 / p->wq);
+    static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
+    p->nt = (nt_env && p->nqt == 1 && p->kv == 0 && p->wq <= 2) ? 1 : 0;
     p->lds_bytes = p->dpad == 384 ? lds_d<384>(p->wq, p->kv)
                  : p->dpad == 768 ? lds_d<768>(p->wq, p->kv) : lds_d<192>(p->wq, p->kv);
     return p->lds_bytes > 0 ? RMU_OK : RMU_E_INVALID;

@@ -55,74 +55,126 @@ __device__ __forceinline__ void merge_stream_slabs(u64 (&top)[NPL], int np, int 
     }
 }
 
-// level-1 of the two-level merge: wave (q, g) folds parts [g*ppg, (g+1)*ppg) into k keys -> scratch[g][q][k]
-template <int NPL>
-__global__ __launch_bounds__(256) void merge_keys_partial_kernel(const u64* __restrict__ partial, int parts, int64_t nq,
-                                                                 int k, int groups, int ppg, u64* __restrict__ scratch,
-                                                                 u32* __restrict__ seed_thr /* optional: [nq] <- max(k-th best) */) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= nq * groups) return;
-    const int64_t q = wid / groups;
-    const int g = (int)(wid % groups);
-    const int p0 = g * ppg;
-    const int np = min(ppg, parts - p0);
-    u64 top[NPL];
-    merge_stream_slabs<NPL>(top, np > 0 ? np : 0, k, lane, [&](int part, int pos) {
-        return partial[((int64_t)(p0 + part) * nq + q) * k + pos];
-    });
+// Software-pipelined form of merge_stream_slabs: the load of the next 64-entry batch is in flight while the current one
+// is sorted and folded, so a wave pays one memory latency per merge instead of one per batch.
+template <int NPL, class LoadKey>
+__device__ __forceinline__ void merge_stream_slabs_pf(u64 (&top)[NPL], int np, int k, int lane, LoadKey load /* (part, pos) */) {
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-        const int e = lane + 64 * p;
-        if (e < k) scratch[((int64_t)g * nq + q) * k + e] = top[p];
-        // screening ladder: the merged K'-th best is a lower bound of the final K'-th best -> next launch's shared threshold
-        if (seed_thr && e == k - 1 && top[p]) atomicMax(seed_thr + q, (u32)(top[p] >> 32));
+    for (int p = 0; p < NPL; ++p) top[p] = 0ull;
+    const int m = np * 4;
+    if (m <= 0) return;
+    auto ld = [&](int s0, int b0) -> u64 {
+        const int i = b0 + lane;
+        const int pos = s0 + (i & 3);
+        return (s0 < k && i < m && pos < k) ? load(i >> 2, pos) : 0ull;
+    };
+    int s0 = 0, b0 = 0;
+    u64 cur = ld(0, 0);
+    bool any = false;
+    while (s0 < k) {
+        int ns0 = s0, nb0 = b0 + 64;
+        if (nb0 >= m) { nb0 = 0; ns0 = s0 + 4; }
+        const u64 nxt = ld(ns0, nb0);
+        if (__any(cur != 0ull)) {
+            any = true;
+            u64 bk[1] = {cur};
+            rmu_bitonic_sort_desc<1>(bk, lane);
+            const u64 rev = __shfl(bk[0], 63 - lane);
+            u64& tail = top[NPL - 1];
+            tail = tail > rev ? tail : rev;
+            rmu_bitonic_merge_desc<NPL>(top, lane);
+        }
+        if (nb0 == 0) {            // the slab is done: lists are sorted with their zeros last, an empty slab ends the merge
+            if (!any) break;
+            any = false;
+        }
+        s0 = ns0; b0 = nb0; cur = nxt;
     }
 }
 
+// Merge of the [parts, nq, k] key lists of one scan launch, `wpq` waves per query inside one 1024-thread workgroup:
+// wave `sub` of a query folds parts sub, sub + wpq, ... (rank-slab order, prefetched), parks its k best in LDS, and the
+// query's first wave folds those wpq lists.  One launch replaces the former two-level pair; few-query batches (the
+// HBM-bound regime, where a merge used to cost 40-60 us of dependent load -> sort rounds on a single wave) get 16 waves per
+// query.  Output: keys (+ threshold seeding for the screening ladder) or final (score, row) lists.
+// `cond`: device-side predicate of the conditional exact re-runs behind the screening path (see ScanLaunch::cond).
+struct MergeOut {
+    u64* keys;            // [nq, k] merged keys, or null
+    u32* seed_thr;        // with keys: atomicMax of the merged k-th best (next ladder launch's shared threshold), or null
+    float* scores;        // [nq, k] final scores, or null
+    int64_t* rows;        // [nq, k] final rows (+ row_base)
+    int64_t row_base;
+    int l2_out;           // scores = max(qnorm2[q] - s, 0), smaller = better (RMU_METRIC_L2SQ)
+    const float* qnorm2;
+    const int64_t* scatter;   // optional: query i writes output row scatter[i] (patching re-run queries into the batch)
+};
 template <int NPL>
-__global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ partial, int parts, int64_t nq,
-                                                         int k, int64_t row_base, int l2_out,
-                                                         const float* __restrict__ qnorm2,
-                                                         float* __restrict__ out_scores,
-                                                         int64_t* __restrict__ out_rows) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= nq) return;
-    const int64_t m = (int64_t)parts * k;
+__global__ __launch_bounds__(1024) void merge_wg_kernel(const u64* __restrict__ partial, int parts, int64_t nq, int k, int wpq,
+                                                        MergeOut o, RmuCond cond) {
+    __shared__ u64 lists[16][64 * NPL];
+    int64_t nq_eff = nq;
+    if (cond.p) {
+        const int c = *cond.p;
+        if (c < cond.lo || c > cond.hi) return;           // uniform over the grid
+        if (cond.clamp && c < nq_eff) nq_eff = c;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int qpb = 16 / wpq;
+    const int64_t q = (int64_t)blockIdx.x * qpb + w / wpq;
+    const int sub = w % wpq;
+    const bool active = q < nq_eff;
     u64 top[NPL];
-    merge_stream<NPL>(top, m, lane, [&](int64_t idx) {
-        const int64_t part = idx / k, pos = idx % k;
-        return partial[(part * nq + q) * k + pos];
-    });
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) top[p] = 0ull;
+    if (active) {
+        const int npw = parts > sub ? (parts - sub + wpq - 1) / wpq : 0;
+        merge_stream_slabs_pf<NPL>(top, npw, k, lane, [&](int part, int pos) {
+            return partial[((int64_t)(sub + part * wpq) * nq + q) * k + pos];
+        });
+        if (wpq > 1) {
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) lists[w][lane + 64 * p] = top[p];
+        }
+    }
+    if (wpq > 1) __syncthreads();
+    if (!active || sub != 0) return;
+    if (wpq > 1)
+        merge_stream_slabs_pf<NPL>(top, wpq, k, lane, [&](int part, int pos) { return lists[w + part][pos]; });
+    const int64_t qo = o.scatter ? o.scatter[q] : q;
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
         const int e = lane + 64 * p;
-        if (e < k) {
-            const u64 key = top[p];
-            float s;
+        if (e >= k) continue;
+        const u64 key = top[p];
+        if (o.keys) {
+            o.keys[qo * k + e] = key;
+            if (o.seed_thr && e == k - 1 && key) atomicMax(o.seed_thr + qo, (u32)(key >> 32));
+        }
+        if (o.scores) {
+            float sc;
             int64_t r;
             if (key == 0ull) {
-                s = l2_out ? INFINITY : -INFINITY;
+                sc = o.l2_out ? INFINITY : -INFINITY;
                 r = -1;
             } else {
-                s = rmu_key_score(key);
-                if (l2_out) s = fmaxf(qnorm2[q] - s, 0.f);
-                r = (int64_t)rmu_key_row(key) + row_base;
+                sc = rmu_key_score(key);
+                if (o.l2_out) sc = fmaxf(o.qnorm2[q] - sc, 0.f);
+                r = (int64_t)rmu_key_row(key) + o.row_base;
             }
-            out_scores[q * k + e] = s;
-            out_rows[q * k + e] = r;
+            o.scores[qo * k + e] = sc;
+            o.rows[qo * k + e] = r;
         }
     }
 }
 
-// generic lists (scores fp32 + int64 rows, [parts, nq, k]); ties resolve to the lower candidate index,
-// i.e. the lower part, then the earlier position -- equal to (score, row) order when parts arrive in
-// ascending row ranges.
+// generic lists (scores fp32 + int64 rows; part p at scores + p*stride_s / rows + p*stride_r, each [nq, k]); ties resolve
+// to the lower candidate index, i.e. the lower part, then the earlier position -- equal to (score, row) order when
+// parts arrive in ascending row ranges.  smaller_better: the scores are distances (keys are built from -score).
 template <int NPL>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ scores,
-                                                          const int64_t* __restrict__ rows, int parts,
-                                                          int64_t nq, int k, float* __restrict__ out_scores,
+                                                          const int64_t* __restrict__ rows, int parts, int64_t stride_s,
+                                                          int64_t stride_r, int64_t nq, int k, int smaller_better,
+                                                          float* __restrict__ out_scores,
                                                           int64_t* __restrict__ out_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -131,10 +183,9 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
     u64 top[NPL];
     merge_stream<NPL>(top, m, lane, [&](int64_t idx) -> u64 {
         const int64_t part = idx / k, pos = idx % k;
-        const int64_t src = (part * nq + q) * k + pos;
-        const float s = scores[src];
-        if (rows[src] < 0 || !(s == s)) return 0ull;
-        return rmu_make_key(s + 0.0f, (u32)idx);
+        const float s = scores[part * stride_s + q * k + pos];
+        if (rows[part * stride_r + q * k + pos] < 0 || !(s == s)) return 0ull;
+        return rmu_make_key((smaller_better ? -s : s) + 0.0f, (u32)idx);
     });
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
@@ -142,13 +193,13 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
         if (e < k) {
             const u64 key = top[p];
             if (key == 0ull) {
-                out_scores[q * k + e] = -INFINITY;
+                out_scores[q * k + e] = smaller_better ? INFINITY : -INFINITY;
                 out_rows[q * k + e] = -1;
             } else {
                 const int64_t idx = rmu_key_row(key);
                 const int64_t part = idx / k, pos = idx % k;
-                out_scores[q * k + e] = rmu_key_score(key);
-                out_rows[q * k + e] = rows[(part * nq + q) * k + pos];
+                out_scores[q * k + e] = smaller_better ? -rmu_key_score(key) : rmu_key_score(key);
+                out_rows[q * k + e] = rows[part * stride_r + q * k + pos];
             }
         }
     }
@@ -156,75 +207,44 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
 
 }  // namespace
 
-int rmu_merge_keys_launch(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out,
-                          const float* qnorm2, float* out_scores, int64_t* out_rows, hipStream_t s) {
-    return rmu_merge_keys_launch2(partial, parts, nq, k, row_base, l2_out, qnorm2, out_scores, out_rows, nullptr, 0, s);
-}
-
-// scratch (optional, >= groups*nq*k keys): enables the two-level merge when few queries face many parts
-// (nq = 1 over 1024 chunk lists is 10k keys for ONE wave: 326 us single-level, ~25 us two-level)
-int rmu_merge_keys_launch2(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out,
-                           const float* qnorm2, float* out_scores, int64_t* out_rows, u64* scratch, int64_t scratch_keys,
-                           hipStream_t s) {
+static int merge_wg_launch(const u64* partial, int parts, int64_t nq, int k, const MergeOut& o, const RmuCond& cond, hipStream_t s) {
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
-    const dim3 block(256);
-    const u64* src = partial;
-    int src_parts = parts;
-    if (scratch && parts >= 64 && nq * 4 <= 4096) {
-        int groups = 32;
-        while (groups > 1 && (int64_t)groups * nq > 8192) groups >>= 1;
-        const int ppg = (parts + groups - 1) / groups;
-        groups = (parts + ppg - 1) / ppg;
-        if (groups > 1 && (int64_t)groups * nq * k <= scratch_keys) {
-            const dim3 g1((unsigned)((nq * groups + 3) / 4));
-            if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
-            else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
-            src = scratch;
-            src_parts = groups;
-        }
-    }
-    const dim3 grid((unsigned)((nq + 3) / 4));
-    if (k <= 64)
-        hipLaunchKernelGGL(merge_keys_kernel<1>, grid, block, 0, s, src, src_parts, nq, k, row_base, l2_out, qnorm2,
-                           out_scores, out_rows);
-    else
-        hipLaunchKernelGGL(merge_keys_kernel<2>, grid, block, 0, s, src, src_parts, nq, k, row_base, l2_out, qnorm2,
-                           out_scores, out_rows);
+    // waves per query: ~16 parts per wave, and at least ~2k waves in flight when the batch is small
+    int wpq = 1;
+    while (wpq < 16 && parts > 16 * wpq) wpq <<= 1;
+    while (wpq < 16 && nq * wpq < 2048 && wpq < parts) wpq <<= 1;
+    const int qpb = 16 / wpq;
+    const dim3 grid((unsigned)((nq + qpb - 1) / qpb)), block(1024);
+    if (k <= 64) hipLaunchKernelGGL(merge_wg_kernel<1>, grid, block, 0, s, partial, parts, nq, k, wpq, o, cond);
+    else hipLaunchKernelGGL(merge_wg_kernel<2>, grid, block, 0, s, partial, parts, nq, k, wpq, o, cond);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr, u64* scratch,
-                             int64_t scratch_keys, hipStream_t s) {
-    if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
-    const dim3 block(256);
-    const u64* src = partial;
-    int src_parts = parts;
-    // few queries x many parts (one query tile scans 256 row chunks): one wave per query would fold thousands of keys
-    // serially (58 us per merge at nq = 1); fold groups of 16 parts in parallel first
-    if (scratch && nq <= 256 && parts >= 32) {
-        const int ppg = 16, groups = (parts + ppg - 1) / ppg;
-        if ((int64_t)groups * nq * k <= scratch_keys) {
-            const dim3 g1((unsigned)((nq * groups + 3) / 4));
-            if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
-            else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, g1, block, 0, s, partial, parts, nq, k, groups, ppg, scratch, (u32*)nullptr);
-            src = scratch;
-            src_parts = groups;
-        }
-    }
-    const dim3 grid((unsigned)((nq + 3) / 4));
-    if (k <= 64) hipLaunchKernelGGL(merge_keys_partial_kernel<1>, grid, block, 0, s, src, src_parts, nq, k, 1, src_parts, out_keys, seed_thr);
-    else hipLaunchKernelGGL(merge_keys_partial_kernel<2>, grid, block, 0, s, src, src_parts, nq, k, 1, src_parts, out_keys, seed_thr);
-    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+// final merge of a scan's part lists -> (scores, rows); `scatter` (optional) redirects query i to output row scatter[i]
+int rmu_merge_final_launch(const u64* partial, int parts, int64_t nq, int k, int64_t row_base, int l2_out, const float* qnorm2,
+                           float* out_scores, int64_t* out_rows, const int64_t* scatter, const RmuCond* cond, hipStream_t s) {
+    MergeOut o{};
+    o.scores = out_scores; o.rows = out_rows; o.row_base = row_base; o.l2_out = l2_out; o.qnorm2 = qnorm2; o.scatter = scatter;
+    return merge_wg_launch(partial, parts, nq, k, o, cond ? *cond : RmuCond{}, s);
 }
 
-int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t nq, int k,
-                           float* out_scores, int64_t* out_rows, u64* /*scratch_keys*/, hipStream_t s) {
+// merge to keys (screening ladder): out_keys [nq, k]; seed_thr (optional) receives the merged k-th best per query
+int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr, hipStream_t s) {
+    MergeOut o{};
+    o.keys = out_keys; o.seed_thr = seed_thr;
+    return merge_wg_launch(partial, parts, nq, k, o, RmuCond{}, s);
+}
+
+int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t stride_s, int64_t stride_r, int64_t nq, int k,
+                           int smaller_better, float* out_scores, int64_t* out_rows, hipStream_t s) {
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
     if ((int64_t)parts * k >= (1ll << 32)) return RMU_E_INVALID;
     const dim3 grid((unsigned)((nq + 3) / 4)), block(256);
     if (k <= 64)
-        hipLaunchKernelGGL(merge_lists_kernel<1>, grid, block, 0, s, scores, rows, parts, nq, k, out_scores, out_rows);
+        hipLaunchKernelGGL(merge_lists_kernel<1>, grid, block, 0, s, scores, rows, parts, stride_s, stride_r, nq, k, smaller_better,
+                           out_scores, out_rows);
     else
-        hipLaunchKernelGGL(merge_lists_kernel<2>, grid, block, 0, s, scores, rows, parts, nq, k, out_scores, out_rows);
+        hipLaunchKernelGGL(merge_lists_kernel<2>, grid, block, 0, s, scores, rows, parts, stride_s, stride_r, nq, k, smaller_better,
+                           out_scores, out_rows);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }

@@ -12,6 +12,7 @@
 // spaces, CJK padding, lower-case + NFD + mark removal, punctuation) comes from wordpiece_tables.h, which
 // tools/gen_wordpiece_tables.py records from the `tokenizers` library itself.  Not captured: the Greek final-sigma rule.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -29,6 +30,7 @@ struct rmu_tok {
     std::unordered_map<std::string, int> vocab;
     int unk = 0, cls = 0, sep = 0, pad = 0;
     bool lower = true;
+    std::vector<std::pair<std::string, int>> specials;   // literal special tokens present in the vocabulary
 };
 
 namespace {
@@ -152,10 +154,32 @@ void wordpiece(const rmu_tok* tk, const std::string& word, std::vector<int>& ids
     ids.insert(ids.end(), sub.begin(), sub.end());
 }
 
-void encode_text(const rmu_tok* tk, const char* text, std::vector<int>& ids) {
+void encode_segment(const rmu_tok* tk, const std::string& text, std::vector<int>& ids) {
     std::vector<std::string> words;
-    basic_tokenize(tk, text ? text : "", words);
+    basic_tokenize(tk, text.c_str(), words);
     for (const std::string& wd : words) wordpiece(tk, wd, ids);
+}
+
+// The special tokens are "added tokens" of the HF tokenizer: literal occurrences in the RAW text (case-sensitive, before
+// normalisation) are cut out first and map to their single id; only the text between them is normalised and split
+// (a chunk that talks about BERT's "[SEP]" keeps one id there, not '[', 'sep', ']').
+void encode_text(const rmu_tok* tk, const char* text, std::vector<int>& ids) {
+    const std::string t = text ? text : "";
+    size_t pos = 0;
+    while (pos <= t.size()) {
+        size_t best = std::string::npos, best_len = 0;
+        int best_id = -1;
+        for (const auto& sp : tk->specials) {
+            const size_t f = t.find(sp.first, pos);
+            if (f != std::string::npos && (f < best || (f == best && sp.first.size() > best_len))) {
+                best = f; best_len = sp.first.size(); best_id = sp.second;
+            }
+        }
+        if (best == std::string::npos) { encode_segment(tk, t.substr(pos), ids); break; }
+        if (best > pos) encode_segment(tk, t.substr(pos, best - pos), ids);
+        ids.push_back(best_id);
+        pos = best + best_len;
+    }
 }
 
 }  // namespace
@@ -183,6 +207,10 @@ extern "C" int rmu_tok_create(rmu_tok_t** out, const char* vocab_path, int do_lo
         return RMU_E_INVALID;
     }
     tk->lower = do_lower_case != 0;
+    for (const char* sp : {"[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"}) {
+        auto it = tk->vocab.find(sp);
+        if (it != tk->vocab.end()) tk->specials.emplace_back(sp, it->second);
+    }
     *out = tk;
     return RMU_OK;
 }
@@ -194,7 +222,8 @@ extern "C" int rmu_tok_encode(rmu_tok_t* tk, const char* const* texts_a, const c
                               int32_t* ids, int32_t* type_ids, int32_t* lens) {
     if (!tk || !texts_a || !ids || !lens || n < 0 || max_len < 3) { rmu_set_error_("rmu_tok_encode: bad argument"); return RMU_E_INVALID; }
     const int nthreads = std::max(1, std::min<int>(n / 64, (int)std::thread::hardware_concurrency()));
-    auto work = [&](int lo, int hi) {
+    std::atomic<int> failed{0};       // an exception (bad_alloc) inside a worker must not reach std::terminate
+    auto work_body = [&](int lo, int hi) {
         std::vector<int> a, b;
         for (int i = lo; i < hi; ++i) {
             a.clear(); b.clear();
@@ -233,9 +262,19 @@ extern "C" int rmu_tok_encode(rmu_tok_t* tk, const char* const* texts_a, const c
             for (; p < max_len; ++p) { row[p] = tk->pad; if (trow) trow[p] = 0; }
         }
     };
-    if (nthreads == 1) { work(0, n); return RMU_OK; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t) th.emplace_back(work, (int)((int64_t)n * t / nthreads), (int)((int64_t)n * (t + 1) / nthreads));
-    for (auto& x : th) x.join();
+    auto work = [&](int lo, int hi) {
+        try { work_body(lo, hi); } catch (...) { failed.store(1); }
+    };
+    if (nthreads == 1) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> th;
+        try {
+            for (int t = 0; t < nthreads; ++t)
+                th.emplace_back(work, (int)((int64_t)n * t / nthreads), (int)((int64_t)n * (t + 1) / nthreads));
+        } catch (...) { failed.store(1); }
+        for (auto& x : th) x.join();
+    }
+    if (failed.load()) { rmu_set_error_("rmu_tok_encode: out of memory while tokenising"); return RMU_E_OOM; }
     return RMU_OK;
 }

@@ -46,7 +46,9 @@ class FlatIndex:
         d = ctypes.c_int()
         N.check(self._lib.rmu_index_dim(h, ctypes.byref(d)), "rmu_index_dim")
         self.dim = int(d.value)
-        self.metric = N.METRIC_IP
+        m = ctypes.c_int()
+        N.check(self._lib.rmu_index_metric(h, ctypes.byref(m)), "rmu_index_metric")
+        self.metric = int(m.value)                 # what the file header says, not an assumption
         return self
 
     # -- lifecycle ---------------------------------------------------------------------------------
@@ -141,6 +143,25 @@ class FlatIndex:
                                            out_s.ctypes.data, out_r.ctypes.data, 0), "rmu_index_search")
         return out_s, out_r
 
+    def set_screening(self, on: bool = True):
+        """RMU_OPT_SCREEN: allow (default) or forbid the fp16 screening path; results are identical either way."""
+        N.check(self._lib.rmu_index_set_option(self._h, N.OPT_SCREEN, 1 if on else 0), "rmu_index_set_option")
+
+    def screen_candidates(self, q):
+        """Test hook (rmu_index_screen_candidates): per query the screening pass's 32 candidates ->
+        (approx scores [nq,32], rows [nq,32], exact fp32 scores of the same rows [nq,32], EPS [nq])."""
+        qq = np.ascontiguousarray(q, dtype=np.float32)
+        if qq.ndim == 1:
+            qq = qq[None]
+        nq = qq.shape[0]
+        ap = np.empty((nq, 32), np.float32)
+        ro = np.empty((nq, 32), np.int64)
+        ex = np.empty((nq, 32), np.float32)
+        eps = np.empty((nq,), np.float32)
+        N.check(self._lib.rmu_index_screen_candidates(self._h, qq.ctypes.data, nq, ap.ctypes.data, ro.ctypes.data, ex.ctypes.data,
+                                                      eps.ctypes.data), "rmu_index_screen_candidates")
+        return ap, ro, ex, eps
+
     # -- measurement hooks (bench.py) ----------------------------------------------------------------
     def set_timing(self, on: bool = True):
         self._lib.rmu_set_timing(1 if on else 0)
@@ -152,7 +173,8 @@ class FlatIndex:
         return float(self._lib.rmu_last_search_ms())
 
     def last_screened(self) -> int:
-        """>0: answered by the fp16 screening pass + exact re-score; 0: exact scan; <0: fell back to the exact scan."""
+        """>0: answered by the fp16 screening pass + exact re-score; 0: exact scan; <0: screened, with that many queries
+        re-run on the exact scan."""
         return int(self._lib.rmu_last_screened())
 
     def last_geometry(self) -> dict:
@@ -161,9 +183,11 @@ class FlatIndex:
         return {"grid": g.value, "block": b.value, "lds_bytes": l.value, "launches": p.value}
 
 
-def topk_merge(part_scores, part_rows, k: int | None = None):
-    """Merge [parts, nq, k] shard lists (numpy or torch CUDA) -> [nq, k]."""
+def topk_merge(part_scores, part_rows, k: int | None = None, smaller_better: bool = False):
+    """Merge [parts, nq, k] shard lists (numpy or torch CUDA) -> [nq, k].  smaller_better: the scores are distances
+    (lists of an RMU_METRIC_L2SQ index)."""
     lib = N.lib()
+    fl = N.F_SMALLER_BETTER if smaller_better else 0
     if _is_torch_cuda(part_scores):
         import torch
         s = part_scores.detach().to(torch.float32).contiguous()
@@ -172,7 +196,7 @@ def topk_merge(part_scores, part_rows, k: int | None = None):
         out_s = torch.empty((nq, kk), dtype=torch.float32, device=s.device)
         out_r = torch.empty((nq, kk), dtype=torch.int64, device=s.device)
         torch.cuda.current_stream().synchronize()
-        N.check(lib.rmu_topk_merge(s.data_ptr(), r.data_ptr(), parts, nq, kk, N.F_Q_DEVICE | N.F_OUT_DEVICE,
+        N.check(lib.rmu_topk_merge(s.data_ptr(), r.data_ptr(), parts, nq, kk, N.F_Q_DEVICE | N.F_OUT_DEVICE | fl,
                                    out_s.data_ptr(), out_r.data_ptr(), 0), "rmu_topk_merge")
         return out_s, out_r
     s = np.ascontiguousarray(part_scores, dtype=np.float32)
@@ -180,6 +204,6 @@ def topk_merge(part_scores, part_rows, k: int | None = None):
     parts, nq, kk = s.shape
     out_s = np.empty((nq, kk), dtype=np.float32)
     out_r = np.empty((nq, kk), dtype=np.int64)
-    N.check(lib.rmu_topk_merge(s.ctypes.data, r.ctypes.data, parts, nq, kk, 0, out_s.ctypes.data, out_r.ctypes.data, 0),
+    N.check(lib.rmu_topk_merge(s.ctypes.data, r.ctypes.data, parts, nq, kk, fl, out_s.ctypes.data, out_r.ctypes.data, 0),
             "rmu_topk_merge")
     return out_s, out_r

@@ -6,15 +6,77 @@ B*k*12 bytes per rank, latency-bound) hands every rank all per-shard top-k lists
 rmu_topk_merge folds into the final top-k.  No reference counterpart (the reference is
 single-process); the local step serves server/RAGHelper.py:497-499.
 
+Two transports for the exchange:
+  * `NativeComm` -- the C-ABI path (`rmu_comm_*`, `rmu_shard_allgather_topk`): RCCL called from librmu.so itself, pack +
+    all-gather + merge in one call on one stream; any host language can drive it.  The 128-byte RCCL unique id travels
+    through whatever side channel the host has (here: torch.distributed's broadcast, or a file).
+  * torch.distributed `all_gather_into_tensor` + `rmu_topk_merge` (the default when no NativeComm is given; with the
+    gloo backend this is also what the CPU tests exercise).
 `local_search` / `merge` are injectable so the orchestration (offsets, packing, ordering) is
 testable on CPU with gloo; the defaults are the HIP paths and raise if librmu.so is missing.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Callable
 
 import torch
 import torch.distributed as dist
+
+
+class NativeComm:
+    """RCCL communicator owned by librmu.so (include/rmu.h: rmu_comm_*).  `NativeComm.from_torch_dist()` bootstraps it from
+    an initialised torch.distributed group (rank 0 creates the unique id, a broadcast distributes it)."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device: int | None = None):
+        from . import _native as N
+        self._N, self._lib = N, N.lib()
+        if device is not None:
+            N.check(self._lib.rmu_init(int(device)), "rmu_init")
+        if len(unique_id) != N.COMM_ID_BYTES:
+            raise ValueError(f"unique id must be {N.COMM_ID_BYTES} bytes")
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, N.COMM_ID_BYTES)
+        N.check(self._lib.rmu_comm_init(ctypes.byref(h), buf, int(world), int(rank)), "rmu_comm_init")
+        self._h, self.world, self.rank = h, int(world), int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _native as N
+        buf = ctypes.create_string_buffer(N.COMM_ID_BYTES)
+        N.check(N.lib().rmu_comm_unique_id(buf), "rmu_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_dist(cls, device: int, group=None) -> "NativeComm":
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ids = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, group=group)
+        return cls(ids[0], world, rank, device=device)
+
+    def allgather_topk(self, s, r, smaller_better: bool = False):
+        """Local [nq, k] torch CUDA lists -> merged global [nq, k] (identical on every rank)."""
+        N = self._N
+        s = s.contiguous()
+        r = r.contiguous()
+        nq, k = s.shape
+        out_s, out_r = torch.empty_like(s), torch.empty_like(r)
+        torch.cuda.current_stream(s.device).synchronize()
+        N.check(self._lib.rmu_shard_allgather_topk(self._h, s.data_ptr(), r.data_ptr(), nq, k,
+                                                   N.F_Q_DEVICE | N.F_OUT_DEVICE | (N.F_SMALLER_BETTER if smaller_better else 0),
+                                                   out_s.data_ptr(), out_r.data_ptr(), 0), "rmu_shard_allgather_topk")
+        return out_s, out_r
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rmu_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_bounds(n_rows: int, world: int, rank: int) -> tuple[int, int]:
@@ -26,10 +88,12 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> tuple[int, int]:
 
 class ShardedSearcher:
     def __init__(self, index=None, row_base: int = 0, group=None,
-                 local_search: Callable | None = None, merge: Callable | None = None, force_collective: bool = False):
+                 local_search: Callable | None = None, merge: Callable | None = None, force_collective: bool = False,
+                 comm: NativeComm | None = None):
         self.index = index
         self.row_base = int(row_base)
         self.group = group
+        self.comm = comm                       # the C-ABI RCCL path when given (else torch.distributed)
         if local_search is None:
             if index is None:
                 raise ValueError("need an index or a local_search callable")
@@ -49,6 +113,8 @@ class ShardedSearcher:
         """q: [B, d] (torch tensor on this rank's device, identical on every rank).
         Returns (scores [B,k] f32, rows [B,k] i64) -- identical on every rank."""
         s, r = self._search(q, k)
+        if self.comm is not None and (self.comm.world > 1 or self.force_collective):
+            return self.comm.allgather_topk(torch.as_tensor(s), torch.as_tensor(r))
         w = self.world
         if w == 1 and not (self.force_collective and dist.is_initialized()):
             return s, r

@@ -166,3 +166,18 @@ def test_committed_golden_from_transformers(tmp_path, librmu):
         assert ids[0, :lens[0]].tolist() == c["ids"], c
         if c["b"] is not None:
             assert tt[0, :lens[0]].tolist() == c["type_ids"], c
+
+
+def test_literal_special_tokens_match_transformers(pair):
+    """literal '[SEP]' / '[CLS]' / '[MASK]' / '[UNK]' / '[PAD]' in the text are single ids in transformers'
+    BertTokenizer (added tokens are cut out of the raw text before normalisation); lower-case look-alikes are not."""
+    mine, hf = pair
+    texts = ["BERT joins segments with [SEP] and starts with [CLS] .", "[MASK]", "a[SEP]b", "the [MASK]ed dog", "[sep] [Sep] [ SEP ]",
+             "[UNK] [PAD] [SEP][SEP]", "x [CLS", "SEP] y", "[[SEP]]", "the quick [MASK] fox [UNK]", "[MASK][MASK] jumps[SEP]over"]
+    ids, tt, lens = mine.encode(texts, max_len=48)
+    for i, t in enumerate(texts):
+        want = hf(t, truncation=True, max_length=48, padding=False)["input_ids"]
+        assert ids[i, :lens[i]].tolist() == want, (t, ids[i, :lens[i]].tolist(), want)
+    e = hf("what is [MASK] ?", "it is the [SEP] token", truncation="longest_first", max_length=32, return_token_type_ids=True)
+    ids, tt, lens = mine.encode(["what is [MASK] ?"], ["it is the [SEP] token"], max_len=32)
+    assert ids[0, :lens[0]].tolist() == e["input_ids"] and tt[0, :lens[0]].tolist() == e["token_type_ids"]
