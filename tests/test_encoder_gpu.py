@@ -132,3 +132,42 @@ def test_text_pipeline_with_the_native_tokenizer(bi, cross, tmp_path):
     ce_n = MI355XCrossEncoder(encoder=cross[0], tokenizer=native, max_seq_length=64)
     ce_h = MI355XCrossEncoder(encoder=cross[0], tokenizer=hf, max_seq_length=64)
     assert ce_n.score(pairs) == ce_h.score(pairs)
+
+
+def test_embeddings_4096_chunk_sample_vs_transformers(bi):
+    """parity on a 4 096-chunk sample of the indexing workload (L ~ clip(N(128, 32), 16, 256), ~524k tokens),
+    against the implementation the reference itself calls -- transformers' BertModel, fp32, on the host cores -- followed by
+    sentence-transformers' pooling (masked mean, L2 normalise).  Bar: cosine >= 0.999 for every chunk."""
+    import torch
+    enc, _ = bi
+    model = make_bert(seed=0, layers=6)                                       # the same seeded weights the fixture uploaded
+    ids, _, lens = synth_tokens(4096, seed=7)
+    order = np.argsort(-lens, kind="stable")
+    got = enc.encode_ids(ids, lens, None, mode=0).cpu().numpy()
+    ref = np.empty((4096, 384), np.float32)
+    with torch.no_grad():
+        for b0 in range(0, 4096, 128):                                        # length-sorted mini-batches: little padding
+            sel = order[b0:b0 + 128]
+            L = int(lens[sel].max())
+            bi_ids = torch.from_numpy(ids[sel, :L].astype(np.int64))
+            mask = (torch.arange(L)[None, :] < torch.from_numpy(lens[sel].astype(np.int64))[:, None])
+            h = model(input_ids=bi_ids, attention_mask=mask.long()).last_hidden_state
+            m = mask.unsqueeze(-1).float()
+            pooled = (h * m).sum(1) / m.sum(1).clamp(min=1e-9)
+            ref[sel] = torch.nn.functional.normalize(pooled, p=2, dim=1).numpy()
+    cos = (got * ref).sum(1)
+    assert cos.min() >= 0.999, (float(cos.min()), int(cos.argmin()), int(lens[cos.argmin()]))
+    assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() < 1e-5
+
+
+def test_cross_encoder_100_pairs_tolerance_1e2(cross):
+    """100 pairs per query (query 16 tokens + passage ~128): rerank order identical to the oracle's except
+    between pairs whose oracle logits differ by < 1e-2."""
+    enc, w = cross
+    ids, tt, lens = synth_tokens(100, seed=55, lmin=40, lmax=200, mean=144, std=30, pair=True)
+    got = enc.encode_ids(ids, lens, tt, mode=1).cpu().numpy()
+    ref = O.cross_encoder_logit(w, O.bert_hidden(w, ids, tt, lens))
+    order_g, order_r = np.argsort(-got, kind="stable"), np.argsort(-ref, kind="stable")
+    for a, b in zip(order_g[:10], order_r[:10]):
+        assert a == b or abs(ref[a] - ref[b]) < 1e-2, (a, b, ref[a], ref[b])
+    assert np.abs(got - ref).max() <= 2e-2 * (1 + np.abs(ref).max())

@@ -10,8 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("RMU_RUN_C_EXAMPLE") != "1",
-                    reason="opt-in until it has been run once on the GPU box (written after this round's GPU budget was spent): RMU_RUN_C_EXAMPLE=1")
 def test_c_example_runs_against_the_library(tmp_path, librmu):
     gcc = shutil.which("gcc")
     assert gcc
