@@ -1,20 +1,22 @@
 #!/usr/bin/env python
-"""bench.py -- headline benchmark of the MI355X-native RAGMeUp retrieval hot path.
+"""bench.py -- benchmark of the MI355X-native RAGMeUp retrieval hot path (one JSON line on rank 0).
 
-Metric (BASELINE.json): queries/sec of exact dense top-10 over a 10M x 384 fp32 corpus resident in
-HBM, batch = 1024 queries per step.  A "step" = one pass of the hot path over one query batch:
-rmu_index_search (default: fp16 screening ladder -> merges -> exact fp32 re-score of 32 candidates per query, results
-bit-identical to the exact fp32 scan; RMU_SCREEN=0: the exact fp32 fused scan+top-k) -> (N>1: one RCCL all-gather of
-per-shard top-k) -> merge.
-N GPUs: the 10M rows are sharded N ways (strong scaling: total work fixed), one process per GPU.
+Headline (BASELINE.json `metric`): queries/sec of exact dense top-10 over a 10M x 384 fp32 corpus resident in HBM,
+batch = 1024 queries per step.  A "step" = one pass of the hot path over one query batch: rmu_index_search (default: fp16
+screening ladder -> merges -> exact fp32 re-score of 32 candidates per query, results bit-identical to the exact fp32 scan)
+-> (N > 1: ONE RCCL all-gather of per-shard top-k, issued from librmu.so) -> merge.  N GPUs: the 10M rows are sharded N ways
+(strong scaling: total work fixed), one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--batch B] [--k K]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--batch B] [--k K] [--legs all|none|a,b,...]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see README/DESIGN for the field meanings).  Inputs are generated on
-the device and are resident in HBM before the timed region.  The oracle is used only for the
-cpu_baseline leg and the recall check (never inside the timed region).
+`value` is timed with nothing but the product path inside the bracket (no per-launch events); the dominant kernel's
+launch durations (roofline) are measured afterwards, on the same inputs, with hipEvents on the stream the kernels run on.
+At N = 1 the same run also reports, under "secondary", every other BASELINE.json configuration with its own roofline and
+CPU figure: the exact fp32 scan (API switch), the HBM-bound batch sizes 1 / 32 / 128, config 2 (1M rows), config 3
+(chunk embedding) and config 5 (dense top-100 -> cross-encoder rerank -> top-10), and the CPU baselines of config 1 timed on
+this box's host cores (count stated).  Inputs are generated on the device and are resident in HBM before any timed region.
+The oracle is used only for the cpu_baseline legs and the recall check (never inside a timed region).
 """
 from __future__ import annotations
 
@@ -31,9 +33,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
-PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-SCREEN_TRAFFIC = {1024: 1.3632e10, 1: 7.683e9}   # HBM bytes per 10M-row batch over all screening launches: rocprofv3 PMC, profiles/r01_summary.md
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (the 5 PF figure is 2:1 sparse)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+IMG_ROW_BYTES = 768            # fp16 screening image of a 384-d row
+# HBM bytes per step from rocprofv3 PMC passes of exactly these configurations (2 x FETCH_SIZE [gfx950 correction] +
+# WRITE_SIZE, summed over the launches of a step; profiles/r02_summary.md).  None = not measured for that configuration.
+TRAFFIC = {("screen", 10_000_000, 1024): 1.3632e10, ("screen", 10_000_000, 1): 7.683e9,
+           ("exact", 10_000_000, 1024): 2 * 7.876e6 * 1024 + 6070 * 1024, ("exact", 10_000_000, 1): 2 * 7.504e6 * 1024}
+TRAFFIC_SOURCE = "profiles/r01_pmc_means.csv (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024)"
 
 
 def make_shard(n_rows: int, d: int, seed: int, device) -> "torch.Tensor":
@@ -50,6 +57,242 @@ def make_shard(n_rows: int, d: int, seed: int, device) -> "torch.Tensor":
     return out
 
 
+def timed(fn, steps: int, warmup: int) -> float:
+    """ms per call: warm-up, then `steps` calls bracketed by device synchronisation."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def scan_roofline(index, run, n_rows: int, d: int, nq: int, k: int, steps: int) -> dict:
+    """Roofline block of the dense scan: launch durations by hipEvents inside librmu.so (rmu_last_scan_ms = sum over the
+    scan launches of one search), algorithmic work of those launches, the roof that binds."""
+    index.set_timing(True)
+    ms, scr = [], []
+    geom = {}
+    for _ in range(steps):
+        run()
+        ms.append(index.last_scan_ms())
+        scr.append(index.last_screened())
+        geom = index.last_geometry()
+    index.set_timing(False)
+    kms = float(np.mean(ms))
+    flops = 2.0 * n_rows * d * nq
+    screened = all(v != 0 for v in scr)
+    if screened:
+        # answered by the fp16 screening scan over the fp16 image (768 B per row) + exact fp32 re-score of 32 candidates per
+        # query; algorithmic bytes = the image once + queries + results
+        path, peak_tf = "screen-f16+rescore-f32", PEAK_F16_MFMA_TFLOPS
+        bytes_alg = n_rows * IMG_ROW_BYTES + nq * IMG_ROW_BYTES + nq * k * 12
+        g2 = nq > 128
+        kname = (f"scan_screen_kernel<G={2 if g2 else 1}> (D=384, {256 if g2 else 128} queries/WG, 32-row tiles as two 12-KiB half-k chunks, "
+                 f"{6 if g2 else 8}-slot LDS-DMA ring{'' if g2 else ', nt stream'}), one launch per row range of the threshold ladder")
+    else:
+        path, peak_tf = "exact-f32", PEAK_F32_MFMA_TFLOPS
+        bytes_alg = n_rows * d * 4 + nq * d * 4 + nq * k * 12
+        wq = 1 if nq <= 32 else (2 if nq <= 64 else 4)
+        kname = {4: f"scan_topk_kernel<D={d},WQ=4,CK=96,RING=4,CAP=64>", 2: f"scan_topk_kernel<D={d},WQ=2,CK=96,RING=3,CAP=64,nt>",
+                 1: f"scan_topk_kernel<D={d},WQ=1,CK=48,RING=3,CAP=64,nt>"}[wq]
+    ach_tf = flops / (kms * 1e-3) / 1e12
+    ach_gbs = bytes_alg / (kms * 1e-3) / 1e9
+    f_mfma, f_hbm = ach_tf / peak_tf, ach_gbs / PEAK_HBM_GBS
+    if f_mfma >= f_hbm:
+        r = {"kernel": kname, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
+    else:
+        r = {"kernel": kname, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}
+    traffic = TRAFFIC.get(("screen" if screened else "exact", n_rows, nq)) if (d == 384 and k == 10) else None
+    r.update({"traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic else None, "kernel_ms": round(kms, 4),
+              "algorithmic_bytes": bytes_alg, "algorithmic_flops": flops, "path": path,
+              "rerun_queries": sum(-v for v in scr if v < 0), "mfma_TFLOPs": round(ach_tf, 2), "mfma_frac": round(f_mfma, 4),
+              "hbm_GBs": round(ach_gbs, 1), "hbm_frac": round(f_hbm, 4), "launch": geom})
+    return r
+
+
+# ---- encoder workloads (configs 3 and 5): synthetic token ids of SURVEY.md 8d, architecture-exact random weights ---------
+def bert_weights(seed: int, head: bool) -> dict:
+    """HF-named fp32 tensors of a BERT-6x384 (all-MiniLM-L6-v2 / ms-marco-MiniLM-L-6-v2 architecture), N(0, 0.02) init as
+    transformers does, LayerNorm/bias perturbed so nothing is trivially 0/1.  No checkpoint exists offline."""
+    from ragmeup_amd.bert import weight_order
+    rng = np.random.default_rng(seed)
+    shapes = {"embeddings.word_embeddings.weight": (30522, 384), "embeddings.position_embeddings.weight": (512, 384),
+              "embeddings.token_type_embeddings.weight": (2, 384)}
+    out = {}
+    for n in weight_order(6, head):
+        if n in shapes:
+            shp = shapes[n]
+        elif n.endswith("intermediate.dense.weight"):
+            shp = (1536, 384)
+        elif n.endswith("intermediate.dense.bias"):
+            shp = (1536,)
+        elif n.endswith("output.dense.weight") and "attention" not in n:
+            shp = (384, 1536)
+        elif n == "classifier.weight":
+            shp = (1, 384)
+        elif n == "classifier.bias":
+            shp = (1,)
+        elif n.endswith(".weight") and "LayerNorm" not in n:
+            shp = (384, 384)
+        else:
+            shp = (384,)
+        if "LayerNorm.weight" in n:
+            out[n] = (1.0 + 0.05 * rng.standard_normal(shp)).astype(np.float32)
+        elif n.endswith(".bias"):
+            out[n] = (0.05 * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            out[n] = (0.02 * rng.standard_normal(shp)).astype(np.float32)
+    return out
+
+
+def synth_tokens(n, seed, lmin=16, lmax=256, mean=128, std=32, pair=False):
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.rint(rng.normal(mean, std, n)), lmin, lmax).astype(np.int32)
+    L = int(lens.max())
+    ids = rng.integers(1000, 30522, (n, L)).astype(np.int32)
+    tt = np.zeros((n, L), dtype=np.int32)
+    ids[:, 0] = 101
+    ids[np.arange(n), lens - 1] = 102
+    if pair:
+        ql = np.minimum(16, lens // 2)
+        ids[np.arange(n), ql] = 102
+        tt[np.arange(L)[None, :] > ql[:, None]] = 1
+    for i in range(n):
+        ids[i, lens[i]:] = 0
+        tt[i, lens[i]:] = 0
+    return ids, tt, lens
+
+
+def encoder_flops(lens) -> float:
+    l = np.asarray(lens, dtype=np.float64)
+    return float((l * (2 * 6 * (4 * 384 * 384 + 2 * 384 * 1536)) + 6 * 4 * l * l * 384).sum())
+
+
+def encoder_roofline(tf: float) -> dict:
+    return {"kernel": "k_gemm / k_attention (bf16 MFMA 16x16x32), whole forward", "bound": "mfma", "achieved": round(tf, 2),
+            "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
+            "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches)"}
+
+
+def leg_embed(args) -> dict:
+    from ragmeup_amd.bert import BertEncoder
+    enc = BertEncoder(bert_weights(0, False), layers=6)
+    ids, _, lens = synth_tokens(8192, seed=7)
+    ids_t, lens_t = torch.as_tensor(ids).cuda(), torch.as_tensor(lens).cuda()
+    out = torch.empty((8192, 384), dtype=torch.float32, device="cuda")
+    ms = timed(lambda: enc.encode_ids(ids_t, lens_t, None, 0, out=out), steps=6, warmup=2)
+    fl = encoder_flops(lens)
+    leg = {"name": "C3 embed chunks (BERT-6x384 bf16 MFMA, mean-pool, L2-norm)", "value": round(8192 / (ms * 1e-3), 1), "unit": "chunks/sec",
+           "ms_per_step": round(ms, 3), "config": {"workload": "8192-chunk batches, L ~ clip(N(128,32),16,256), synthetic ids, random-init weights",
+                                                   "tokens_per_step": int(lens.sum())},
+           "tokens_per_sec": round(float(lens.sum()) / (ms * 1e-3), 1), "roofline": encoder_roofline(fl / (ms * 1e-3) / 1e12)}
+    if not args.no_cpu_baseline:
+        leg["cpu_baseline"] = cpu_encoder_baseline(head=False)
+    enc.close()
+    return leg
+
+
+def leg_rerank(args, x1m) -> dict:
+    from ragmeup_amd import FlatIndex
+    from ragmeup_amd.bert import BertEncoder
+    ce = BertEncoder(bert_weights(1, True), layers=6)
+    idx = FlatIndex(384, capacity_hint=x1m.shape[0])
+    idx.add(x1m)
+    nqr = 64
+    q = x1m[:nqr].clone()
+    ids, tt, lens = synth_tokens(nqr * 100, seed=9, lmin=100, lmax=190, mean=147, std=20, pair=True)
+    ids_t, tt_t, lens_t = (torch.as_tensor(a).cuda() for a in (ids, tt, lens))
+
+    def step():
+        s, r = idx.search(q, 100)                                            # dense top-100 (exact fp32 scan: k > 24)
+        logits = ce.encode_ids(ids_t, lens_t, tt_t, mode=1)                  # 100 (query, passage) pairs per query
+        top = torch.topk(logits.view(nqr, 100), 10, dim=1)                   # final top-10
+        return r.gather(1, top.indices)
+
+    ms = timed(step, steps=4, warmup=2)
+    ms_ce = timed(lambda: ce.encode_ids(ids_t, lens_t, tt_t, mode=1), steps=4, warmup=1)
+    fl = encoder_flops(lens)
+    leg = {"name": "C5 retrieve-then-rerank (dense top-100 over 1M rows -> cross-encoder 100 pairs/query -> top-10)",
+           "value": round(nqr / (ms * 1e-3), 1), "unit": "queries/sec", "ms_per_step": round(ms, 3),
+           "config": {"workload": "64 queries/step, 1M x 384 corpus, pairs = 16 query + ~128 passage tokens", "pairs_per_step": nqr * 100},
+           "pairs_per_sec": round(nqr * 100 / (ms * 1e-3), 1), "cross_encoder_ms": round(ms_ce, 3),
+           "roofline": encoder_roofline(fl / (ms_ce * 1e-3) / 1e12)}
+    if not args.no_cpu_baseline:
+        leg["cpu_baseline"] = cpu_encoder_baseline(head=True)
+    idx.close(); ce.close()
+    return leg
+
+
+# ---- CPU baselines (config 1: what the reference itself runs with force_cpu): bounded samples, host cores stated ----------
+def cpu_encoder_baseline(head: bool) -> dict:
+    """transformers' BertModel / BertForSequenceClassification -- the third-party forward behind HuggingFaceEmbeddings /
+    HuggingFaceCrossEncoder -- fp32 on the host cores, sentence-transformers' batching (32 per mini-batch, sorted by length,
+    padded to the longest)."""
+    from transformers import BertConfig, BertForSequenceClassification, BertModel
+    cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12, intermediate_size=1536,
+                     max_position_embeddings=512, layer_norm_eps=1e-12, num_labels=1)
+    torch.manual_seed(0)
+    model = (BertForSequenceClassification(cfg) if head else BertModel(cfg, add_pooling_layer=False)).eval()
+    n = 100 if head else 256
+    ids, tt, lens = synth_tokens(n, seed=11, **({"lmin": 100, "lmax": 190, "mean": 147, "std": 20, "pair": True} if head else {}))
+    order = np.argsort(-lens, kind="stable")
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for b0 in range(0, n, 32):
+            sel = order[b0:b0 + 32]
+            L = int(lens[sel].max())
+            mask = (torch.arange(L)[None, :] < torch.from_numpy(lens[sel].astype(np.int64))[:, None]).long()
+            kw = {"input_ids": torch.from_numpy(ids[sel, :L].astype(np.int64)), "attention_mask": mask}
+            if head:
+                kw["token_type_ids"] = torch.from_numpy(tt[sel, :L].astype(np.int64))
+                model(**kw).logits
+            else:
+                h = model(**kw).last_hidden_state
+                m = mask.unsqueeze(-1).float()
+                torch.nn.functional.normalize((h * m).sum(1) / m.sum(1).clamp(min=1e-9), dim=1)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "pairs/sec" if head else "chunks/sec", "cores": torch.get_num_threads(), "kind": "reference",
+            "sample": f"{n} {'pairs' if head else 'chunks'}, transformers {'BertForSequenceClassification' if head else 'BertModel'} fp32 on CPU, "
+                      f"mini-batch 32 sorted by length ({dt:.2f} s); the tokenizer is not timed"}
+
+
+def cpu_search_baselines(q_host: np.ndarray, sample: np.ndarray, n_full: int, k: int) -> dict:
+    """(a) B = 1024: torch CPU sgemm + torch.topk (both threaded) in row blocks; (b) B = 1, the reference's one query per
+    call: the OpenMP C oracle (oracle/flat_search.c, scalar fmaf per (query, row), rows split over the threads).
+    Both on a row sample, scaled linearly to the full corpus."""
+    from oracle import cflat
+    threads = torch.get_num_threads()
+    xs = torch.from_numpy(sample)
+    qs = torch.from_numpy(q_host)
+    t0 = time.perf_counter()
+    best_s = torch.full((qs.shape[0], k), -float("inf"))
+    best_r = torch.full((qs.shape[0], k), -1, dtype=torch.int64)
+    blk = 262144
+    for lo in range(0, xs.shape[0], blk):
+        sc = qs @ xs[lo:lo + blk].T
+        cs, ci = torch.topk(sc, k, dim=1)
+        alls, allr = torch.cat([best_s, cs], 1), torch.cat([best_r, ci + lo], 1)
+        o = torch.topk(alls, k, dim=1).indices
+        best_s, best_r = torch.gather(alls, 1, o), torch.gather(allr, 1, o)
+    dt_b = time.perf_counter() - t0
+    scale = n_full / sample.shape[0]
+    batch = {"value": round(qs.shape[0] / (dt_b * scale), 3), "unit": "queries/sec", "cores": threads, "kind": "port",
+             "sample": f"{qs.shape[0]} queries x first {sample.shape[0]} rows, torch-CPU sgemm + torch.topk, {threads} threads ({dt_b:.2f} s), "
+                       f"scaled linearly to {n_full} rows"}
+    nq1 = 8
+    t0 = time.perf_counter()
+    for i in range(nq1):
+        cflat.flat_search(q_host[i:i + 1], sample, k)
+    dt_1 = time.perf_counter() - t0
+    single = {"value": round(nq1 / (dt_1 * scale), 3), "unit": "queries/sec", "cores": cflat.num_threads(), "kind": "port",
+              "sample": f"{nq1} single-query calls x first {sample.shape[0]} rows, OpenMP C oracle (scalar fmaf scan + per-thread top-k), "
+                        f"{cflat.num_threads()} threads ({dt_1:.2f} s), scaled linearly to {n_full} rows"}
+    return {"batch": batch, "single": single, "rows": best_r.numpy()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,11 +302,13 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c2,embed,rerank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-identity-check", action="store_true",
                     help="skip the post-run comparison with the exact fp32 scan (keeps rocprofv3 per-kernel statistics to the timed launches)")
-    ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="diagnostic: no hipEvents around the scan launches (roofline fields become meaningless)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the hipEvent pass (no roofline block)")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="N > 1: rmu_shard_allgather_topk (RCCL from librmu.so) or torch.distributed all_gather + rmu_topk_merge")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,7 +332,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from ragmeup_amd import FlatIndex, _native
-    from ragmeup_amd.shard import ShardedSearcher, shard_bounds
+    from ragmeup_amd.shard import NativeComm, ShardedSearcher, shard_bounds
 
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     lo, hi = shard_bounds(N, world, rank)
@@ -111,32 +356,39 @@ def main():
     if world > 1:
         dist.broadcast(q, 0)
         dist.broadcast(planted, 0)
+    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c2,embed,rerank".split(",") if args.legs == "all" else args.legs.split(","))
     sample_host = None
-    if rank == 0 and not args.no_cpu_baseline:
-        sample_rows = min(n_local, 2_000_000)
-        sample_host = shard[:sample_rows].cpu().numpy()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample_host = shard[:min(n_local, 2_000_000)].cpu().numpy()
+    x1m = shard[:1_000_000].clone() if (legs & {"c2", "rerank"}) and n_local >= 1_000_000 else None
     del shard
     torch.cuda.empty_cache()
 
-    searcher = ShardedSearcher(index, row_base=lo)
-    index.set_timing(not args.no_kernel_timing)
+    exchange = "none"
+    comm = None
+    if world > 1:
+        exchange = "torch.distributed all_gather_into_tensor + rmu_topk_merge"
+        if args.exchange == "native":
+            try:
+                comm = NativeComm.from_torch_dist(device=local_rank)
+                exchange = "rmu_shard_allgather_topk (one ncclAllGather issued from librmu.so + device merge)"
+            except Exception as e:  # noqa: BLE001 - the torch.distributed exchange is the same algorithm
+                exchange += f" [native exchange unavailable: {e}]"
+    searcher = ShardedSearcher(index, row_base=lo, comm=comm)
 
     def step():
         return searcher.search(q, K)
 
+    # ---- headline: exactly K steps, barrier + synchronize on both sides, MAX over ranks ---------------
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    scan_ms, screened = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_s, out_r = step()
-        scan_ms.append(index.last_scan_ms())   # hipEvents on the stream the scan kernel ran on
-        screened.append(index.last_screened())
-        geom = index.last_geometry()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,20 +404,24 @@ def main():
     sorted_ok = bool((out_s[:, :-1] >= out_s[:, 1:]).all().item())
 
     # ---- full-size parity property (outside the timed region): on this rank's whole shard the default path (fp16 screen
-    # + fp32 re-score) must return the exact fp32 scan's ids AND scores bit for bit.  k = 25 > 24 always takes the exact scan.
+    # + fp32 re-score) must return the exact fp32 scan's ids AND scores bit for bit (RMU_OPT_SCREEN switches the path).
     nchk = min(B, 256)
-    index.set_timing(False)
     identical, path_chk = None, 0
     if not args.no_identity_check:
         s_def, r_def = index.search(q[:nchk], K)
         path_chk = index.last_screened()
-        s_ex, r_ex = index.search(q[:nchk], max(K, 25))
-        identical = bool(torch.equal(torch.as_tensor(r_def), torch.as_tensor(r_ex)[:, :K]) and
-                         torch.equal(torch.as_tensor(s_def), torch.as_tensor(s_ex)[:, :K]))
+        index.set_screening(False)
+        s_ex, r_ex = index.search(q[:nchk], K)
+        index.set_screening(True)
+        identical = bool(torch.equal(r_def, r_ex) and torch.equal(s_def, s_ex))
     if world > 1 and identical is not None:
         t = torch.tensor([1.0 if identical else 0.0], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         identical = bool(t.item() > 0.5)
+
+    roofline = None
+    if not args.no_kernel_timing:     # every rank runs it (same launches); rank 0 reports its own shard's kernel
+        roofline = scan_roofline(index, lambda: index.search(q, K), n_local, D, B, K, steps=max(3, min(args.steps, 10)))
 
     if rank != 0:
         if world > 1:
@@ -174,77 +430,63 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     qps = B * args.steps / elapsed
-    scan_avg_ms = float(np.mean(scan_ms))
-    # algorithmic work of ONE scan launch on this rank's shard (DESIGN.md "roofline" section)
-    flops = 2.0 * n_local * D * B
-    # algorithmic bytes: the shard read ONCE + queries in + (score,row) out.  The 8 query tiles of a
-    # 1024-query batch share each corpus chunk through one XCD's L2, so one pass is the honest figure.
-    bytes_alg = n_local * D * 4 + B * D * 4 + B * K * 12
-    ach_tf = flops / (scan_avg_ms * 1e-3) / 1e12
-    ach_gbs = bytes_alg / (scan_avg_ms * 1e-3) / 1e9
-    f_mfma, f_hbm = ach_tf / PEAK_F32_MFMA_TFLOPS, ach_gbs / PEAK_HBM_GBS
-    wq = 1 if B <= 32 else (2 if B <= 64 else 4)
-    kname = {4: "scan_topk_kernel<D=384,WQ=4,CK=96,RING=4,CAP=64>", 2: "scan_topk_kernel<D=384,WQ=2,CK=96,RING=3,CAP=64>",
-             1: "scan_topk_kernel<D=384,WQ=1,CK=48,RING=3,CAP=64>"}[wq]
-    # HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE [gfx950 correction] + WRITE_SIZE), measured on this
-    # exact configuration and committed under profiles/; null for any other configuration.
-    traffic = None
-    if world == 1 and N == 10_000_000 and D == 384 and K == 10 and B in (1024, 1):
-        traffic = {1024: 2 * 7.876e6 * 1024 + 6070 * 1024, 1: 2 * 7.504e6 * 1024}[B]
-    path = "exact-f32"
-    rerun = 0
-    if all(v != 0 for v in screened):
-        # answered by the fp16 screening scan (one f16 MFMA per 16 k over the fp16 image of the corpus) + exact fp32
-        # re-score of 32 candidates per query; queries failing the sufficiency test are re-run on the exact scan
-        # (`rerun_queries`), so results are bit-identical to the exact path.  Roof: dense f16 MFMA.
-        path = "screen-f16+rescore-f32"
-        rerun = sum(-v for v in screened if v < 0)
-        kname = (f"scan_screen_kernel<G={2 if B > 128 else 1}> (D=384, {256 if B > 128 else 128} queries/WG, 32-row tiles as two 12-KiB half-k chunks, "
-                 f"{6 if B > 128 else 8}-slot LDS-DMA ring), one launch per row range of the threshold ladder")
-        f_mfma = ach_tf / PEAK_F16_MFMA_TFLOPS
-        traffic = SCREEN_TRAFFIC.get(B) if (world == 1 and N == 10_000_000 and K == 10) else None
-        # the screen streams the fp16 image (768 B per row), not the fp32 rows: its HBM roof is priced on those bytes
-        img_gbs = n_local * 768 / (scan_avg_ms * 1e-3) / 1e9
-        if f_mfma >= img_gbs / PEAK_HBM_GBS:
-            roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F16_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(f_mfma, 4), "rerun_queries": rerun}
-        else:
-            roofline = {"kernel": kname, "bound": "hbm", "achieved": round(img_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(img_gbs / PEAK_HBM_GBS, 4), "rerun_queries": rerun,
-                        "bytes_basis": "fp16 screening image, 768 B per row, once per batch"}
-    elif f_mfma >= f_hbm:
-        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(ach_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
-    else:
-        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(f_hbm, 4)}
-    roofline.update({"traffic": traffic, "traffic_source": "profiles/r01_pmc_means.csv (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024)" if traffic else None,
-                     "kernel_ms": round(scan_avg_ms, 4), "algorithmic_bytes": bytes_alg, "algorithmic_flops": flops,
-                     "path": path, "algorithmic_TFLOPs": round(ach_tf, 2),
-                     "hbm_algorithmic_GBs": round(ach_gbs, 1), "hbm_frac_of_8TBs": round(f_hbm, 4), "launch": geom})
 
-    # ---- CPU baseline + recall on a bounded sample (rank 0, N=1 only) -------------------------------
+    # ---- secondary legs (N = 1): the other BASELINE configurations, each with its own roofline -------
+    secondary = []
+
+    def scan_leg(name, idx, qq, n_rows, steps, note=None):
+        nq = qq.shape[0]
+        ms = timed(lambda: idx.search(qq, K), steps=steps, warmup=2)
+        leg = {"name": name, "value": round(nq / (ms * 1e-3), 1), "unit": "queries/sec", "ms_per_step": round(ms, 4),
+               "config": {"workload": f"{n_rows}x{D} fp32 unit-norm corpus, batch {nq} queries, top-{K}, inner product"},
+               "roofline": scan_roofline(idx, lambda: idx.search(qq, K), n_rows, D, nq, K, steps=min(steps, 5))}
+        if note:
+            leg["note"] = note
+        return leg
+
+    if "exact" in legs:
+        index.set_screening(False)
+        secondary.append(scan_leg("exact fp32 scan only (RMU_OPT_SCREEN = 0), same workload as the headline", index, q, n_local, 4))
+        index.set_screening(True)
+    for b in (128, 32, 1):
+        if f"b{b}" in legs and B >= b:
+            secondary.append(scan_leg(f"HBM-bound regime: batch {b}" + (" (the reference's one query per call)" if b == 1 else ""),
+                                      index, q[:b].contiguous(), n_local, 20))
+    if "c2" in legs and x1m is not None:
+        i2 = FlatIndex(D, _native.METRIC_IP, capacity_hint=x1m.shape[0], device=local_rank)
+        i2.add(x1m)
+        q2 = x1m[:B] + 0.1 * torch.randn((B, D), generator=gq, dtype=torch.float32, device=device)
+        q2 /= q2.norm(dim=1, keepdim=True)
+        secondary.append(scan_leg("C2 1M x 384, batch 1024 (BASELINE.json configs[1])", i2, q2.contiguous(), x1m.shape[0], 20))
+        i2.close()
+
+    # ---- CPU baselines + recall on a bounded sample ------------------------------------------------------
     cpu = None
     recall = None
-    if world == 1 and sample_host is not None:
-        from oracle import oracle as O
-        nq_s = min(B, 1024)          # ~10-20 s of CPU work on the GPU box's host cores
+    cpu_single = None
+    if sample_host is not None:
+        nq_s = min(B, 1024)
         qh = q[:nq_s].cpu().numpy()
-        threads = os.cpu_count() or 1
-        t1 = time.perf_counter()
-        cs, cr = O.flat_search_f32_blas(qh, sample_host, K)
-        cpu_t = time.perf_counter() - t1
-        # scale to the metric's unit: queries/sec over the full N-row corpus
-        cpu_qps = nq_s / (cpu_t * (N / sample_host.shape[0]))
-        cpu = {"value": round(cpu_qps, 3), "unit": "queries/sec", "cores": threads, "kind": "port",
-               "sample": f"{nq_s} queries x first {sample_host.shape[0]} rows, numpy/OpenBLAS sgemm+argpartition "
-                         f"({cpu_t:.2f} s), scaled linearly to {N} rows"}
+        cb = cpu_search_baselines(qh, sample_host, N, K)
+        cpu, cpu_single = cb["batch"], cb["single"]
         sub = FlatIndex(D, _native.METRIC_IP, capacity_hint=sample_host.shape[0])
         sub.add(sample_host)
         gs, gr = sub.search(qh, K)
-        recall = float(np.mean([len(set(gr[i]) & set(cr[i])) / K for i in range(nq_s)]))
+        recall = float(np.mean([len(set(gr[i]) & set(cb["rows"][i])) / K for i in range(nq_s)]))
         sub.close()
+        for leg in secondary:
+            if leg["name"].startswith("HBM-bound regime: batch 1 "):
+                leg["cpu_baseline"] = cpu_single
+            elif leg["unit"] == "queries/sec" and "cpu_baseline" not in leg and leg["config"]["workload"].startswith(f"{N}x"):
+                leg["cpu_baseline"] = cpu
+    index.close()
+    torch.cuda.empty_cache()
+    if "embed" in legs:
+        secondary.append(leg_embed(args))
+    if "rerank" in legs and x1m is not None:
+        secondary.append(leg_rerank(args, x1m))
 
+    path = roofline["path"] if roofline else "unknown"
     line = {
         "metric": "queries/sec, exact dense top-10 over an HBM-resident 10Mx384 fp32 corpus",
         "value": round(qps, 1), "unit": "queries/sec",
@@ -254,10 +496,12 @@ def main():
         "dtype": "f16 screen (fp32 accumulate) + f32 re-score" if path.startswith("screen") else "f32", "data": "synthetic",
         "config": {"workload": f"{N}x{D} fp32 unit-norm corpus, batch {B} queries, top-{K}, inner product",
                    "rows": N, "dim": D, "batch": B, "k": K,
-                   "parallelism": f"row-shard x{world}" + (" + 1 RCCL all-gather of per-shard top-k" if world > 1 else "")},
+                   "parallelism": f"row-shard x{world}" + (" + 1 RCCL all-gather of per-shard top-k" if world > 1 else ""),
+                   "exchange": exchange},
         "recall_at_10": recall, "planted_top1": top1_ok, "sorted": sorted_ok,
-        "identical_to_exact_f32_scan": identical, "identical_check": f"{nchk} queries x full shard, ids and scores bit-equal; default path answered by {'screen' if path_chk != 0 else 'exact'}",
-        "roofline": roofline, "cpu_baseline": cpu,
+        "identical_to_exact_f32_scan": identical,
+        "identical_check": f"{nchk} queries x full shard, ids and scores bit-equal; default path answered by {'screen' if path_chk != 0 else 'exact'}",
+        "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary, "host_cores": os.cpu_count(),
     }
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -4,6 +4,7 @@
 // and the 8-GPU shard merge after the RCCL all-gather.  One wave per query streams
 // the `parts*k` candidate keys in batches of 64, sorts each batch with a shuffle bitonic network and
 // folds it into the running (sorted) top-K with one half-cleaner + bitonic merge.
+#include <cstdlib>
 #include "rmu_common.h"
 #include "../../include/rmu.h"
 
@@ -167,6 +168,95 @@ __global__ __launch_bounds__(1024) void merge_wg_kernel(const u64* __restrict__ 
     }
 }
 
+// k <= 32: merge by SELECTION instead of sorting -- no shuffle network at all.  One workgroup per query:
+//   A. heads[p] = best key of part p; tau = the k-th largest head (enumeration rank over LDS broadcasts).  k distinct parts
+//      hold a key >= tau, so the final k-th best is >= tau and only keys >= tau can be in the result;
+//   B. every wave walks its parts rank slab by rank slab (the lists are sorted, zeros last: a slab without a key >= tau
+//      ends that batch) and appends the keys >= tau to an LDS array -- at most k parts x k keys = k^2 <= 1024 of them;
+//   C. enumeration rank among those; rank < k -> output position rank.
+// The wave-serial sort/merge rounds of merge_wg_kernel (27 dependent 64-bit shuffle steps per 64 keys) made a ladder merge
+// cost 40 us -- six of them were 0.24 ms of a 1.7 ms HBM-bound batch; this form is a few LDS sweeps.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void merge_select_kernel(const u64* __restrict__ partial, int parts, int64_t nq, int k,
+                                                             MergeOut o, RmuCond cond) {
+    constexpr int CAPM = 1024, MAXP = 1024;
+    __shared__ u64 heads[MAXP];
+    __shared__ u64 cand[CAPM];
+    __shared__ u64 tau_s;
+    __shared__ u32 count;
+    int64_t nq_eff = nq;
+    if (cond.p) {
+        const int c = *cond.p;
+        if (c < cond.lo || c > cond.hi) return;           // uniform over the grid
+        if (cond.clamp && c < nq_eff) nq_eff = c;
+    }
+    const int64_t q = blockIdx.x;
+    if (q >= nq_eff) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int NW = BLOCK / 64;
+    const u64* base = partial + q * k;
+    const int64_t pstride = nq * k;
+    for (int p = tid; p < parts; p += BLOCK) heads[p] = base[(int64_t)p * pstride];
+    if (tid == 0) { count = 0u; tau_s = 0ull; }
+    __syncthreads();
+    if (parts >= k) {
+        for (int p = tid; p < parts; p += BLOCK) {
+            const u64 mine = heads[p];
+            int rank = 0;
+            for (int j = 0; j < parts; ++j) rank += heads[j] > mine ? 1 : 0;
+            if (mine != 0ull && rank == k - 1) tau_s = mine;      // keys are distinct: exactly one writer (or none)
+        }
+        __syncthreads();
+    }
+    const u64 tau = tau_s;
+    for (int pb = w * 16; pb < parts; pb += NW * 16) {
+        const int part = pb + (lane >> 2);
+        for (int s0 = 0; s0 < k; s0 += 4) {
+            const int pos = s0 + (lane & 3);
+            u64 key = 0ull;
+            if (part < parts && pos < k) key = base[(int64_t)part * pstride + pos];
+            const bool take = key != 0ull && key >= tau;
+            const u64 bal = __ballot(take);
+            if (!bal) break;
+            u32 at = 0;
+            if (lane == 0) at = atomicAdd(&count, (u32)__builtin_popcountll(bal));
+            at = __shfl(at, 0) + (u32)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            if (take && at < (u32)CAPM) cand[at] = key;
+        }
+    }
+    __syncthreads();
+    const u32 m = count < (u32)CAPM ? count : (u32)CAPM;
+    const int64_t qo = o.scatter ? o.scatter[q] : q;
+    auto emit = [&](int e, u64 key) {
+        if (o.keys) {
+            o.keys[qo * k + e] = key;
+            if (o.seed_thr && e == k - 1 && key) atomicMax(o.seed_thr + qo, (u32)(key >> 32));
+        }
+        if (o.scores) {
+            float sc;
+            int64_t r;
+            if (key == 0ull) {
+                sc = o.l2_out ? INFINITY : -INFINITY;
+                r = -1;
+            } else {
+                sc = rmu_key_score(key);
+                if (o.l2_out) sc = fmaxf(o.qnorm2[q] - sc, 0.f);
+                r = (int64_t)rmu_key_row(key) + o.row_base;
+            }
+            o.scores[qo * k + e] = sc;
+            o.rows[qo * k + e] = r;
+        }
+    };
+    for (u32 i = tid; i < m; i += BLOCK) {
+        const u64 mine = cand[i];
+        u32 rank = 0;
+        for (u32 j = 0; j < m; ++j) rank += cand[j] > mine ? 1u : 0u;
+        if (rank < (u32)k) emit((int)rank, mine);
+    }
+    for (int e = tid; e < k; e += BLOCK)
+        if ((u32)e >= m) emit(e, 0ull);
+}
+
 // generic lists (scores fp32 + int64 rows; part p at scores + p*stride_s / rows + p*stride_r, each [nq, k]); ties resolve
 // to the lower candidate index, i.e. the lower part, then the earlier position -- equal to (score, row) order when
 // parts arrive in ascending row ranges.  smaller_better: the scores are distances (keys are built from -score).
@@ -209,6 +299,12 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
 
 static int merge_wg_launch(const u64* partial, int parts, int64_t nq, int k, const MergeOut& o, const RmuCond& cond, hipStream_t s) {
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
+    static const int use_select = getenv("RMU_MERGE_SELECT") ? atoi(getenv("RMU_MERGE_SELECT")) : 1;
+    if (use_select && k <= 32 && parts <= 1024) {          // selection merge: one workgroup per query
+        if (nq <= 512) hipLaunchKernelGGL(merge_select_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, s, partial, parts, nq, k, o, cond);
+        else hipLaunchKernelGGL(merge_select_kernel<256>, dim3((unsigned)nq), dim3(256), 0, s, partial, parts, nq, k, o, cond);
+        return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+    }
     // waves per query: ~16 parts per wave, and at least ~2k waves in flight when the batch is small
     int wpq = 1;
     while (wpq < 16 && parts > 16 * wpq) wpq <<= 1;
