@@ -14,10 +14,12 @@
 // v_mfma_f32_16x16x32_bf16 on 128x128x64 tiles staged through LDS by LDS-DMA (global_load_lds_dwordx4) with the
 // XOR swizzle applied to the per-lane SOURCE address (the DMA writes lane-linear).  Operands are swapped
 // (D^T = W . A^T) so a lane ends up with 4 consecutive output features of one token: 8-byte bf16 stores.
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rmu_common.h"
@@ -46,6 +48,50 @@ __device__ __forceinline__ float fast_erf(float x) {
     return copysignf(r, x);
 }
 
+// GELU(erf) for the fused FFN kernel, where one wave per SIMD has to fit the activation into the MFMA shadow: no
+// reciprocal, no exponential.  erf(t) ~= clamp(tc * P(tc^2), -1, 1), tc = clamp(t, -3, 3), P of degree 7 (minimax fit on
+// [0, 3]): |error| <= 1e-4 in erf, i.e. <= 5e-5 |v| in GELU -- an order of magnitude below the bf16 rounding of the result.
+__device__ __forceinline__ float gelu_poly(float v) {
+    const float t = v * 0.70710678118654752f;
+    const float tc = __builtin_amdgcn_fmed3f(t, -3.0f, 3.0f);
+    const float u = tc * tc;
+    float p = -4.055360137e-07f;
+    p = fmaf(p, u, 1.715983126e-05f);
+    p = fmaf(p, u, -3.145953815e-04f);
+    p = fmaf(p, u, 3.318710718e-03f);
+    p = fmaf(p, u, -2.268579789e-02f);
+    p = fmaf(p, u, 1.077178270e-01f);
+    p = fmaf(p, u, -3.732314110e-01f);
+    p = fmaf(p, u, 1.127895713e+00f);
+    const float e = __builtin_amdgcn_fmed3f(tc * p, -1.0f, 1.0f);
+    const float hv = 0.5f * v;
+    return fmaf(hv, e, hv);
+}
+
+// the same on four values at once, written with vector operations so that every polynomial step is emitted for all four
+// elements before the next step (four independent dependency chains in flight instead of one)
+__device__ __forceinline__ f32x4 gelu_poly4(f32x4 v) {
+    auto sp = [](float c) { return f32x4{c, c, c, c}; };
+    const f32x4 t = v * 0.70710678118654752f;
+    f32x4 tc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tc[e] = __builtin_amdgcn_fmed3f(t[e], -3.0f, 3.0f);
+    const f32x4 u = tc * tc;
+    f32x4 p = __builtin_elementwise_fma(sp(-4.055360137e-07f), u, sp(1.715983126e-05f));
+    p = __builtin_elementwise_fma(p, u, sp(-3.145953815e-04f));
+    p = __builtin_elementwise_fma(p, u, sp(3.318710718e-03f));
+    p = __builtin_elementwise_fma(p, u, sp(-2.268579789e-02f));
+    p = __builtin_elementwise_fma(p, u, sp(1.077178270e-01f));
+    p = __builtin_elementwise_fma(p, u, sp(-3.732314110e-01f));
+    p = __builtin_elementwise_fma(p, u, sp(1.127895713e+00f));
+    const f32x4 ep = tc * p;
+    f32x4 e4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) e4[e] = __builtin_amdgcn_fmed3f(ep[e], -1.0f, 1.0f);
+    const f32x4 hv = v * 0.5f;
+    return __builtin_elementwise_fma(hv, e4, hv);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------------------
@@ -56,6 +102,16 @@ __global__ void k_f32_to_bf16(const float* __restrict__ src, bf16* __restrict__ 
 __global__ void k_scale_copy(const float* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i] * scale;
+}
+
+// W2 copy for k_ffn_fused: inside every block of 16 columns, slot 8 h + e holds column (e < 4 ? 4 h + e : 8 + 4 h + e - 4)
+// -- the order in which a lane half h of GEMM1's 32x32 accumulator layout holds 8 of the block's 16 features (see k_ffn_fused)
+__global__ void k_permute_w2(const bf16* __restrict__ src, bf16* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t blk = i & ~(int64_t)15;
+    const int s16 = (int)(i & 15), h = s16 >> 3, e = s16 & 7;
+    dst[i] = src[blk + (e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4))];
 }
 
 // cu[0] = 0, cu[b+1] = cu[b] + clamp(lens[b], 0, max_len); one block
@@ -440,6 +496,339 @@ __global__ __launch_bounds__(512) void k_gemm_ln(const bf16* __restrict__ A, con
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Fused FFN block: out = LayerNorm( GELU(h1 . W1^T + b1) . W2^T + b2 + h1 ) for a tile of 128 tokens.
+//
+// Unfused, the 1536-wide intermediate makes two HBM round trips per layer (3.2 GB written by FFN1, read again by FFN2),
+// the pre-LN sum a third and the LayerNorm a fourth; here the intermediate never leaves the registers:
+//   * 4 waves (one per SIMD, 512-register budget), wave w owns tokens [32w, 32w+32) of the tile for the WHOLE kernel:
+//     its h1 rows are v_mfma_f32_32x32x16_bf16 B-fragments held in registers (96), the FFN2 accumulators for all 384
+//     outputs too (192);
+//   * the 1536 intermediate features are walked in 24 chunks of 64 (two MFMA tiles; with 128 the accumulators would fill
+//     all 256 AGPRs and hipcc then spills the token fragments to scratch, whose reloads wait vmcnt(0) and drain the
+//     LDS-DMA ring at every k-step): GEMM1 (K = 384) into 32 accumulator registers
+//     (initialised with the bias), GELU(erf) + bf16 rounding (the same rounding point as the unfused `mid` tensor), and the
+//     result is used DIRECTLY as the B operand of GEMM2: with swapped operands (A = weights) the D layout -- lane = token,
+//     registers 8s .. 8s+7 = features {4h+e, 8+4h+e} of the 16-block s -- is a k-permuted B fragment of k-step s, and the
+//     W2 copy this kernel reads has the columns of every 16-block permuted the same way (k_permute_w2);
+//   * only the weights stream: W1 in [64 x 128] slabs, W2 in [384 x 32] slabs through a 4-slot LDS-DMA ring with
+//     counted vmcnt (XOR swizzles on the source address as in k_gemm); 5 slabs = 5 barriers per chunk;
+//   * a lone wave per SIMD hides only ~5 single-issue instructions behind a 32-cycle MFMA (MI355X_MICROARCH.md), so the
+//     inner loops are ONE fragment read (address = per-k-step base register + literal offset), ONE counted wait and ONE
+//     MFMA per step, four reads in flight; the activation of the next 32 features is slotted between GEMM2's MFMAs;
+//   * epilogue as k_gemm_ln: bf16(acc + b2) parked in LDS, residual added, LayerNorm per token row.
+// Weight traffic L2->LDS: 2.36 MB per 128 tokens (the layer's FFN weights stay L2-resident).
+// ------------------------------------------------------------------------------------------------------------
+namespace ffn {
+constexpr int TOK = 128, CH = 64, NCH = FF / CH;      // tokens per tile, intermediate features per chunk, chunks
+constexpr int SLOT = 24 * 1024, NSLOT = 4;            // ring slot (holds the larger slab type), slots (a power of two)
+constexpr int W1_SLABS = 3, W2_SLABS = 2, PERIOD = W1_SLABS + W2_SLABS;
+constexpr int W1_NI = 4, W2_NI = 6;                    // LDS-DMA wave-instructions per wave per slab
+constexpr int TSTR = H * 2 + 16;                       // pre-LN tile row stride (epilogue, reuses the ring)
+constexpr int B1_OFF = NSLOT * SLOT > TOK * TSTR ? NSLOT * SLOT : ((TOK * TSTR + 255) / 256) * 256;   // b1 (1536 fp32) behind ring / tile
+constexpr int LDS_BYTES = B1_OFF + FF * 4;
+constexpr int PRE = 4;                                 // fragment reads in flight
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+__host__ __device__ constexpr int slab_ni(int t) { return (t % PERIOD) < W1_SLABS ? W1_NI : W2_NI; }
+// DMA instructions that may still be in flight when slab t must have landed: those of slabs t+1 .. t+NSLOT-2
+__host__ __device__ constexpr int wait_n(int t) {
+    int n = 0;
+    for (int u = 1; u <= NSLOT - 2; ++u) n += slab_ni(t + u);
+    return n;
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}) -- the index is a
+// constant expression inside f, which inline-asm immediates (ds_read offset:, s_waitcnt) require
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int OFF>
+__device__ __forceinline__ void ds_read16(bf16x8& d, u32 addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void frag_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(PRE - 1)); }
+// a wave-uniform pointer pinned into an SGPR pair: `sgpr_ptr(base) + lane_offset` then selects the saddr + 32-bit voffset
+// form of global_load_lds (left alone hipcc re-associates base + stride + offset into 64-bit VGPR adds per instruction)
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+}  // namespace ffn
+
+template <bool DBG>      // DBG: cycle counters into `dbg` (RMU_FFN_DBG diagnostics); the product instantiation carries none of it
+__global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, const bf16* __restrict__ W1,
+                                                   const float* __restrict__ b1, const bf16* __restrict__ W2,
+                                                   const float* __restrict__ b2, const float* __restrict__ g,
+                                                   const float* __restrict__ bta, float eps, bf16* __restrict__ out,
+                                                   const int* __restrict__ cu, int batch,
+                                                   unsigned long long* __restrict__ dbg /* RMU_FFN_DBG: cycle counters, else null */) {
+    using namespace ffn;
+    const unsigned long long t_begin = DBG ? clock64() : 0;
+    unsigned long long t_wait = 0, t_g1 = 0, t_g2 = 0;
+    const int M = cu[batch];
+    const int m0 = blockIdx.x * TOK;
+    if (m0 >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31, hh = lane >> 5;       // MFMA 32x32x16: row / column of the operand tile, k-half
+    char* ring = gsm;
+    float* b1s = (float*)(gsm + B1_OFF);
+
+    // ---- h1 rows of this wave as B fragments (k-step ks covers k [16 ks, +16); lane half hh owns 8 of them), and b1 into
+    // LDS: all ordinary loads are issued and waited for BEFORE the first LDS-DMA (an ordinary load beside an in-flight DMA
+    // makes hipcc drain the ring) ------------------------------------------------------------------------------------------
+    bf16x8 hf[24];
+    {
+        const int tok = min(m0 + 32 * w + r31, M - 1);
+        const bf16* row = h1 + (int64_t)tok * H + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) hf[ks] = *(const bf16x8*)(row + ks * 16);
+    }
+    for (int i = threadIdx.x; i < FF; i += 256) b1s[i] = b1[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- slab stream: slab (c, i), i < 3: W1 rows [64 c, +64) x k [128 i, +128);  i >= 3: W2 rows [0, 384) x
+    // k [64 c + 32 (i - 3), +32).  Slabs past the last chunk re-load the last chunk (keeps the vmcnt bookkeeping uniform).
+    // Per-lane byte offsets are fixed for the whole kernel; a DMA issue is scalar base + 32-bit lane offset (no VALU).
+    // (LDS unit f = (it * 4 + w) * 64 + lane of a slab: W1 row f >> 4, W2 row f >> 2; the swizzle term of a lane does not
+    // depend on `it`, so instruction `it` is the lane's offset for it = 0 plus a SCALAR stride: 16 W1 rows / 64 W2 rows)
+    u32 w1off0, w2off0;
+    {
+        const int f = w * 64 + lane;
+        const int row1 = f >> 4, p1 = f & 15;
+        w1off0 = (u32)((row1 * H + ((p1 ^ (row1 & 15)) * 8)) * 2);
+        const int row2 = f >> 2, p2 = f & 3;
+        w2off0 = (u32)((row2 * FF + ((p2 ^ ((row2 >> 2) & 3)) * 8)) * 2);
+    }
+    // DMA instruction `it` of slab number i of the period (compile time) for chunk cc (run time, clamped), into ring slot
+    // `slotn`.  One at a time: an LDS-DMA issue costs the wave 60-180 cycles (MI355X_MICROARCH.md), so the instructions of a
+    // slab are handed out BETWEEN the MFMAs of the slab being computed, not as a burst behind the barrier.
+    auto issue_part = [&](int cc, int i, int slotn, int it) {
+        if (cc >= NCH) cc = NCH - 1;
+        char* slot = ring + slotn * SLOT;
+        if (i < W1_SLABS) {
+            const char* sbase = (const char*)W1 + ((size_t)cc * CH * H + (size_t)i * 128) * 2;
+            u32 o = w1off0;
+            asm volatile("" : "+v"(o));      // opaque: keeps hipcc from hoisting base + offset into loop-invariant 64-bit VGPR pairs
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(sbase + (size_t)it * (16 * H * 2)) + o),
+                                             (__attribute__((address_space(3))) void*)(slot + (it * 4 + w) * 1024), 16, 0, 0);
+        } else {
+            const char* sbase = (const char*)W2 + ((size_t)cc * CH + (size_t)(i - W1_SLABS) * 32) * 2;
+            u32 o = w2off0;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(sbase + (size_t)it * (64 * FF * 2)) + o),
+                                             (__attribute__((address_space(3))) void*)(slot + (it * 4 + w) * 1024), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int cc, int i, int slotn) {
+        const int ni = i < W1_SLABS ? W1_NI : W2_NI;
+#pragma unroll
+        for (int it = 0; it < W2_NI; ++it)
+            if (it < ni) issue_part(cc, i, slotn, it);
+    };
+
+    f32x16 acc2[12];                                // [output feature tile of 32]: rows = output features, columns = tokens
+#pragma unroll
+    for (int o = 0; o < 12; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[o][r] = 0.f;
+
+    // Fragment addressing.  W1 slab image: [128 rows][16 units of 16 B], unit u of row r at physical unit u ^ (r & 15);
+    // fragment (feature tile ft, k-step ks) of lane (row r31, half hh) = unit 2 ks + hh of row 32 ft + r31: one base register
+    // per k-step, the feature tile is the literal offset ft * 8192.  W2 slab image: [384 rows][4 units], physical unit
+    // u ^ ((r >> 2) & 3); fragment (output tile ot, k-step s) = unit 2 s + hh of row 32 ot + r31: base per s, offset ot * 2048.
+    const u32 ring_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    u32 a1rel[8], a2rel[2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) a1rel[ks] = (u32)(r31 * 256 + (((2 * ks + hh) ^ (r31 & 15)) * 16));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) a2rel[s2] = (u32)(r31 * 64 + (((2 * s2 + hh) ^ ((r31 >> 2) & 3)) * 16));
+    bf16x8 fq[PRE];
+#pragma unroll
+    for (int m = 0; m < PRE; ++m) fq[m] = bf16x8{};
+
+    static_assert(NSLOT - 1 <= PERIOD, "prologue stays inside chunk 0");
+#pragma unroll
+    for (int t = 0; t < NSLOT - 1; ++t) issue(0, t, t);
+    int slot_cur = 0;                               // ring slot of the slab being consumed (run time: 84 slabs over 4 slots)
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pfu[2][2];                                // [tile parity][k-step]: B fragments of GEMM2 (current / next tile), as dwords
+    for (int c = 0; c < NCH; ++c) {
+        // GEMM1 accumulators start from the bias: register 4q + e of lane half hh <-> feature 32 ft + 8 q + 4 hh + e
+        f32x16 acc1[2];                             // [intermediate feature tile of 32]
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4*)(b1s + c * CH + ft * 32 + q * 8 + hh * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[ft][4 * q + e] = bv[e];
+            }
+        // activation of register group q (4 values) of feature tile t -> two dwords of the B fragment of k-step q / 2
+        auto gelu_group = [&](int t, int q) {
+            f32x4 v = {acc1[t][4 * q], acc1[t][4 * q + 1], acc1[t][4 * q + 2], acc1[t][4 * q + 3]};
+            asm volatile("" : "+v"(v));              // program-order anchor: the work below cannot be hoisted above this point
+            const f32x4 r = gelu_poly4(v);
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            bf16x2 lo, hi;
+            lo[0] = (bf16)r[0]; lo[1] = (bf16)r[1]; hi[0] = (bf16)r[2]; hi[1] = (bf16)r[3];
+            u32 d0 = __builtin_bit_cast(u32, lo), d1 = __builtin_bit_cast(u32, hi);
+            asm volatile("" : "+v"(d0), "+v"(d1));   // ... nor sunk below this one: the group stays in the MFMA shadow it was given
+            pfu[t & 1][q >> 1][(q & 1) * 2] = d0;
+            pfu[t & 1][q >> 1][(q & 1) * 2 + 1] = d1;
+        };
+        static_for<PERIOD>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            // slab i of the chunk has landed (own DMA) once only the younger slabs' instructions are outstanding; own LDS reads
+            // returned; after the barrier every wave is done with the slot that the new issue refills
+            const unsigned long long tw0 = DBG ? clock64() : 0;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(wait_n(i)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (DBG) t_wait += clock64() - tw0;
+            // the slab prefetched now (NSLOT - 1 ahead) goes into the slot everyone finished reading before this barrier
+            constexpr int pi = (i + NSLOT - 1) % PERIOD, pni = pi < W1_SLABS ? W1_NI : W2_NI;
+            const int pc = c + (i + NSLOT - 1) / PERIOD, pslot = (slot_cur + NSLOT - 1) & (NSLOT - 1);
+            const u32 sa = ring_addr + (u32)slot_cur * SLOT;
+            slot_cur = (slot_cur + 1) & (NSLOT - 1);
+            const unsigned long long tc0 = DBG ? clock64() : 0;
+            if constexpr (i < W1_SLABS) {
+                // GEMM1: 8 k-steps x 2 feature tiles = 16 fragments, n = ks * 2 + ft; A = W1 rows (32 intermediate features
+                // x 16 k), B = the token fragments in registers
+                // The LAST k-slab runs feature tile 0 first (n = ft * 8 + ks): tile 0 is complete after 8 steps and the first half
+                // of its activation (k-step 0 of GEMM2) is computed in the shadow of tile 1's MFMAs.
+                constexpr bool last = i == W1_SLABS - 1;
+                static_for<PRE>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int ks = last ? (n & 7) : (n >> 1), ft = last ? (n >> 3) : (n & 1);
+                    ds_read16<ft * 8192>(fq[n], sa + a1rel[ks]);
+                });
+                static_for<16>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int ks = last ? (n & 7) : (n >> 1), ft = last ? (n >> 3) : (n & 1);
+                    frag_wait(fq[n % PRE]);
+                    acc1[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PRE], hf[i * 8 + ks], acc1[ft], 0, 0, 0);
+                    constexpr int nn = n + PRE < 16 ? n + PRE : 15;      // tail: re-read the last fragment (keeps the count uniform)
+                    constexpr int ks2 = last ? (nn & 7) : (nn >> 1), ft2 = last ? (nn >> 3) : (nn & 1);
+                    ds_read16<ft2 * 8192>(fq[n % PRE], sa + a1rel[ks2]);
+                    if constexpr (n % 2 == 1 && n / 2 < pni) issue_part(pc, pi, pslot, n / 2);     // steps 1, 3, 5, ...
+                    if constexpr (last && n == 10) gelu_group(0, 0);
+                    if constexpr (last && n == 13) gelu_group(0, 1);
+                });
+            } else {
+                // GEMM2 over feature tile t = i - 3 of the chunk: 2 k-steps x 12 output tiles = 24 fragments, n = s * 12 + ot.
+                // The activations are slotted between MFMAs (schedule below), so their VALU work sits in the MFMA shadow.
+                constexpr int t = i - W1_SLABS;
+                u32 ab[2];
+                ab[0] = sa + a2rel[0];
+                ab[1] = sa + a2rel[1];
+                static_for<PRE>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    ds_read16<(n % 12) * 2048>(fq[n], ab[n / 12]);
+                });
+                static_for<24>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int s2 = n / 12, ot = n % 12;
+                    frag_wait(fq[n % PRE]);
+                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PRE], __builtin_bit_cast(bf16x8, pfu[t & 1][s2]), acc2[ot], 0, 0, 0);
+                    constexpr int nn = n + PRE < 24 ? n + PRE : 23;
+                    ds_read16<(nn % 12) * 2048>(fq[n % PRE], ab[nn / 12]);
+                    // activation schedule: every 12-MFMA half-slab carries two register groups, each the half-slab before the
+                    // k-step that consumes it: tile 0 k-step 1 | tile 1 k-step 0 | tile 1 k-step 1 | (none)
+                    if constexpr (t == 0 && n == 2) gelu_group(0, 2);
+                    if constexpr (t == 0 && n == 7) gelu_group(0, 3);
+                    if constexpr (t == 0 && n == 14) gelu_group(1, 0);
+                    if constexpr (t == 0 && n == 19) gelu_group(1, 1);
+                    if constexpr (t == 1 && n == 2) gelu_group(1, 2);
+                    if constexpr (t == 1 && n == 7) gelu_group(1, 3);
+                    if constexpr (n % 4 == 0 && n / 4 < pni) issue_part(pc, pi, pslot, n / 4);     // steps 0, 4, 8, ...
+                });
+            }
+            if (DBG) { if (i < W1_SLABS) t_g1 += clock64() - tc0; else t_g2 += clock64() - tc0; }
+        });
+    }
+    if (DBG && lane == 0) {     // [0] cycles waiting for slabs + barrier, [1] main-loop cycles, [2] wave count
+        atomicAdd(dbg + 0, t_wait);
+        atomicAdd(dbg + 1, (unsigned long long)(clock64() - t_begin));
+        atomicAdd(dbg + 2, 1ull);
+        atomicAdd(dbg + 3, t_g1);
+        atomicAdd(dbg + 4, t_g2);
+    }
+    // the re-reads issued past each slab's last fragment are still in flight: their registers must stay allocated until the
+    // data has landed (the compiler sees dead values and would reuse the registers under them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < PRE; ++m) asm volatile("" : "+v"(fq[m]));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the tail reloads: the ring becomes the pre-LN tile
+    __syncthreads();
+    char* tile = gsm;
+    {
+        // acc2[ot][4 q + e] = output feature n = 32 ot + 8 q + 4 hh + e of token 32 w + r31.  The residual h1[token][n] is
+        // already on chip: hf[ks], ks = 2 ot + (q >> 1), holds features 16 ks + 8 h' .. + 7 in lane half h' -- the lane needs
+        // element 8 (q & 1) + 4 hh + e of that block, which is its own register when (q & 1) == hh and the other half-lane's
+        // (lane ^ 32) otherwise: one 2-dword exchange per k-step instead of 48 scattered 8-byte global loads.
+        // y = bf16(bf16(acc + b2) + resid): the rounding points of the unfused path.
+        const int tr = 32 * w + r31;
+        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const u32x4 hv = __builtin_bit_cast(u32x4, hf[2 * ot + qq]);
+                const u32x2 own = hh ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]};      // elements 4 hh .. 4 hh + 3 of this half's 8
+                const u32x2 oth = hh ? u32x2{hv[0], hv[1]} : u32x2{hv[2], hv[3]};      // what the partner half-lane needs
+                u32x2 rcv;
+                rcv[0] = (u32)__shfl_xor((int)oth[0], 32);
+                rcv[1] = (u32)__shfl_xor((int)oth[1], 32);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int q = 2 * qq + qb;
+                    const u32x2 rs2 = (qb == hh) ? own : rcv;
+                    const bf16x4 res = __builtin_bit_cast(bf16x4, rs2);
+                    const int n = ot * 32 + q * 8 + hh * 4;
+                    const f32x4 bv = *(const f32x4*)(b2 + n);
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16)(bf2f((bf16)(acc2[ot][4 * q + e] + bv[e])) + bf2f(res[e]));
+                    *(bf16x4*)(tile + tr * TSTR + n * 2) = v;
+                }
+            }
+    }
+    __syncthreads();
+    // LayerNorm: each wave normalises its own 32 token rows; lanes 0..47 own 8 consecutive columns (16-byte accesses)
+    {
+        const bool act = lane < 48;
+        const int c0 = (act ? lane : 0) * 8;
+        float gg[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gg[i] = g[c0 + i]; bb[i] = bta[c0 + i]; }
+        for (int r = 0; r < 32; ++r) {
+            const int tr = w * 32 + r;
+            const int m = m0 + tr;
+            if (m >= M) break;                         // uniform per wave
+            const bf16x8 yv = *(const bf16x8*)(tile + tr * TSTR + c0 * 2);
+            float v[8];
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] = act ? bf2f(yv[i]) : 0.f; sm += v[i]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            const float mu = sm * (1.0f / H);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = act ? v[i] - mu : 0.f; q = fmaf(d, d, q); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rs = rsqrtf(q * (1.0f / H) + eps);
+            bf16x8 ov;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] = (bf16)((v[i] - mu) * rs * gg[i] + bb[i]);
+            if (act) *(bf16x8*)(out + (int64_t)m * H + c0) = ov;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // attention: one workgroup = (sequence, head); K rows and V^T of the whole sequence staged in LDS once; each wave
 // takes 16 queries per round (rounds of 64) and keeps its full score strip S^T[keys, 16] in registers
 // (<= 32 key tiles): exact softmax, no online rescaling.
@@ -634,6 +1023,7 @@ __global__ __launch_bounds__(128) void k_cls_head(const bf16* __restrict__ h, co
 // ------------------------------------------------------------------------------------------------------------
 struct BertLayer {
     bf16 *wqkv, *wo, *w1, *w2;
+    bf16* w2p;      // W2 with the columns of every 32-block permuted to the fused FFN kernel's k-slot order
     float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 struct rmu_bert {
@@ -738,7 +1128,11 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
         wi++;
         rc |= copy_f32(m, &L.b1, wptr[wi++], FF, 1.f, s);
         rc |= dev_alloc(m, &L.w2, (size_t)H * FF);
-        if (!rc) conv_bf16(L.w2, wptr[wi], (size_t)H * FF, 1.f, s);
+        rc |= dev_alloc(m, &L.w2p, (size_t)H * FF);
+        if (!rc) {
+            conv_bf16(L.w2, wptr[wi], (size_t)H * FF, 1.f, s);
+            hipLaunchKernelGGL(k_permute_w2, dim3((unsigned)(((size_t)H * FF + 255) / 256)), dim3(256), 0, s, (const bf16*)L.w2, L.w2p, (int64_t)H * FF);
+        }
         wi++;
         rc |= copy_f32(m, &L.b2, wptr[wi++], H, 1.f, s);
         rc |= copy_f32(m, &L.ln2g, wptr[wi++], H, 1.f, s);
@@ -823,6 +1217,27 @@ static void launch_gemm_ln(const bf16* A, const bf16* W, const float* bias, cons
                        cu, batch, K);
 }
 
+static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
+    static const bool want_dbg = getenv("RMU_FFN_DBG") != nullptr;
+    static const hipError_t attr_rc = hipFuncSetAttribute(want_dbg ? (const void*)k_ffn_fused<true> : (const void*)k_ffn_fused<false>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, ffn::LDS_BYTES);
+    (void)attr_rc;
+    static unsigned long long* dbg = nullptr;
+    if (want_dbg && !dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+    const dim3 grid((unsigned)((m_cap + ffn::TOK - 1) / ffn::TOK));
+    if (want_dbg) hipLaunchKernelGGL(k_ffn_fused<true>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
+    else hipLaunchKernelGGL(k_ffn_fused<false>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
+    if (want_dbg) {
+        unsigned long long h[5];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, dbg, 40, hipMemcpyDeviceToHost);
+        (void)hipMemset(dbg, 0, 64);
+        fprintf(stderr, "[ffn dbg] waves=%llu  cycles/wave: total=%.0f  wait(slab+barrier)=%.0f (%.1f%%)  gemm1=%.0f (per slab %.0f)  gemm2+gelu=%.0f (per slab %.0f)\n",
+                h[2], (double)h[1] / (double)h[2], (double)h[0] / (double)h[2], 100.0 * (double)h[0] / (double)h[1], (double)h[3] / (double)h[2],
+                (double)h[3] / (double)h[2] / 72.0, (double)h[4] / (double)h[2], (double)h[4] / (double)h[2] / 48.0);
+    }
+}
+
 template <int MAXT>
 static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
     static bool attr = false;
@@ -864,6 +1279,11 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
         } else {
             launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
             hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
+        }
+        static const bool fused_ffn = !(getenv("RMU_FUSED_FFN") && atoi(getenv("RMU_FUSED_FFN")) == 0);
+        if (fused_ffn) {          // FFN1 + GELU + FFN2 + residual + LayerNorm in one kernel: the 1536-wide intermediate stays on chip
+            launch_ffn_fused(m->h1, L, eps, m->h, m->cu, batch, cap, s);
+            continue;
         }
         launch_gemm<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, cap, FF, H, s);
         if (fuse_ln) {
