@@ -545,7 +545,9 @@ template <int OFF>
 __device__ __forceinline__ void ds_read16(bf16x8& d, u32 addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
-__device__ __forceinline__ void frag_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(PRE - 1)); }
+// wait until at most N fragment reads are outstanding (the oldest has landed); tied to the register the MFMA reads
+template <int N>
+__device__ __forceinline__ void frag_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
 // a wave-uniform pointer pinned into an SGPR pair: `sgpr_ptr(base) + lane_offset` then selects the saddr + 32-bit voffset
 // form of global_load_lds (left alone hipcc re-associates base + stride + offset into 64-bit VGPR adds per instruction)
 __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
@@ -706,11 +708,15 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
                 static_for<16>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     constexpr int ks = last ? (n & 7) : (n >> 1), ft = last ? (n >> 3) : (n & 1);
-                    frag_wait(fq[n % PRE]);
+                    // reads n+1 .. min(n+PRE-1, 15) may still be in flight.  NO read is issued past the slab: a fragment register
+                    // with a read in flight looks dead to hipcc, which would hand it out (as an address register!) under the data
+                    frag_wait<(16 - 1 - n < PRE - 1 ? 16 - 1 - n : PRE - 1)>(fq[n % PRE]);
                     acc1[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PRE], hf[i * 8 + ks], acc1[ft], 0, 0, 0);
-                    constexpr int nn = n + PRE < 16 ? n + PRE : 15;      // tail: re-read the last fragment (keeps the count uniform)
-                    constexpr int ks2 = last ? (nn & 7) : (nn >> 1), ft2 = last ? (nn >> 3) : (nn & 1);
-                    ds_read16<ft2 * 8192>(fq[n % PRE], sa + a1rel[ks2]);
+                    if constexpr (n + PRE < 16) {
+                        constexpr int nn = n + PRE;
+                        constexpr int ks2 = last ? (nn & 7) : (nn >> 1), ft2 = last ? (nn >> 3) : (nn & 1);
+                        ds_read16<ft2 * 8192>(fq[n % PRE], sa + a1rel[ks2]);
+                    }
                     if constexpr (n % 2 == 1 && n / 2 < pni) issue_part(pc, pi, pslot, n / 2);     // steps 1, 3, 5, ...
                     if constexpr (last && n == 10) gelu_group(0, 0);
                     if constexpr (last && n == 13) gelu_group(0, 1);
@@ -729,10 +735,12 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
                 static_for<24>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     constexpr int s2 = n / 12, ot = n % 12;
-                    frag_wait(fq[n % PRE]);
+                    frag_wait<(24 - 1 - n < PRE - 1 ? 24 - 1 - n : PRE - 1)>(fq[n % PRE]);
                     acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PRE], __builtin_bit_cast(bf16x8, pfu[t & 1][s2]), acc2[ot], 0, 0, 0);
-                    constexpr int nn = n + PRE < 24 ? n + PRE : 23;
-                    ds_read16<(nn % 12) * 2048>(fq[n % PRE], ab[nn / 12]);
+                    if constexpr (n + PRE < 24) {
+                        constexpr int nn = n + PRE;
+                        ds_read16<(nn % 12) * 2048>(fq[n % PRE], ab[nn / 12]);
+                    }
                     // activation schedule: every 12-MFMA half-slab carries two register groups, each the half-slab before the
                     // k-step that consumes it: tile 0 k-step 1 | tile 1 k-step 0 | tile 1 k-step 1 | (none)
                     if constexpr (t == 0 && n == 2) gelu_group(0, 2);
@@ -754,11 +762,6 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
         atomicAdd(dbg + 3, t_g1);
         atomicAdd(dbg + 4, t_g2);
     }
-    // the re-reads issued past each slab's last fragment are still in flight: their registers must stay allocated until the
-    // data has landed (the compiler sees dead values and would reuse the registers under them)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int m = 0; m < PRE; ++m) asm volatile("" : "+v"(fq[m]));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the tail reloads: the ring becomes the pre-LN tile
     __syncthreads();
     char* tile = gsm;
@@ -963,6 +966,181 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// attention, second form: ONE WAVE per (sequence, head), v_mfma_f32_32x32x16_bf16, no cross-wave traffic at all.
+//
+// The first kernel (above) is issue-bound: ~1000 instructions per wave for 32 small MFMAs (per-element masking, 4-lane
+// shuffles for every row maximum / sum, per-element divides, 2-byte stores).  Here the operands are swapped twice:
+//   * S^T = K . Q^T  (A = K rows from LDS, B = Q fragments straight from global memory): lane (query = lane & 31, half h) holds
+//     the scores of ITS query against 16 keys per 32-key tile -- a row maximum / sum is a chain over the lane's own registers
+//     plus ONE exchange with lane ^ 32;
+//   * O^T = V^T . P^T  (A = V^T from LDS, B = P^T): the accumulator layout of S^T (registers 8s .. 8s+7 <-> keys
+//     {4h+e, 8+4h+e} of the 16-key block s) IS a k-permuted B fragment, so P never leaves the registers; V^T is written to
+//     LDS with the same key permutation when it is staged (that transpose is the only scattered LDS traffic);
+//   * exp2 with log2(e)/sqrt(d) folded into Wq, masking only in the last key tile, one reciprocal per query, 8-byte stores.
+// Workgroup = 4 waves = 4 consecutive heads of one sequence (256 contiguous bytes of every token row between them); the three
+// workgroups of a sequence run on one XCD.  KT = key tiles of 32 (sequence length <= 32 KT); NW = waves per workgroup.
+// ------------------------------------------------------------------------------------------------------------
+template <int KT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attention2(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch,
+                                                        bf16* __restrict__ ctx) {
+    constexpr int LP = KT * 32;                    // padded keys
+    constexpr int VSTR = LP * 2 + 16;              // bytes per V^T row (dim): +16 spreads the 32 dims over the banks
+    constexpr int KBYTES = LP * 64, WBYTES = KBYTES + 32 * VSTR;
+    constexpr bool CACHEK = KT <= 4;               // K fragments of the whole sequence stay in registers across query tiles
+    constexpr int HG = NH / NW;                    // head groups (workgroups) per sequence
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int seq, hg;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        seq = (idx / HG) * 8 + xcd;                // the HG workgroups of a sequence share an XCD (same token rows through one L2)
+        hg = idx % HG;
+    }
+    if (seq >= batch) return;
+    const int head = hg * NW + w;
+    const int t0 = cu[seq], L = cu[seq + 1] - t0;
+    if (L <= 0) return;
+    const int c31 = lane & 31, hh = lane >> 5;
+    char* ks = gsm + w * WBYTES;                   // [LP keys][4 units of 16 B], unit u of key r at u ^ ((r >> 2) & 3)
+    char* vt = ks + KBYTES;                        // [32 dims][VSTR]: V^T, keys in GEMM-slot order inside every 16-block
+    const int nkt = (L + 31) >> 5;                 // key tiles in use
+    const int64_t rs = 3 * H;                      // qkv row stride (elements)
+    const bf16* base = qkv + (int64_t)t0 * rs + head * DH;
+
+    // ---- stage K (row-major, swizzled) and V^T (transposed, key-permuted); rows >= L are zero -------------------------
+    for (int p0 = 0; p0 < nkt * 32 * 4; p0 += 128) {       // 2 x 64 pieces of 16 B per iteration: both loads in flight
+        uint4 kv[2], vv[2];
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+            const int p = p0 + u2 * 64 + lane, r = p >> 2, u = p & 3;
+            kv[u2] = uint4{0u, 0u, 0u, 0u};
+            vv[u2] = uint4{0u, 0u, 0u, 0u};
+            if (r < L) {
+                kv[u2] = *(const uint4*)(base + (int64_t)r * rs + H + u * 8);
+                vv[u2] = *(const uint4*)(base + (int64_t)r * rs + 2 * H + u * 8);
+            }
+        }
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+            const int p = p0 + u2 * 64 + lane, r = p >> 2, u = p & 3;
+            *(uint4*)(ks + r * 64 + ((u ^ ((r >> 2) & 3)) * 16)) = kv[u2];
+            // key r -> slot inside its 16-block: keys 0-3 -> 0-3, 4-7 -> 8-11, 8-11 -> 4-7, 12-15 -> 12-15
+            const int r16 = r & 15, slot = (r & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
+            const unsigned short* ve = (const unsigned short*)&vv[u2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(unsigned short*)(vt + (u * 8 + e) * VSTR + slot * 2) = ve[e];
+        }
+    }
+    // (one wave owns this LDS region: program order + the compiler's lgkmcnt waits are all the synchronisation needed)
+
+    // K fragments: key tile kt, k-step s (dims 16 s .. 16 s + 15): lane (key c31, half hh) reads unit 2 s + hh of key 32 kt + c31
+    auto kfrag = [&](int kt, int s2) -> bf16x8 {
+        const int r = kt * 32 + c31;
+        return *(const bf16x8*)(ks + r * 64 + (((2 * s2 + hh) ^ ((r >> 2) & 3)) * 16));
+    };
+    bf16x8 kc[CACHEK ? KT : 1][2];
+    if (CACHEK) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            if (kt < nkt) { kc[kt][0] = kfrag(kt, 0); kc[kt][1] = kfrag(kt, 1); }
+    }
+    // key index of accumulator register r of this lane inside a 32-key tile
+    const int nq_tiles = (L + 31) >> 5;
+    bf16x8 qf[2];                                  // Q fragments (B operand): query c31 of the tile, dims 16 s + 8 hh ..
+    {
+        const int q = min(c31, L - 1);
+        qf[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
+        qf[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
+    }
+    for (int qt = 0; qt < nq_tiles; ++qt) {
+        bf16x8 qn[2] = {qf[0], qf[1]};
+        if (qt + 1 < nq_tiles) {                   // next tile's Q in flight while this tile computes
+            const int q = min((qt + 1) * 32 + c31, L - 1);
+            qn[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
+            qn[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
+        }
+        // ---- S^T tiles: st[kt][r] = score of query (qt, c31) against key 32 kt + (r & 3) + 8 (r >> 2) + 4 hh, log2 domain ---
+        f32x16 st[KT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt < nkt) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CACHEK ? kc[kt][0] : kfrag(kt, 0), qf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CACHEK ? kc[kt][1] : kfrag(kt, 1), qf[1], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(acc[r], acc[r + 1]));
+                st[kt] = acc;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));        // the other half of this query's keys
+        // Keys >= L (padding of the last tile) need no per-element mask: their K rows are zero, so each scores exactly 0, their
+        // V rows are zero too (no contribution to O), and their share of the row sum is n_pad * exp2(0 - mx), subtracted below.
+        // They can only distort the MAXIMUM -- when every real score of a query is <= 0 the shift would be the padding's 0
+        // instead of the true maximum (harmless unless the real scores are far below 0): that case takes the masked re-scan.
+        const int n_pad = nkt * 32 - L;
+        if (n_pad > 0 && __any(mx == 0.f)) {
+            float mm = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt < nkt) {
+                    const int lim = L - kt * 32 - 4 * hh;      // register r is a real key iff (r & 3) + 8 (r >> 2) < lim
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mm = fmaxf(mm, ((r & 3) + 8 * (r >> 2) < lim) ? st[kt][r] : -INFINITY);
+                }
+            }
+            mm = fmaxf(mm, __shfl_xor(mm, 32));
+            mx = (mx == 0.f) ? mm : mx;            // (a query whose true maximum is exactly 0 gets the same value back)
+        }
+        float sum = 0.f;
+        f32x16 ot;                                 // O^T tile: dims (r & 3) + 8 (r >> 2) + 4 hh of query c31
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt < nkt) {
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                u32x4 pu[2];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(st[kt][r] - mx);       // exp2(-inf) = 0 for masked keys
+                    const float p1 = __builtin_amdgcn_exp2f(st[kt][r + 1] - mx);
+                    sum += p0 + p1;
+                    bf16x2 pb;
+                    pb[0] = (bf16)p0; pb[1] = (bf16)p1;
+                    pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
+                }
+                // registers 8 s .. 8 s + 7 of the tile = the B fragment of k-step s (keys 32 kt + 16 s + {4hh+e, 8+4hh+e})
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 vf = *(const bf16x8*)(vt + c31 * VSTR + (kt * 32 + s2 * 16 + hh * 8) * 2);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pu[s2]), ot, 0, 0, 0);
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        sum -= (float)n_pad * __builtin_amdgcn_exp2f(-mx);        // the padded keys' share (each is exp2(0 - mx))
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        const int q = qt * 32 + c31;
+        if (q < L) {
+            bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 4;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (bf16)(ot[4 * g4 + e] * inv);
+                *(bf16x4*)(dst + 8 * g4) = o4;
+            }
+        }
+        qf[0] = qn[0];
+        qf[1] = qn[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // pooling heads
 // ------------------------------------------------------------------------------------------------------------
 // sentence-transformers Pooling(mean) + Normalize: one wave per sequence
@@ -1103,7 +1281,9 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
     rc |= copy_f32(m, &m->temb, wptr[wi++], (size_t)cfg->type_vocab * H, 1.f, s);
     rc |= copy_f32(m, &m->elng, wptr[wi++], H, 1.f, s);
     rc |= copy_f32(m, &m->elnb, wptr[wi++], H, 1.f, s);
-    const float qs = 1.0f / sqrtf((float)DH);       // softmax scale folded into the query projection
+    // softmax scale folded into the query projection; with RMU_ATTN2=1 also log2(e): that kernel uses exp2
+    static const bool attn2_scale = getenv("RMU_ATTN2") && atoi(getenv("RMU_ATTN2")) != 0;
+    const float qs = (attn2_scale ? 1.4426950408889634f : 1.0f) / sqrtf((float)DH);
     m->layers.resize(cfg->layers);
     for (int l = 0; l < cfg->layers && !rc; ++l) {
         BertLayer& L = m->layers[l];
@@ -1238,6 +1418,17 @@ static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16
     }
 }
 
+template <int KT, int NW>
+static void launch_attn2(int batch, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
+    constexpr int lds = NW * (KT * 32 * 64 + 32 * (KT * 32 * 2 + 16));
+    static const hipError_t attr_rc =
+        hipFuncSetAttribute((const void*)k_attention2<KT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)attr_rc;
+    const int hgs = NH / NW;
+    const unsigned grid = (unsigned)(((batch + 7) / 8) * 8 * hgs);
+    hipLaunchKernelGGL((k_attention2<KT, NW>), dim3(grid), dim3(64 * NW), lds, s, qkv, cu, batch, ctx);
+}
+
 template <int MAXT>
 static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
     static bool attr = false;
@@ -1269,7 +1460,12 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     const dim3 at_grid(NH, (unsigned)batch);   // one workgroup per (head, sequence)
     for (const BertLayer& L : m->layers) {
         launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
-        if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
+        static const bool attn2 = getenv("RMU_ATTN2") && atoi(getenv("RMU_ATTN2")) != 0;   // opt-in: measured 7% slower than k_attention at L ~ 128
+        if (attn2) {
+            if (max_len <= 128) launch_attn2<4, 4>(batch, m->qkv, m->cu, m->ctx, s);
+            else if (max_len <= 256) launch_attn2<8, 4>(batch, m->qkv, m->cu, m->ctx, s);
+            else launch_attn2<16, 2>(batch, m->qkv, m->cu, m->ctx, s);
+        } else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
         // measured: the fused 128x384 kernel (one workgroup per CU, serial LN pass) is 12% slower than GEMM + LN launches
