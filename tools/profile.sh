@@ -11,10 +11,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-identity-check"
+B="python $R/bench.py --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check"
 keep() {  # keep only our kernels' rows of a CSV
   f=$(find $OUT/$1 -name "*$2" | head -1)
-  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|k_gemm|k_attention|k_layernorm|k_embed_ln|k_meanpool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
+  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|merge_select|merge_wg|k_gather_flagged|k_ffn_fused|k_gemm|k_attention|k_layernorm|k_embed_ln|k_meanpool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
 }
 # 1) headline bench (10M x 384, B=1024) on the default path (fp16 hi/lo screening + exact re-score): stats + PMC passes
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan -o scan -- $B > $OUT/scan_bench.json 2> $OUT/scan.err
@@ -35,7 +35,7 @@ timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 keep exact_pmc_b counter_collection.csv counters
 unset RMU_SCREEN
 # 3) HBM-bound regime (B=1): default path (fp16 image, screening ladder) and the exact fp32 scan; kernel stats + FETCH_SIZE
-B1="python $R/bench.py --batch 1 --steps 10 --warmup 2 --no-cpu-baseline --no-identity-check"
+B1="python $R/bench.py --batch 1 --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b1 -o scan -- $B1 > $OUT/scan_b1_bench.json 2>> $OUT/scan.err
 keep scan_b1 kernel_stats.csv stats
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b1 -o b -- $B1 > $OUT/pmc_b1_bench.json 2>> $OUT/scan.err
@@ -46,8 +46,14 @@ keep exact_b1 kernel_stats.csv stats
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/exact_pmc_b1 -o b -- $B1 > $OUT/exact_pmc_b1_bench.json 2>> $OUT/scan.err
 keep exact_pmc_b1 counter_collection.csv counters
 unset RMU_SCREEN
-# 4) encoder (config 3) kernel stats
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed -o e -- python $R/tools/bench_configs.py embed --chunks 32768 --batch 8192 > $OUT/embed_bench.json 2>> $OUT/scan.err
+# 3b) the north-star regime (B=32, screened, nt stream): kernel stats + FETCH_SIZE
+B32="python $R/bench.py --batch 32 --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check"
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b32 -o scan -- $B32 > $OUT/scan_b32_bench.json 2>> $OUT/scan.err
+keep scan_b32 kernel_stats.csv stats
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b32 -o b -- $B32 > $OUT/pmc_b32_bench.json 2>> $OUT/scan.err
+keep pmc_b32 counter_collection.csv counters
+# 4) encoder (config 3) kernel stats (kernel-trace only: a PMC pass over the encoder hung rocprofv3 in round 1)
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed -o e -- python $R/bench.py --legs embed --rows 100000 --steps 2 --no-cpu-baseline --no-identity-check --no-kernel-timing > $OUT/embed_bench.json 2>> $OUT/scan.err
 keep embed kernel_stats.csv stats
-for d in scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 embed; do rm -rf $OUT/$d; done
+for d in scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
 ls -la $OUT

@@ -2,7 +2,7 @@
   r01_<run>_stats.csv / _bench.json   rocprofv3 --kernel-trace --stats tables and the bench line of the same command
   r01_pmc_means.csv                   PMC counters: per kernel, mean per dispatch AND sum per bench step
   r01_summary.md                      the tables + derived HBM traffic / MFMA-busy / clock figures
-usage: python tools/summarize_profiles.py r01d"""
+usage: python tools/summarize_profiles.py <gpurun_out tag> [<round prefix, default r02>]"""
 import collections
 import csv
 import glob
@@ -12,14 +12,15 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01d"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02p"
+RP = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = f"gpurun_out/{tag}"
-STEPS = 12   # tools/profile.sh runs bench.py with --steps 10 --warmup 2
+STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.py then repeats 10 searches with per-launch events (roofline pass)
 
 
 def short(n):
     m = re.search(r'(scan_topk_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
-                  r'merge_lists_kernel|k_gemm<\d, \d, \d+, \d>|k_attention|k_layernorm|k_embed_ln|k_meanpool_l2|k_cls_head)', n)
+                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn_fused|k_gemm<\d, \d, \d+, \d>|k_attention2|k_attention|k_layernorm|k_embed_ln|k_meanpool_l2|k_cls_head)', n)
     s = m.group(1) if m else n[:40]
     if s in ('scan_topk_kernel',):
         c = re.search(r'Cfg<([^>]*)>', n)
@@ -38,27 +39,29 @@ for f in sorted(glob.glob(src + '/*_counters.csv')):
         meta[k[0]] = (r['Workgroup_Size'], r['LDS_Block_Size'], r['Scratch_Size'], r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'])
     for (kn, cn), v in sorted(acc.items()):
         rows.append((p, kn, cn, len(v), sum(v) / len(v), sum(v) / STEPS) + meta[kn])
-with open('profiles/r01_pmc_means.csv', 'w') as o:
+with open(f'profiles/{RP}_pmc_means.csv', 'w') as o:
     o.write('pass,kernel,counter,dispatches,mean_per_dispatch,sum_per_bench_step,wg,lds_block,scratch,vgpr,agpr,sgpr\n')
     for r in rows:
         o.write(','.join(str(x) for x in r) + '\n')
-for t in ['scan', 'exact', 'scan_b1', 'exact_b1', 'embed']:
-    shutil.copy(f'{src}/{t}_stats.csv', f'profiles/r01_{t}_stats.csv')
-    open(f'profiles/r01_{t}_bench.json', 'w').write(open(f'{src}/{t}_bench.json').read().strip().splitlines()[-1] + '\n')
+for t in ['scan', 'exact', 'scan_b1', 'exact_b1', 'scan_b32', 'embed']:
+    shutil.copy(f'{src}/{t}_stats.csv', f'profiles/{RP}_{t}_stats.csv')
+    open(f'profiles/{RP}_{t}_bench.json', 'w').write(open(f'{src}/{t}_bench.json').read().strip().splitlines()[-1] + '\n')
 
 
 def stats(t, title):
     out = [f"## kernel-trace --stats, {title}\n", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-    for r in csv.DictReader(open(f'profiles/r01_{t}_stats.csv')):
+    for r in csv.DictReader(open(f'profiles/{RP}_{t}_stats.csv')):
         n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
         out.append(f"| `{n[:78]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {r['Percentage']} |")
-    b = json.loads(open(f'profiles/r01_{t}_bench.json').read())
-    if 'roofline' in b:
+    b = json.loads(open(f'profiles/{RP}_{t}_bench.json').read())
+    if t == 'embed' and b.get('secondary'):
+        out.append(f"\nbench leg of the same command (`profiles/{RP}_{t}_bench.json`): " + json.dumps({k: v for k, v in b['secondary'][0].items() if k != 'config'}))
+    elif b.get('roofline'):
         rf = b['roofline']
-        out.append(f"\nbench line of the same command (`profiles/r01_{t}_bench.json`): value {b['value']} {b['unit']}, ms_per_step {b['ms_per_step']}, "
+        out.append(f"\nbench line of the same command (`profiles/{RP}_{t}_bench.json`): value {b['value']} {b['unit']}, ms_per_step {b['ms_per_step']}, "
                    f"hipEvent kernel_ms {rf['kernel_ms']} over {rf['launch']['launches']} launch(es), roofline {rf['bound']} {rf['achieved']} / {rf['peak']} {rf['unit']} = {rf['frac']}")
     else:
-        out.append(f"\nbench line (`profiles/r01_{t}_bench.json`): {json.dumps(b)}")
+        out.append(f"\nbench line (`profiles/{RP}_{t}_bench.json`): {json.dumps(b)}")
     return "\n".join(out) + "\n"
 
 
@@ -77,11 +80,18 @@ def line(p, k):
 
 
 SK = 'scan_screen_kernel'
-EK = 'scan_topk_kernel<Cfg<384;4;96;4;64;1;0;1>>'
-B1 = 'scan_topk_kernel<Cfg<384;1;48;3;64;1;0;0>>'
+
+
+def find(p, prefix):
+    ks = [k for (pp, k) in pm if pp == p and k.startswith(prefix)]
+    return ks[0]
+
+
+EK = find('exact_pmc_a', 'scan_topk_kernel<Cfg<384;4;')
+B1 = find('exact_pmc_b1', 'scan_topk_kernel<Cfg<384;1;')
 f = lambda p, k, c: pm[(p, k)][c][1]      # per bench step
-sb = json.loads(open('profiles/r01_scan_bench.json').read())
-eb = json.loads(open('profiles/r01_exact_bench.json').read())
+sb = json.loads(open(f'profiles/{RP}_scan_bench.json').read())
+eb = json.loads(open(f'profiles/{RP}_exact_bench.json').read())
 k_ms, e_ms = sb['roofline']['kernel_ms'], eb['roofline']['kernel_ms']
 scr_fetch = f('pmc_b', SK, 'FETCH_SIZE') * 2048
 scr_write = f('pmc_c', SK, 'WRITE_SIZE') * 1024
@@ -89,17 +99,18 @@ hit = f('pmc_c', SK, 'TCC_HIT_sum') / (f('pmc_c', SK, 'TCC_HIT_sum') + f('pmc_c'
 clk_s = f('pmc_a', SK, 'GRBM_GUI_ACTIVE') / 8 / (k_ms * 1e-3) / 1e9
 clk_e = f('exact_pmc_a', EK, 'GRBM_GUI_ACTIVE') / 8 / (e_ms * 1e-3) / 1e9
 txt = [
-    "# Round 1 rocprofv3 summary (MI355X, gfx950, ROCm 7.2)",
+    f"# Round {int(RP[1:])} rocprofv3 summary (MI355X, gfx950, ROCm 7.2)",
     f"Produced by `tools/profile.sh {tag}` on the GPU box, condensed by `tools/summarize_profiles.py {tag}`; per-kernel tables:",
-    "`r01_*_stats.csv`; counters (mean per dispatch and sum per bench step): `r01_pmc_means.csv`.  The screening path launches its",
+    f"`{RP}_*_stats.csv`; counters (mean per dispatch and sum per bench step): `{RP}_pmc_means.csv`.  The screening path launches its",
     "kernel once per row range of the threshold ladder (7 launches per 10M-row batch), so its counters are summed per bench step.\n",
     stats('scan', 'headline bench (10M x 384 fp32, batch 1024, top-10), default path = fp16 screening ladder + exact fp32 re-score'),
     stats('exact', 'same workload forced onto the exact fp32 scan (`RMU_SCREEN=0`)'),
     stats('scan_b1', 'HBM-bound regime: batch 1, default path (fp16 image, 768 B per row, screening ladder with ratio 8)'),
     stats('exact_b1', 'batch 1 forced onto the exact fp32 scan (`RMU_SCREEN=0`, WQ=1 geometry)'),
-    stats('embed', 'encoder: 4 calls x 8192 chunks x ~128 tokens (BERT-6x384, bf16 MFMA)'),
+    stats('scan_b32', 'north-star regime: batch 32 over 10M rows, default path (fp16 image, nt stream, ladder ratio 8)'),
+    stats('embed', 'encoder: 8192-chunk calls x ~128 tokens (BERT-6x384, bf16 MFMA; fused FFN kernel)'),
     "## PMC passes (separate runs, `--kernel-trace --pmc ...` only)\n",
-    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK), line('exact_pmc_b1', B1),
+    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK), line('exact_pmc_b1', B1), line('pmc_b32', SK),
     "\n## Derived (FETCH_SIZE is in KiB and under-reports by 2x on gfx950 per MI355X_MICROARCH.md -> bytes = FETCH_SIZE x 1024 x 2)\n",
     f"- screening launches, per batch: HBM fetch {scr_fetch/1e9:.2f} GB + write {scr_write/1e6:.1f} MB; the fp16 image is 7.68 GB and each of the 4 "
     f"query-tile workgroups of a row chunk streams it (L2 hit {hit:.3f}; ideal 0.75), i.e. x{scr_fetch/7.68e9:.2f} the image, x{scr_fetch/15.36e9:.2f} the "
@@ -109,8 +120,9 @@ txt = [
     f"- exact kernel: HBM fetch {f('exact_pmc_b',EK,'FETCH_SIZE')*2048/1e9:.2f} GB per launch vs 15.36 GB algorithmic (x{f('exact_pmc_b',EK,'FETCH_SIZE')*2048/15.36e9:.3f}); "
     f"MFMA busy {f('exact_pmc_a',EK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('exact_pmc_a',EK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles; mean clock {clk_e:.2f} GHz",
     f"- batch 1, default path: HBM fetch {f('pmc_b1',SK,'FETCH_SIZE')*2048/1e9:.3f} GB per query over all launches vs the 7.680 GB image (x{f('pmc_b1',SK,'FETCH_SIZE')*2048/7.68e9:.4f})",
+    f"- batch 32, default path: HBM fetch {f('pmc_b32',SK,'FETCH_SIZE')*2048/1e9:.3f} GB per batch over all launches vs the 7.680 GB image (x{f('pmc_b32',SK,'FETCH_SIZE')*2048/7.68e9:.4f})",
     f"- batch 1, exact scan: HBM fetch {f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
 ]
-open('profiles/r01_summary.md', 'w').write("\n".join(txt) + "\n")
+open(f'profiles/{RP}_summary.md', 'w').write("\n".join(txt) + "\n")
 print("\n".join(txt[-4:]))
-print("SCREEN_TRAFFIC =", scr_fetch + scr_write)
+print("SCREEN_TRAFFIC =", scr_fetch + scr_write, "B1 screen", f('pmc_b1',SK,'FETCH_SIZE')*2048, "B32 screen", f('pmc_b32',SK,'FETCH_SIZE')*2048, "exact", f('exact_pmc_b',EK,'FETCH_SIZE')*2048, "exact B1", f('exact_pmc_b1',B1,'FETCH_SIZE')*2048)
