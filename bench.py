@@ -38,9 +38,9 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 IMG_ROW_BYTES = 768            # fp16 screening image of a 384-d row
 # HBM bytes per step from rocprofv3 PMC passes of exactly these configurations (2 x FETCH_SIZE [gfx950 correction] +
 # WRITE_SIZE, summed over the launches of a step; profiles/r02_summary.md).  None = not measured for that configuration.
-TRAFFIC = {("screen", 10_000_000, 1024): 1.3632e10, ("screen", 10_000_000, 1): 7.683e9,
-           ("exact", 10_000_000, 1024): 2 * 7.876e6 * 1024 + 6070 * 1024, ("exact", 10_000_000, 1): 2 * 7.504e6 * 1024}
-TRAFFIC_SOURCE = "profiles/r01_pmc_means.csv (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024)"
+TRAFFIC = {("screen", 10_000_000, 1024): 1.3665e10, ("screen", 10_000_000, 32): 7.691e9, ("screen", 10_000_000, 1): 7.687e9,
+           ("exact", 10_000_000, 1024): 1.6185e10}
+TRAFFIC_SOURCE = "profiles/r02_pmc_means.csv (sum per bench step of FETCH_SIZE x 1024 x 2 [+ WRITE_SIZE x 1024]; profiles/r02_summary.md)"
 
 
 def make_shard(n_rows: int, d: int, seed: int, device) -> "torch.Tensor":
@@ -172,7 +172,7 @@ def encoder_flops(lens) -> float:
 
 
 def encoder_roofline(tf: float) -> dict:
-    return {"kernel": "k_gemm / k_attention (bf16 MFMA 16x16x32), whole forward", "bound": "mfma", "achieved": round(tf, 2),
+    return {"kernel": "whole forward: k_ffn_fused (bf16 MFMA 32x32x16: FFN1+GELU+FFN2+residual+LayerNorm), k_gemm (16x16x32: QKV, out-proj), k_attention, k_layernorm", "bound": "mfma", "achieved": round(tf, 2),
             "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
             "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches)"}
 
