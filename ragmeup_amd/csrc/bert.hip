@@ -832,6 +832,324 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_gemm3 -- persistent big-tile GEMM for the encoder's shapes: out[m, n] = epi( sum_k A[m, k] W[n, k] + bias[n] ).
+//
+// What the cycle counters of k_gemm / k_ffn_fused and tools/ubench/fill.hip say about a CU's memory pipeline (all 256 CUs busy,
+// L2-resident source): an LDS fill (global_load_lds, or global_load + ds_write alike) runs at ~146 GB/s per CU when a wave
+// instruction covers 1 KiB of contiguous bytes but ~75 GB/s as 16 rows x 64 B -- the address path is paid per cache line touched
+// (~0.55 lines per clock), whatever the number of waves (4..16) or loads in flight; stores leave at ~14 B/clk per CU (a 1-KiB
+// global_store_dwordx4 per ~70 cycles, whatever the pattern); loads and stores of all waves share one in-order queue.  With
+// 32-k stages (64-B row pieces) k_gemm's 128 x 128 tile needs 16 such loads (~480 cycles) per 256 cycles of MFMA work: it is
+// bound by that queue, not by the matrix cores, and so is every LDS-staged GEMM here whose tile is small.
+// Hence: a 256-token x 192-feature tile per workgroup (448 rows per 768 MFMA cycles), 8 waves per CU (two per SIMD, <= 256
+// registers: while one sits in a load/store issue the other feeds the MFMA pipe), a 64 x 96 tile per wave (5 fragment reads
+// per 6 v_mfma_f32_32x32x16_bf16), and a PERSISTENT loop over tiles whose 5-slot LDS-DMA ring never drains: the stages of the
+// next tile are already in flight while the current tile's accumulators are stored (K is only 12 stages deep for three of
+// the four GEMMs of a layer, so a drained prologue per tile would cost as much as the tile's MFMAs).
+// Measured (8192 chunks, 1.04 M tokens): QKV 1.22 ms vs k_gemm's 1.38; the loop runs at ~2300 cycles per stage against 768
+// of MFMA work -- ablations: without the epilogue's stores 1770, without DMA issue 1700, MFMAs + barrier alone 1200.  The
+// 64-B row pieces (840 cycles of queue time per stage) and the stores (~580) are what is left to remove: 128-B rows need
+// 64-k stages, i.e. 3 x 56 KiB of LDS, which does not fit beside anything; a tiled activation layout would (next round).
+//   * stage = 32 k (64-B rows: X 16 KiB + W 12 KiB); DMA instructions (SGPR base + lane offset) are handed out between MFMAs,
+//     2 X pieces per wave in the second half-step, 1-2 W pieces in the first; counted vmcnt; ONE barrier per stage;
+//   * fragments are read one 16-k step ahead of the MFMAs that eat them (inline asm, literal offsets, counted lgkmcnt 2/4/4):
+//     the token fragments of the next step go to the other register set, each weight fragment is re-read in place behind
+//     its two MFMAs;
+//   * epilogue through a 2-KiB strip per wave BESIDE the ring (which stays in use): bias (scalar loads) | + GELU | + residual;
+//     weight rows are read permuted so that a lane owns 16 consecutive features; stores are 16 rows x 64 B per instruction
+//     (the CU's store path moves ~14 B/clk whatever the pattern; spreading the stores over the next tile's stages was slower);
+//   * tiles: the column blocks of one token tile run on neighbouring CUs of one XCD (its L2 serves the re-reads of X).
+// ------------------------------------------------------------------------------------------------------------
+namespace g3 {
+constexpr int BM = 256, BNF = 192;
+constexpr int XBYTES = BM * 64, SLOT = XBYTES + BNF * 64, NSLOT = 5;   // 28 KiB per stage
+constexpr int RING = NSLOT * SLOT;
+constexpr int STRIP = 32 * 64;                                         // epilogue: one 32-token x 32-feature tile per wave (swizzled)
+constexpr int LDS_BYTES = RING + 8 * STRIP;
+}  // namespace g3
+
+template <int EPI, bool DBG>
+__global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
+                                               const bf16* __restrict__ resid, bf16* __restrict__ out, const int* __restrict__ cu,
+                                               int batch, int N, int K, unsigned long long* dbg, int dflags) {
+    using namespace g3;
+    using ffn::static_for; using ffn::ds_read16; using ffn::frag_wait; using ffn::sgpr_ptr;
+    const int M = cu[batch];
+    const int ncb = N / BNF, nk = K / 32;
+    const int mtiles = (M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, cslot = blockIdx.x >> 3, ncu = gridDim.x >> 3;
+    // tiles of this XCD: local index li -> token tile (li / ncb) * 8 + xcd, column block li % ncb; this workgroup takes li = cslot + j * ncu
+    const int mt_x = mtiles > xcd ? (mtiles - xcd + 7) / 8 : 0;
+    const int L = mt_x * ncb;
+    const int ntiles = L > cslot ? (L - cslot + ncu - 1) / ncu : 0;
+    if (ntiles == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int r31 = lane & 31, hh = lane >> 5;
+    char* ring = gsm;
+    char* strip = gsm + RING + w * STRIP;
+    unsigned long long tc0 = 0, tc1 = 0, twait = 0, tepi = 0;
+    if (DBG) tc0 = __builtin_readcyclecounter();
+
+    auto tile_of = [&](int j, int& m0, int& n0) {
+        const int li = cslot + j * ncu;
+        const int q = li / ncb;
+        m0 = (q * 8 + xcd) * BM;
+        n0 = (li - q * ncb) * BNF;
+    };
+
+    // ---- issue cursor: the stage the next DMA instructions belong to (runs NSLOT - 1 stages ahead of the MFMAs, across tiles) --
+    // X piece xi = w + 8 i (i = 0, 1): rows 16 xi + (lane >> 2), physical unit lane & 3 holding logical unit (lane & 3) ^ ((row >> 2) & 3)
+    // (= lane >> 4); rows past the last token are clamped (never stored).  W piece wi = w (+ 8 for waves 0..3).
+    int ij = 0, it = 0, islot = 0;
+    const char *ia, *iw;
+    u32 xoff[2];
+    const u32 woff = (u32)(((size_t)(lane >> 2) * K + (((lane & 3) ^ (lane >> 4)) * 8)) * 2);
+    auto set_issue_tile = [&](int j) {
+        int m0, n0;
+        tile_of(j, m0, n0);
+        const int rows_here = M - m0;
+        ia = (const char*)(A + (size_t)m0 * K);
+        iw = (const char*)(W + (size_t)n0 * K);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (w + 8 * i) * 16 + (lane >> 2);
+            const int rc = row < rows_here ? row : rows_here - 1;
+            xoff[i] = (u32)(((size_t)rc * K + (((lane & 3) ^ (lane >> 4)) * 8)) * 2);
+        }
+    };
+    auto issue_x = [&](int i) {
+        u32 o = xoff[i];
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(ia + (size_t)it * 64) + o),
+                                         (__attribute__((address_space(3))) void*)(ring + islot * SLOT + (w + 8 * i) * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&](int i) {
+        if (i == 1 && w >= 4) return;
+        u32 o = woff;
+        asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(iw + (size_t)it * 64 + (size_t)(w + 8 * i) * 16 * K * 2) + o),
+                                         (__attribute__((address_space(3))) void*)(ring + islot * SLOT + XBYTES + (w + 8 * i) * 1024), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        islot = islot == NSLOT - 1 ? 0 : islot + 1;
+        if (++it == nk) {
+            if (ij + 1 < ntiles) { ++ij; set_issue_tile(ij); it = 0; }
+            else it = nk - 1;                          // past the end: harmless re-loads of the last stage into free slots
+        }
+    };
+    set_issue_tile(0);
+#pragma unroll
+    for (int s0 = 0; s0 < NSLOT - 1; ++s0) { issue_x(0); issue_x(1); issue_w(0); issue_w(1); advance(); }
+
+    f32x16 acc[3][2];                                  // [feature tile of 32][token tile of 32]
+#pragma unroll
+    for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ft][tt][e] = 0.f;
+
+    // fragment addressing: lane (row r31, half hh) reads unit 2 s + hh of row (tile base + r31): base register per s, tile = literal
+    const u32 ring_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    // Weight rows are read PERMUTED: MFMA row i of a 32-feature tile is LDS row f(i) = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3), so
+    // that the accumulator registers 0..15 of a lane (D rows 8 q + 4 hh + e) hold the 16 CONSECUTIVE features 16 hh + 4 q + e of
+    // its token: the epilogue moves 16-byte pieces.  (Bank-conflict-free like the identity: the 16-lane groups of a b128 read
+    // still meet four different (row >> 2) & 3 swizzles.)
+    const int fr = 16 * ((r31 >> 2) & 1) + 4 * (r31 >> 3) + (r31 & 3);
+    u32 xrel[2], wrel[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        xrel[s2] = (u32)(r31 * 64 + (((2 * s2 + hh) ^ ((r31 >> 2) & 3)) * 16)) + (u32)(wm * 64 * 64);
+        wrel[s2] = (u32)(fr * 64 + (((2 * s2 + hh) ^ ((fr >> 2) & 3)) * 16)) + (u32)(XBYTES + wn * 96 * 64);
+    }
+    bf16x8 wf[3], xf[2][2];
+
+    if (w < 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // stage 0 landed
+    __syncthreads();
+    if (DBG) tc1 = __builtin_readcyclecounter();
+    ds_read16<0>(xf[0][0], ring_addr + xrel[0]);
+    ds_read16<2048>(xf[0][1], ring_addr + xrel[0]);
+    static_for<3>([&](auto c) { constexpr int ft = decltype(c)::value; ds_read16<ft * 2048>(wf[ft], ring_addr + wrel[0]); });
+
+    // one 16-k step: 3 groups of 2 MFMAs on (wf[ft], xf[cur][0..1]); the reads of the NEXT step (bases nxb / nwb) go out underneath:
+    // xf[1 - cur][0..1] during group 0, wf[ft] in place behind group ft.  DMA: 0 = none, 1 = the X pieces, 2 = the W pieces.
+    auto step = [&](auto curc, u32 nxb, u32 nwb, auto dmac) {
+        constexpr int cur = decltype(curc)::value;
+        constexpr int dma = decltype(dmac)::value;
+        // group 0 needs wf[0] and xf[cur]: everything but the last two reads (wf[1], wf[2]) has to have landed
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wf[0]), "+v"(xf[cur][0]), "+v"(xf[cur][1]));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[cur][0], acc[0][0], 0, 0, 0);
+        if (!DBG || !(dflags & 2)) ds_read16<0>(xf[1 - cur][0], nxb);
+        if (!DBG || !(dflags & 1)) {
+            if constexpr (dma == 1) issue_x(0);
+            if constexpr (dma == 2) issue_w(0);
+        }
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[cur][1], acc[0][1], 0, 0, 0);
+        if (!DBG || !(dflags & 2)) { ds_read16<2048>(xf[1 - cur][1], nxb); ds_read16<0>(wf[0], nwb); }
+        frag_wait<4>(wf[1]);                           // behind wf[1]'s read: wf[2], 2 x, wf[0]
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[cur][0], acc[1][0], 0, 0, 0);
+        if (!DBG || !(dflags & 1)) {
+            if constexpr (dma == 1) issue_x(1);
+            if constexpr (dma == 2) issue_w(1);
+        }
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[cur][1], acc[1][1], 0, 0, 0);
+        if (!DBG || !(dflags & 2)) ds_read16<2048>(wf[1], nwb);
+        frag_wait<4>(wf[2]);                           // behind wf[2]'s read: 2 x, wf[0], wf[1]
+        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], xf[cur][0], acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], xf[cur][1], acc[2][1], 0, 0, 0);
+        if (!DBG || !(dflags & 2)) ds_read16<4096>(wf[2], nwb);
+    };
+
+    int cj = 0, ct = 0, cs = 0, m0c, n0c;
+    tile_of(0, m0c, n0c);
+
+    // ---- the finished tile as 12 store-ready pieces per lane (16 rows x 64 B per instruction).  The store path of a CU moves
+    // ~14 B/clk (one 1-KiB global_store_dwordx4 per ~70 cycles, whichever wave issues it): a tile's 96 KiB cost ~7k cycles.
+    // Piece k = 4 ft + 2 tt + i: row 32 tt + 16 i + (lane >> 2) of the wave's 64, features 32 ft + 8 (lane & 3)...
+    bf16x8 so[12];
+    int spend = 12;                                    // next piece to store (12 = nothing parked)
+    int srows = 0;                                     // rows of the parked tile below this lane's first row that exist (m < M)
+    const bf16* sbase = out;
+    auto store_piece = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int ft = k >> 2, tt = (k >> 1) & 1, i = k & 1;
+        if (tt * 32 + i * 16 < srows) {
+            if (DBG && (dflags & 8)) asm volatile("" ::"v"(so[k]));
+            else *(bf16x8*)(sbase + (int64_t)(tt * 32 + i * 16) * N + ft * 32) = so[k];
+        }
+    };
+    auto store_next = [&]() {                          // wave-uniform dispatch: the pieces live in fixed registers
+        switch (spend) {
+            case 0: store_piece(std::integral_constant<int, 0>{}); break;
+            case 1: store_piece(std::integral_constant<int, 1>{}); break;
+            case 2: store_piece(std::integral_constant<int, 2>{}); break;
+            case 3: store_piece(std::integral_constant<int, 3>{}); break;
+            case 4: store_piece(std::integral_constant<int, 4>{}); break;
+            case 5: store_piece(std::integral_constant<int, 5>{}); break;
+            case 6: store_piece(std::integral_constant<int, 6>{}); break;
+            case 7: store_piece(std::integral_constant<int, 7>{}); break;
+            case 8: store_piece(std::integral_constant<int, 8>{}); break;
+            case 9: store_piece(std::integral_constant<int, 9>{}); break;
+            case 10: store_piece(std::integral_constant<int, 10>{}); break;
+            default: store_piece(std::integral_constant<int, 11>{}); break;
+        }
+        ++spend;
+    };
+    int s1 = 0, s2 = 0;                                // a store went out in the previous / the one-before-previous iteration
+    // MEASURED (8192 chunks, QKV): deferring is SLOWER -- 1.69 ms vs 1.32 ms with the twelve stores issued at once behind the
+    // epilogue: a store queued among the DMA instructions of a stage delays them (one in-order memory-instruction queue per CU),
+    // and the counted waits then also wait for store acknowledgements.  Kept switchable (dflags bit 5, debug build) for the record.
+    const bool defer = DBG && (dflags & 32);
+
+    step(std::integral_constant<int, 0>{}, ring_addr + xrel[1], ring_addr + wrel[1], std::integral_constant<int, 0>{});
+    for (;;) {
+        // stage (current + 1) has to have landed for every wave before its fragments are read ahead; every wave is done with the
+        // stage before the current one (its last reads completed before the current stage's first step began): its slot is refilled.
+        // Younger than that stage's last DMA instruction: the DMA instructions of two stages and up to two deferred stores.
+        unsigned long long tw = 0;
+        if (DBG) tw = __builtin_readcyclecounter();
+        switch ((w < 4 ? 8 : 6) + s1 + s2) {
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        if (DBG) twait += __builtin_readcyclecounter() - tw;
+        const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
+        const u32 sn = ring_addr + (u32)ns * SLOT;
+        step(std::integral_constant<int, 1>{}, sn + xrel[0], sn + wrel[0], std::integral_constant<int, 1>{});
+        if (++ct == nk) {
+            // ---- tile done: acc[ft][tt][i] = feature n0c + 96 wn + 32 ft + 16 hh + i of token m0c + 64 wm + 32 tt + r31.  Each
+            // 32 x 32 tile goes through the wave's LDS strip (lane writes its 2 x 16 B, rows of 64 B, unit ^ ((row >> 2) & 3)) and
+            // comes back as pieces of 16 rows x 64 contiguous bytes (nk >= 12: the previous tile's pieces have all left by now).
+            unsigned long long te = 0;
+            if (DBG) te = __builtin_readcyclecounter();
+            const int row0 = m0c + wm * 64 + (lane >> 2);
+            srows = M - row0;
+            const int64_t lane_off = (int64_t)row0 * N + n0c + wn * 96 + (lane & 3) * 8;
+            sbase = out + lane_off;
+            if (EPI == EPI_RESID) {                    // the residual arrives in store layout, all twelve loads in flight at once
+#pragma unroll
+                for (int k = 0; k < 12; ++k) {
+                    const int ft = k >> 2, tt = (k >> 1) & 1, i = k & 1;
+                    so[k] = bf16x8{};
+                    if (tt * 32 + i * 16 < srows) so[k] = *(const bf16x8*)(resid + lane_off + (int64_t)(tt * 32 + i * 16) * N + ft * 32);
+                }
+            }
+#pragma unroll
+            for (int ft = 0; ft < 3; ++ft) {
+                const float* bp = bias + n0c + wn * 96 + ft * 32;      // uniform address: scalar loads
+                float bv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { const float lo = bp[i], hi = bp[16 + i]; bv[i] = hh ? hi : lo; }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 v0 = {acc[ft][tt][8 * j] + bv[8 * j], acc[ft][tt][8 * j + 1] + bv[8 * j + 1], acc[ft][tt][8 * j + 2] + bv[8 * j + 2], acc[ft][tt][8 * j + 3] + bv[8 * j + 3]};
+                        f32x4 v1 = {acc[ft][tt][8 * j + 4] + bv[8 * j + 4], acc[ft][tt][8 * j + 5] + bv[8 * j + 5], acc[ft][tt][8 * j + 6] + bv[8 * j + 6], acc[ft][tt][8 * j + 7] + bv[8 * j + 7]};
+                        if (EPI == EPI_GELU) { v0 = gelu_poly4(v0); v1 = gelu_poly4(v1); }
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] = (bf16)v0[e]; o[4 + e] = (bf16)v1[e]; }
+                        *(bf16x8*)(strip + r31 * 64 + (((2 * hh + j) ^ ((r31 >> 2) & 3)) * 16)) = o;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = (lane >> 2) + 16 * i, u = lane & 3;
+                        bf16x8 o = *(const bf16x8*)(strip + row * 64 + ((u ^ ((row >> 2) & 3)) * 16));
+                        const int k = ft * 4 + tt * 2 + i;
+                        if (EPI == EPI_RESID) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (bf16)(bf2f(o[e]) + bf2f(so[k][e]));
+                        }
+                        so[k] = o;
+                    }
+                }
+            }
+            spend = 0;
+            if (!defer) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) store_next();
+            }
+#pragma unroll
+            for (int ft = 0; ft < 3; ++ft)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[ft][tt][e] = 0.f;
+            if (DBG) tepi += __builtin_readcyclecounter() - te;
+            ct = 0;
+            if (++cj == ntiles) break;
+            tile_of(cj, m0c, n0c);
+        }
+        if (defer) {
+            s2 = s1;
+            s1 = 0;
+            if (spend < 12) { store_next(); s1 = 1; }
+        }
+        step(std::integral_constant<int, 0>{}, sn + xrel[1], sn + wrel[1], std::integral_constant<int, 2>{});
+        advance();
+        cs = ns;
+    }
+    while (spend < 12) store_next();                   // the last tile's pieces
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the fragments read ahead for a step that does not exist have landed now; their registers stayed allocated until here
+    asm volatile("" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[1][0]), "+v"(xf[1][1]));
+    if (DBG) {
+        const unsigned long long tc3 = __builtin_readcyclecounter();
+        if (lane == 0) {
+            atomicAdd(dbg + 0, 1ull); atomicAdd(dbg + 1, tc1 - tc0); atomicAdd(dbg + 2, tc3 - tc1); atomicAdd(dbg + 3, tepi); atomicAdd(dbg + 4, twait);
+            atomicAdd(dbg + 5, (unsigned long long)ntiles);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // attention: one workgroup = (sequence, head); K rows and V^T of the whole sequence staged in LDS once; each wave
 // takes 16 queries per round (rounds of 64) and keeps its full score strip S^T[keys, 16] in registers
 // (<= 32 key tiles): exact softmax, no online rescaling.
@@ -946,19 +1264,22 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
                     bf16x8 vf;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { vf[i] = v0[i]; vf[4 + i] = v1[i]; }
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);   // O^T: V^T is the A operand
                 }
             }
         }
-        // D layout: row = query 4*kg + i, col = dim fr (+16*dt).  Row sums live in lanes whose fr == that query.
+        // D layout of O^T: row = dim 4*kg + i (+16*dt), col = query fr -- the lane's own query, whose row sum it already holds:
+        // two 8-byte stores per lane and round (the store path is paid per instruction, ~70 cycles each: 2-byte stores of the
+        // O layout made this kernel store-issue-bound).
+        if (q0 + fr < L) {
+            const float rden = 1.0f / sum;
+            bf16* dst = ctx + (int64_t)(t0 + q0 + fr) * H + head * DH + kg * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int qi = kg * 4 + i;
-            const float den = __shfl(sum, qi);
-            if (q0 + qi < L) {
-                bf16* dst = ctx + (int64_t)(t0 + q0 + qi) * H + head * DH + fr;
-                dst[0] = (bf16)(o[0][i] / den);
-                dst[16] = (bf16)(o[1][i] / den);
+            for (int dt = 0; dt < 2; ++dt) {
+                bf16x4 ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = (bf16)(o[dt][i] * rden);
+                *(bf16x4*)(dst + dt * 16) = ov;
             }
         }
         qf = qn;
@@ -1418,6 +1739,31 @@ static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16
     }
 }
 
+template <int EPI>
+static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu, int batch,
+                         int N, int K, hipStream_t s) {
+    static const bool want_dbg = getenv("RMU_G3_DBG") != nullptr;
+    static const hipError_t attr_rc = hipFuncSetAttribute(want_dbg ? (const void*)k_gemm3<EPI, true> : (const void*)k_gemm3<EPI, false>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
+    (void)attr_rc;
+    static const int n_wg = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus / 8 * 8; }();
+    if (!want_dbg) {
+        hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, 0);
+        return;
+    }
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+    static const int dflags = getenv("RMU_G3_FLAGS") ? atoi(getenv("RMU_G3_FLAGS")) : 0;   // 1: no DMA in the loop, 2: no fragment reads, 4: no epilogue (timing only)
+    hipLaunchKernelGGL((k_gemm3<EPI, true>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, dbg, dflags);
+    unsigned long long h[6];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, dbg, 48, hipMemcpyDeviceToHost);
+    (void)hipMemset(dbg, 0, 64);
+    const double nw = (double)h[0], stages = (double)h[5] / nw * (K / 32);
+    fprintf(stderr, "[gemm3<%d> N=%d K=%d dbg] waves=%llu tiles/wg=%.1f ticks/wave: prologue=%.0f loop=%.0f (per stage %.0f; of which vmcnt+barrier %.0f, epilogue %.0f)\n",
+            EPI, N, K, h[0], (double)h[5] / nw, h[1] / nw, h[2] / nw, h[2] / nw / stages, h[4] / nw / stages, h[3] / nw / stages);
+}
+
 template <int KT, int NW>
 static void launch_attn2(int batch, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
     constexpr int lds = NW * (KT * 32 * 64 + 32 * (KT * 32 * 2 + 16));
@@ -1459,7 +1805,9 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     const dim3 ln_grid((unsigned)((cap + 3) / 4));
     const dim3 at_grid(NH, (unsigned)batch);   // one workgroup per (head, sequence)
     for (const BertLayer& L : m->layers) {
-        launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
+        static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
+        if (g3_mask & 1) launch_gemm3<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
+        else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         static const bool attn2 = getenv("RMU_ATTN2") && atoi(getenv("RMU_ATTN2")) != 0;   // opt-in: measured 7% slower than k_attention at L ~ 128
         if (attn2) {
             if (max_len <= 128) launch_attn2<4, 4>(batch, m->qkv, m->cu, m->ctx, s);
@@ -1470,11 +1818,20 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
         // measured: the fused 128x384 kernel (one workgroup per CU, serial LN pass) is 12% slower than GEMM + LN launches
         static const bool fuse_ln = getenv("RMU_FUSED_LN") != nullptr;
-        if (fuse_ln) {
+        if (g3_mask & 2) {
+            launch_gemm3<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, H, H, s);
+            hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
+        } else if (fuse_ln) {
             launch_gemm_ln(m->ctx, L.wo, L.bo, m->h, L.ln1g, L.ln1b, eps, m->h1, m->cu, batch, cap, H, s);
         } else {
             launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
             hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
+        }
+        if (g3_mask & 4) {
+            launch_gemm3<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, FF, H, s);
+            launch_gemm3<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, H, FF, s);
+            hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
+            continue;
         }
         static const bool fused_ffn = !(getenv("RMU_FUSED_FFN") && atoi(getenv("RMU_FUSED_FFN")) == 0);
         if (fused_ffn) {          // FFN1 + GELU + FFN2 + residual + LayerNorm in one kernel: the 1536-wide intermediate stays on chip
