@@ -134,26 +134,36 @@ __global__ void k_cu_seqlens(const int* __restrict__ lens, int batch, int max_le
     for (int i = lo; i < hi; ++i) { run += min(max(lens[i], 0), max_len); cu[i + 1] = run; }
 }
 
-// wave-wide LayerNorm of 384 values held 6 per lane
-__device__ __forceinline__ void ln_row(float (&v)[6], const float* __restrict__ g, const float* __restrict__ b, int c0,
+// wave-wide LayerNorm of 384 values held 8 per lane by lanes 0..47 (16-byte row pieces: a CU's load/store path is paid per
+// wave instruction, ~70 cycles per store whatever its width -- with 4-byte pieces k_layernorm was bound by store issue,
+// 0.39 ms per call for 1.6 GB of traffic); lanes 48..63 hold zeros and are masked out of the variance
+__device__ __forceinline__ void ln_row(float (&v)[8], bool act, const float* __restrict__ g, const float* __restrict__ b, int c0,
                                        float eps) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) s += v[i];
+    for (int i = 0; i < 8; ++i) s += v[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mu = s * (1.0f / H);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const float d = v[i] - mu; q = fmaf(d, d, q); }
+    for (int i = 0; i < 8; ++i) { const float d = act ? v[i] - mu : 0.f; q = fmaf(d, d, q); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rs = rsqrtf(q * (1.0f / H) + eps);
+    if (act) {
+        const f32x4 g0 = *(const f32x4*)(g + c0), g1 = *(const f32x4*)(g + c0 + 4);
+        const f32x4 b0 = *(const f32x4*)(b + c0), b1 = *(const f32x4*)(b + c0 + 4);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = (v[i] - mu) * rs * g[c0 + i] + b[c0 + i];
+        for (int i = 0; i < 4; ++i) {
+            v[i] = (v[i] - mu) * rs * g0[i] + b0[i];
+            v[4 + i] = (v[4 + i] - mu) * rs * g1[i] + b1[i];
+        }
+    }
 }
 
-// embeddings + LayerNorm: one wave per (sequence, position); packed output row cu[b] + pos
+// embeddings + LayerNorm: one wave per (sequence, position); packed output row cu[b] + pos.  (Four slots per wave, as in
+// k_layernorm below, measured slower here: half the slots are padding and exit at once.)
 __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, const int* __restrict__ type_ids,
                                                   const int* __restrict__ cu, int batch, int max_len,
                                                   const float* __restrict__ wemb, const float* __restrict__ pemb,
@@ -170,33 +180,84 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, c
     id = min(max(id, 0), vocab - 1);
     int tt = type_ids ? type_ids[slot] : 0;
     tt = min(max(tt, 0), type_vocab - 1);
-    const int c0 = lane * 6;
-    float v[6];
+    const bool act = lane < 48;
+    const int c0 = lane * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (act) {
+        const float* we = wemb + (int64_t)id * H + c0;
+        const float* pe = pemb + (int64_t)pos * H + c0;
+        const float* te = temb + (int64_t)tt * H + c0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-        v[i] = wemb[(int64_t)id * H + c0 + i] + pemb[(int64_t)pos * H + c0 + i] + temb[(int64_t)tt * H + c0 + i];
-    ln_row(v, g, bta, c0, eps);
-    bf16* o = out + ((int64_t)cu[b] + pos) * H + c0;
+        for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 a = *(const f32x4*)(we + 4 * hf), p = *(const f32x4*)(pe + 4 * hf), t = *(const f32x4*)(te + 4 * hf);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = (bf16)v[i];
+            for (int i = 0; i < 4; ++i) v[4 * hf + i] = a[i] + p[i] + t[i];
+        }
+    }
+    ln_row(v, act, g, bta, c0, eps);
+    if (act) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16)v[i];
+        *(bf16x8*)(out + ((int64_t)cu[b] + pos) * H + c0) = o;
+    }
 }
 
-// out = LayerNorm(y) (y already holds GEMM + bias + residual); one wave per token
+// out = LayerNorm(y) (y already holds GEMM + bias + residual); a wave takes LN_ROWS consecutive tokens with all their loads in
+// flight before the first reduction (one row per wave left the kernel latency-bound at ~4 TB/s of its 1.6 GB)
+constexpr int LN_ROWS = 4;
 __global__ __launch_bounds__(256) void k_layernorm(const bf16* __restrict__ y, const int* __restrict__ cu, int batch,
                                                    const float* __restrict__ g, const float* __restrict__ bta, float eps,
                                                    bf16* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= cu[batch]) return;
-    const int c0 = lane * 6;
-    float v[6];
-    const bf16* r = y + t * H + c0;
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+    const int64_t M = cu[batch];
+    if (t0 >= M) return;
+    const bool act = lane < 48;
+    const int c0 = lane * 8;
+    bf16x8 r[LN_ROWS];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = bf2f(r[i]);
-    ln_row(v, g, bta, c0, eps);
-    bf16* o = out + t * H + c0;
+    for (int u = 0; u < LN_ROWS; ++u) {
+        r[u] = bf16x8{};
+        if (act && t0 + u < M) r[u] = *(const bf16x8*)(y + (t0 + u) * H + c0);
+    }
+    f32x4 g0 = {}, g1 = {}, b0 = {}, b1 = {};
+    if (act) { g0 = *(const f32x4*)(g + c0); g1 = *(const f32x4*)(g + c0 + 4); b0 = *(const f32x4*)(bta + c0); b1 = *(const f32x4*)(bta + c0 + 4); }
+    float v[LN_ROWS][8], s[LN_ROWS], q[LN_ROWS];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = (bf16)v[i];
+    for (int u = 0; u < LN_ROWS; ++u) {
+        s[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[u][i] = bf2f(r[u][i]); s[u] += v[u][i]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < LN_ROWS; ++u) s[u] += __shfl_xor(s[u], o);
+#pragma unroll
+    for (int u = 0; u < LN_ROWS; ++u) {
+        s[u] *= (1.0f / H);
+        q[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = act ? v[u][i] - s[u] : 0.f; q[u] = fmaf(d, d, q[u]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < LN_ROWS; ++u) q[u] += __shfl_xor(q[u], o);
+#pragma unroll
+    for (int u = 0; u < LN_ROWS; ++u) {
+        const float rs = rsqrtf(q[u] * (1.0f / H) + eps);
+        if (act && t0 + u < M) {
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i] = (bf16)((v[u][i] - s[u]) * rs * g0[i] + b0[i]);
+                o[4 + i] = (bf16)((v[u][4 + i] - s[u]) * rs * g1[i] + b1[i]);
+            }
+            *(bf16x8*)(out + (t0 + u) * H + c0) = o;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -526,7 +587,7 @@ constexpr int W1_NI = 4, W2_NI = 6;                    // LDS-DMA wave-instructi
 constexpr int TSTR = H * 2 + 16;                       // pre-LN tile row stride (epilogue, reuses the ring)
 constexpr int B1_OFF = NSLOT * SLOT > TOK * TSTR ? NSLOT * SLOT : ((TOK * TSTR + 255) / 256) * 256;   // b1 (1536 fp32) behind ring / tile
 constexpr int LDS_BYTES = B1_OFF + FF * 4;
-constexpr int PRE = 4;                                 // fragment reads in flight
+constexpr int PRE = 4;                                 // fragment reads in flight (8 measured the same: 3.35 ms)
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 __host__ __device__ constexpr int slab_ni(int t) { return (t % PERIOD) < W1_SLABS ? W1_NI : W2_NI; }
 // DMA instructions that may still be in flight when slab t must have landed: those of slabs t+1 .. t+NSLOT-2
@@ -566,6 +627,7 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
                                                    unsigned long long* __restrict__ dbg /* RMU_FFN_DBG: cycle counters, else null */) {
     using namespace ffn;
     const unsigned long long t_begin = DBG ? clock64() : 0;
+    const int dflags = DBG ? (int)dbg[7] : 0;   // timing ablations (wrong results): 1 no DMA in the loop, 2 no fragment reads, 4 no GELU
     unsigned long long t_wait = 0, t_g1 = 0, t_g2 = 0;
     const int M = cu[batch];
     const int m0 = blockIdx.x * TOK;
@@ -715,11 +777,13 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
                     if constexpr (n + PRE < 16) {
                         constexpr int nn = n + PRE;
                         constexpr int ks2 = last ? (nn & 7) : (nn >> 1), ft2 = last ? (nn >> 3) : (nn & 1);
-                        ds_read16<ft2 * 8192>(fq[n % PRE], sa + a1rel[ks2]);
+                        if (!DBG || !(dflags & 2)) ds_read16<ft2 * 8192>(fq[n % PRE], sa + a1rel[ks2]);
                     }
-                    if constexpr (n % 2 == 1 && n / 2 < pni) issue_part(pc, pi, pslot, n / 2);     // steps 1, 3, 5, ...
-                    if constexpr (last && n == 10) gelu_group(0, 0);
-                    if constexpr (last && n == 13) gelu_group(0, 1);
+                    if constexpr (n % 2 == 1 && n / 2 < pni) { if (!DBG || !(dflags & 1)) issue_part(pc, pi, pslot, n / 2); }     // steps 1, 3, 5, ...
+                    if (!DBG || !(dflags & 4)) {
+                        if constexpr (last && n == 10) gelu_group(0, 0);
+                        if constexpr (last && n == 13) gelu_group(0, 1);
+                    }
                 });
             } else {
                 // GEMM2 over feature tile t = i - 3 of the chunk: 2 k-steps x 12 output tiles = 24 fragments, n = s * 12 + ot.
@@ -739,17 +803,19 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
                     acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PRE], __builtin_bit_cast(bf16x8, pfu[t & 1][s2]), acc2[ot], 0, 0, 0);
                     if constexpr (n + PRE < 24) {
                         constexpr int nn = n + PRE;
-                        ds_read16<(nn % 12) * 2048>(fq[n % PRE], ab[nn / 12]);
+                        if (!DBG || !(dflags & 2)) ds_read16<(nn % 12) * 2048>(fq[n % PRE], ab[nn / 12]);
                     }
                     // activation schedule: every 12-MFMA half-slab carries two register groups, each the half-slab before the
                     // k-step that consumes it: tile 0 k-step 1 | tile 1 k-step 0 | tile 1 k-step 1 | (none)
-                    if constexpr (t == 0 && n == 2) gelu_group(0, 2);
-                    if constexpr (t == 0 && n == 7) gelu_group(0, 3);
-                    if constexpr (t == 0 && n == 14) gelu_group(1, 0);
-                    if constexpr (t == 0 && n == 19) gelu_group(1, 1);
-                    if constexpr (t == 1 && n == 2) gelu_group(1, 2);
-                    if constexpr (t == 1 && n == 7) gelu_group(1, 3);
-                    if constexpr (n % 4 == 0 && n / 4 < pni) issue_part(pc, pi, pslot, n / 4);     // steps 0, 4, 8, ...
+                    if (!DBG || !(dflags & 4)) {
+                        if constexpr (t == 0 && n == 2) gelu_group(0, 2);
+                        if constexpr (t == 0 && n == 7) gelu_group(0, 3);
+                        if constexpr (t == 0 && n == 14) gelu_group(1, 0);
+                        if constexpr (t == 0 && n == 19) gelu_group(1, 1);
+                        if constexpr (t == 1 && n == 2) gelu_group(1, 2);
+                        if constexpr (t == 1 && n == 7) gelu_group(1, 3);
+                    }
+                    if constexpr (n % 4 == 0 && n / 4 < pni) { if (!DBG || !(dflags & 1)) issue_part(pc, pi, pslot, n / 4); }     // steps 0, 4, 8, ...
                 });
             }
             if (DBG) { if (i < W1_SLABS) t_g1 += clock64() - tc0; else t_g2 += clock64() - tc0; }
@@ -1268,18 +1334,23 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
                 }
             }
         }
-        // D layout of O^T: row = dim 4*kg + i (+16*dt), col = query fr -- the lane's own query, whose row sum it already holds:
-        // two 8-byte stores per lane and round (the store path is paid per instruction, ~70 cycles each: 2-byte stores of the
-        // O layout made this kernel store-issue-bound).
-        if (q0 + fr < L) {
+        // D layout of O^T: row = dim 4*kg + i (+16*dt), col = query fr -- the lane's own query, whose row sum it already holds.
+        // Lanes kg and kg ^ 1 (lane ^ 16) trade one 8-byte half so that each stores 8 consecutive dims: ONE 16-byte store per
+        // lane and round (2-byte stores of the O layout made this kernel store-issue-bound).
+        {
             const float rden = 1.0f / sum;
-            bf16* dst = ctx + (int64_t)(t0 + q0 + fr) * H + head * DH + kg * 4;
+            union { bf16x4 v; int i[2]; } a0, a1, snd, rcv;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                bf16x4 ov;
+            for (int i = 0; i < 4; ++i) { a0.v[i] = (bf16)(o[0][i] * rden); a1.v[i] = (bf16)(o[1][i] * rden); }
+            const bool odd = kg & 1;
+            snd.v = odd ? a0.v : a1.v;                 // even kg keeps dims 4kg.. and gets 4(kg+1)..; odd keeps 16+4kg.. and gets 16+4(kg-1)..
+            rcv.i[0] = __shfl_xor(snd.i[0], 16);
+            rcv.i[1] = __shfl_xor(snd.i[1], 16);
+            if (q0 + fr < L) {
+                bf16x8 ov;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = (bf16)(o[dt][i] * rden);
-                *(bf16x4*)(dst + dt * 16) = ov;
+                for (int i = 0; i < 4; ++i) { ov[i] = odd ? rcv.v[i] : a0.v[i]; ov[4 + i] = odd ? a1.v[i] : rcv.v[i]; }
+                *(bf16x8*)(ctx + (int64_t)(t0 + q0 + fr) * H + head * DH + (odd ? 16 + 4 * (kg - 1) : 4 * kg)) = ov;
             }
         }
         qf = qn;
@@ -1469,23 +1540,44 @@ __global__ __launch_bounds__(64) void k_meanpool_l2(const bf16* __restrict__ h, 
                                                     float* __restrict__ out, int64_t out_stride) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int t0 = cu[b], L = cu[b + 1] - t0;
-    const int c0 = lane * 6;
-    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < L; ++t) {
-        const bf16* r = h + (int64_t)(t0 + t) * H + c0;
+    const bool act = lane < 48;                        // 16-byte row pieces, four rows in flight
+    const int c0 = lane * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (act) {
+        const bf16* r = h + (int64_t)t0 * H + c0;
+        int t = 0;
+        for (; t + 4 <= L; t += 4) {
+            bf16x8 v[4];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s[i] += bf2f(r[i]);
+            for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(r + (int64_t)(t + u) * H);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[i] += bf2f(v[u][i]);
+        }
+        for (; t < L; ++t) {
+            const bf16x8 v = *(const bf16x8*)(r + (int64_t)t * H);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += bf2f(v[i]);
+        }
     }
     const float inv = 1.0f / fmaxf((float)L, 1e-9f);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { s[i] *= inv; q = fmaf(s[i], s[i], q); }
+    for (int i = 0; i < 8; ++i) { s[i] *= inv; q = fmaf(s[i], s[i], q); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rn = 1.0f / fmaxf(sqrtf(q), 1e-12f);
-    float* dst = out + (int64_t)b * out_stride + c0;
+    if (act) {
+        float* dst = out + (int64_t)b * out_stride + c0;
+        if ((((uintptr_t)out | (uintptr_t)(out_stride * 4)) & 15) == 0) {   // any caller stride is legal: wide stores when aligned
+            *(f32x4*)dst = f32x4{s[0] * rn, s[1] * rn, s[2] * rn, s[3] * rn};
+            *(f32x4*)(dst + 4) = f32x4{s[4] * rn, s[5] * rn, s[6] * rn, s[7] * rn};
+        } else {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dst[i] = s[i] * rn;
+            for (int i = 0; i < 8; ++i) dst[i] = s[i] * rn;
+        }
+    }
 }
 
 // BertForSequenceClassification(num_labels=1): logit = wc . tanh(Wp h_cls + bp) + bc ; one block per sequence
@@ -1726,6 +1818,10 @@ static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16
     static unsigned long long* dbg = nullptr;
     if (want_dbg && !dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
     const dim3 grid((unsigned)((m_cap + ffn::TOK - 1) / ffn::TOK));
+    if (want_dbg) {
+        static const unsigned long long fl = getenv("RMU_FFN_FLAGS") ? strtoull(getenv("RMU_FFN_FLAGS"), nullptr, 10) : 0ull;
+        (void)hipMemcpyAsync(dbg + 7, &fl, 8, hipMemcpyHostToDevice, s);
+    }
     if (want_dbg) hipLaunchKernelGGL(k_ffn_fused<true>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
     else hipLaunchKernelGGL(k_ffn_fused<false>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
     if (want_dbg) {
@@ -1802,7 +1898,7 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, (const int*)ids, (const int*)type_ids,
                        (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
                        m->cfg.type_vocab, m->h);
-    const dim3 ln_grid((unsigned)((cap + 3) / 4));
+    const dim3 ln_grid((unsigned)((cap + 4 * LN_ROWS - 1) / (4 * LN_ROWS)));
     const dim3 at_grid(NH, (unsigned)batch);   // one workgroup per (head, sequence)
     for (const BertLayer& L : m->layers) {
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
