@@ -1,0 +1,25 @@
+"""Runs ONE encoder kernel variant (selected by the environment, read once per process by librmu) on a fixed synthetic batch
+and prints its parity against the fp64 oracle as JSON.  Executed by tests/test_encoder_gpu.py in a fresh interpreter."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402
+from tests.helpers import bert_weights_numpy, make_bert, synth_tokens  # noqa: E402
+from ragmeup_amd.bert import BertEncoder  # noqa: E402
+
+m = make_bert(seed=0, layers=6)
+w = bert_weights_numpy(m)
+enc = BertEncoder(w, layers=6)
+# 300 sequences ~ 38k tokens: more than one 256-token tile per workgroup of the persistent GEMM, ragged tails everywhere
+ids, tt, lens = synth_tokens(300, seed=11, lmin=3, lmax=250, mean=128, std=60)
+got = enc.encode_ids(ids, lens, None, mode=0).cpu().numpy()
+sel = np.arange(0, 300, 10)                      # the oracle is fp64 numpy: compare a sample of 30 sequences
+ref = O.embed_pool(O.bert_hidden(w, ids[sel], np.zeros_like(ids[sel]), lens[sel]), lens[sel])
+g = got[sel]
+cos = (g * ref).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(ref, axis=1)
+print("RESULT " + json.dumps({"min_cos": float(cos.min()), "finite": bool(np.isfinite(got).all()),
+                              "norm_err": float(np.abs(np.linalg.norm(got, axis=1) - 1).max())}))

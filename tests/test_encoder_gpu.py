@@ -171,3 +171,20 @@ def test_cross_encoder_100_pairs_tolerance_1e2(cross):
     for a, b in zip(order_g[:10], order_r[:10]):
         assert a == b or abs(ref[a] - ref[b]) < 1e-2, (a, b, ref[a], ref[b])
     assert np.abs(got - ref).max() <= 2e-2 * (1 + np.abs(ref).max())
+
+
+@pytest.mark.parametrize("env", [{"RMU_GEMM3": "0"}, {"RMU_GEMM3": "7"}, {"RMU_GEMM3": "2", "RMU_FUSED_FFN": "0"},
+                                 {"RMU_ATTN2": "1"}, {"RMU_FUSED_LN": "1", "RMU_FUSED_FFN": "0"}],
+                         ids=["k_gemm_only", "k_gemm3_everywhere", "unfused_ffn", "attention2", "gemm_ln"])
+def test_every_switchable_kernel_variant_keeps_parity(env):
+    """The opt-in kernels (kept for the measurements DESIGN.md quotes) are held to the same bar as the default path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "enc_variant_driver.py")], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["finite"] and res["min_cos"] >= 0.999 and res["norm_err"] < 1e-5, res
