@@ -115,6 +115,22 @@ __global__ void k_permute_w2(const bf16* __restrict__ src, bf16* __restrict__ ds
     dst[i] = src[blk + (e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4))];
 }
 
+// Weight copy for k_gemm3's LDS-DMA: block (nb, kb) = rows [16 nb, +16) x k [32 kb, +32) stored as the very 1 KiB its ring
+// slot holds (row r of the block at byte 64 r, logical 16-byte unit u at physical unit u ^ ((r >> 2) & 3)), blocks in [nb][kb]
+// order: one DMA wave instruction then reads 1 KiB of CONTIGUOUS bytes (8 cache lines) instead of 16 rows x 64 B (16 lines) --
+// the address path of a CU is paid per line touched.  One thread per 16-byte unit of the destination.
+__global__ void k_tile_w(const bf16* __restrict__ src, bf16* __restrict__ dst, int N, int K) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= (int64_t)N * K / 8) return;
+    const int64_t blk = d >> 6;
+    const int within = (int)(d & 63), r = within >> 2, pu = within & 3;
+    const int u = pu ^ ((r >> 2) & 3);
+    const int kbn = K / 32;
+    const int64_t nb = blk / kbn;
+    const int kb = (int)(blk % kbn);
+    *(bf16x8*)(dst + d * 8) = *(const bf16x8*)(src + (nb * 16 + r) * K + kb * 32 + u * 8);
+}
+
 // cu[0] = 0, cu[b+1] = cu[b] + clamp(lens[b], 0, max_len); one block
 __global__ void k_cu_seqlens(const int* __restrict__ lens, int batch, int max_len, int* __restrict__ cu) {
     __shared__ int part[1024];
@@ -972,13 +988,13 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
     int ij = 0, it = 0, islot = 0;
     const char *ia, *iw;
     u32 xoff[2];
-    const u32 woff = (u32)(((size_t)(lane >> 2) * K + (((lane & 3) ^ (lane >> 4)) * 8)) * 2);
+    const u32 woff = (u32)lane * 16;                   // W is the k_tile_w copy: a DMA instruction reads one contiguous 1-KiB block
     auto set_issue_tile = [&](int j) {
         int m0, n0;
         tile_of(j, m0, n0);
         const int rows_here = M - m0;
         ia = (const char*)(A + (size_t)m0 * K);
-        iw = (const char*)(W + (size_t)n0 * K);
+        iw = (const char*)W + (size_t)(n0 / 16) * (K / 32) * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (w + 8 * i) * 16 + (lane >> 2);
@@ -996,7 +1012,7 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
         if (i == 1 && w >= 4) return;
         u32 o = woff;
         asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(iw + (size_t)it * 64 + (size_t)(w + 8 * i) * 16 * K * 2) + o),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(iw + ((size_t)(w + 8 * i) * (K / 32) + it) * 1024) + o),
                                          (__attribute__((address_space(3))) void*)(ring + islot * SLOT + XBYTES + (w + 8 * i) * 1024), 16, 0, 0);
     };
     auto advance = [&]() {
@@ -1616,6 +1632,7 @@ __global__ __launch_bounds__(128) void k_cls_head(const bf16* __restrict__ h, co
 struct BertLayer {
     bf16 *wqkv, *wo, *w1, *w2;
     bf16* w2p;      // W2 with the columns of every 32-block permuted to the fused FFN kernel's k-slot order
+    bf16 *wqkv_t, *wo_t, *w1_t, *w2_t;   // k_tile_w copies for k_gemm3
     float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 struct rmu_bert {
@@ -1730,6 +1747,13 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
         rc |= copy_f32(m, &L.b2, wptr[wi++], H, 1.f, s);
         rc |= copy_f32(m, &L.ln2g, wptr[wi++], H, 1.f, s);
         rc |= copy_f32(m, &L.ln2b, wptr[wi++], H, 1.f, s);
+        {   // k_gemm3's tiled weight copies (all four: the RMU_GEMM3 mask can route any of the layer's GEMMs through it)
+            struct { bf16* src; bf16** dst; int n, k; } tw[4] = {{L.wqkv, &L.wqkv_t, 3 * H, H}, {L.wo, &L.wo_t, H, H}, {L.w1, &L.w1_t, FF, H}, {L.w2, &L.w2_t, H, FF}};
+            for (auto& t : tw) {
+                rc |= dev_alloc(m, t.dst, (size_t)t.n * t.k);
+                if (!rc) hipLaunchKernelGGL(k_tile_w, dim3((unsigned)(((size_t)t.n * t.k / 8 + 255) / 256)), dim3(256), 0, s, (const bf16*)t.src, *t.dst, t.n, t.k);
+            }
+        }
     }
     if (!rc && cfg->has_head) {
         rc |= copy_f32(m, &m->wp, wptr[wi++], (size_t)H * H, 1.f, s);
@@ -1902,7 +1926,7 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     const dim3 at_grid(NH, (unsigned)batch);   // one workgroup per (head, sequence)
     for (const BertLayer& L : m->layers) {
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
-        if (g3_mask & 1) launch_gemm3<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
+        if (g3_mask & 1) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         static const bool attn2 = getenv("RMU_ATTN2") && atoi(getenv("RMU_ATTN2")) != 0;   // opt-in: measured 7% slower than k_attention at L ~ 128
         if (attn2) {
@@ -1915,7 +1939,7 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
         // measured: the fused 128x384 kernel (one workgroup per CU, serial LN pass) is 12% slower than GEMM + LN launches
         static const bool fuse_ln = getenv("RMU_FUSED_LN") != nullptr;
         if (g3_mask & 2) {
-            launch_gemm3<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, H, H, s);
+            launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
             hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
         } else if (fuse_ln) {
             launch_gemm_ln(m->ctx, L.wo, L.bo, m->h, L.ln1g, L.ln1b, eps, m->h1, m->cu, batch, cap, H, s);
@@ -1924,8 +1948,8 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
             hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
         }
         if (g3_mask & 4) {
-            launch_gemm3<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, FF, H, s);
-            launch_gemm3<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, H, FF, s);
+            launch_gemm3<EPI_GELU>(m->h1, L.w1_t, L.b1, nullptr, m->mid, m->cu, batch, FF, H, s);
+            launch_gemm3<EPI_RESID>(m->mid, L.w2_t, L.b2, m->h1, m->y, m->cu, batch, H, FF, s);
             hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
             continue;
         }
