@@ -12,7 +12,7 @@ screening ladder -> merges -> exact fp32 re-score of 32 candidates per query, re
 
 `value` is timed with nothing but the product path inside the bracket (no per-launch events); the dominant kernel's
 launch durations (roofline) are measured afterwards, on the same inputs, with hipEvents on the stream the kernels run on.
-At N = 1 the same run also reports, under "secondary", every other BASELINE.json configuration with its own roofline and
+At N = 1 the same run also reports, under "secondary", every other BASELINE.json configuration (C1 on the GPU path, C2, C3, C5) with its own roofline and
 CPU figure: the exact fp32 scan (API switch), the HBM-bound batch sizes 1 / 32 / 128, config 2 (1M rows), config 3
 (chunk embedding) and config 5 (dense top-100 -> cross-encoder rerank -> top-10), and the CPU baselines of config 1 timed on
 this box's host cores (count stated).  Inputs are generated on the device and are resident in HBM before any timed region.
@@ -172,7 +172,7 @@ def encoder_flops(lens) -> float:
 
 
 def encoder_roofline(tf: float) -> dict:
-    return {"kernel": "whole forward: k_ffn_fused (bf16 MFMA 32x32x16: FFN1+GELU+FFN2+residual+LayerNorm), k_gemm (16x16x32: QKV, out-proj), k_attention, k_layernorm", "bound": "mfma", "achieved": round(tf, 2),
+    return {"kernel": "whole forward: k_ffn_fused (bf16 MFMA 32x32x16: FFN1+GELU+FFN2+residual+LayerNorm), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj), k_attention, k_layernorm", "bound": "mfma", "achieved": round(tf, 2),
             "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
             "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches)"}
 
@@ -192,6 +192,62 @@ def leg_embed(args) -> dict:
     if not args.no_cpu_baseline:
         leg["cpu_baseline"] = cpu_encoder_baseline(head=False)
     enc.close()
+    return leg
+
+
+def leg_c1(args) -> dict:
+    """BASELINE.json configs[0], the reference's own CPU-runnable case, on the GPU path: a 10k-chunk corpus is embedded and
+    indexed, then ONE query per call goes through embed_query (encoder, batch 1) + dense top-10 -- the call pattern of
+    RAGHelper's retriever.  Latency-bound by construction (a handful of launches per query); the CPU baseline is the same
+    pattern with transformers' BertModel + a torch-CPU scan."""
+    from ragmeup_amd import FlatIndex
+    from ragmeup_amd.bert import BertEncoder
+    enc = BertEncoder(bert_weights(0, False), layers=6)
+    n, nq = 10_000, 64
+    ids, _, lens = synth_tokens(n, seed=21)
+    ids_t, lens_t = torch.as_tensor(ids).cuda(), torch.as_tensor(lens).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = enc.encode_ids(ids_t, lens_t, None, 0)
+    idx = FlatIndex(384, capacity_hint=n)
+    idx.add(emb)
+    torch.cuda.synchronize()
+    index_s = time.perf_counter() - t0
+    qids, _, qlens = synth_tokens(nq, seed=22, lmin=8, lmax=24, mean=16, std=4)
+    qs = [(torch.as_tensor(qids[i:i + 1, :qlens[i]]).cuda(), torch.as_tensor(qlens[i:i + 1]).cuda()) for i in range(nq)]
+
+    def step():
+        for qi, ql in qs:
+            idx.search(enc.encode_ids(qi, ql, None, 0), 10)
+
+    ms = timed(step, steps=3, warmup=1)
+    per_q = ms / nq
+    bytes_q = 6 * (4 * 384 * 384 + 2 * 384 * 1536) * 2 + n * 384 * 4        # encoder weights (bf16) + the corpus, once per query
+    leg = {"name": "C1 the reference's CPU-runnable case on the GPU path: 10k-chunk corpus, one query per call (embed_query + dense top-10)",
+           "value": round(nq / (ms * 1e-3), 1), "unit": "queries/sec", "ms_per_step": round(per_q, 4),
+           "config": {"workload": "10k x 384 corpus (embedded here), 64 single-query calls per timed pass, ~16-token queries",
+                      "index_build_s": round(index_s, 3)},
+           "roofline": {"kernel": "encoder forward at batch 1 + scan_topk over 10k rows (launch-latency-bound: ~45 launches per query)", "bound": "hbm",
+                        "achieved": round(bytes_q / (per_q * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(bytes_q / (per_q * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                        "basis": "21.3 MB of encoder weights + 15.4 MB of corpus per query; not a bandwidth-bound regime"}}
+    if not args.no_cpu_baseline:
+        from transformers import BertConfig, BertModel
+        cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12, intermediate_size=1536,
+                         max_position_embeddings=512, layer_norm_eps=1e-12)
+        torch.manual_seed(0)
+        model = BertModel(cfg, add_pooling_layer=False).eval()
+        xc = emb.cpu()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for i in range(nq):
+                h = model(input_ids=torch.from_numpy(qids[i:i + 1, :qlens[i]].astype(np.int64))).last_hidden_state
+                v = torch.nn.functional.normalize(h.mean(1), dim=1)
+                torch.topk(v @ xc.T, 10, dim=1)
+        dt = time.perf_counter() - t0
+        leg["cpu_baseline"] = {"value": round(nq / dt, 2), "unit": "queries/sec", "cores": torch.get_num_threads(), "kind": "reference",
+                               "sample": f"{nq} single-query calls: transformers BertModel fp32 + torch-CPU matmul/topk over the 10k rows ({dt:.2f} s); tokenizer not timed"}
+    idx.close(); enc.close()
     return leg
 
 
@@ -302,7 +358,7 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c2,embed,rerank")
+    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c1,c2,embed,rerank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-identity-check", action="store_true",
                     help="skip the post-run comparison with the exact fp32 scan (keeps rocprofv3 per-kernel statistics to the timed launches)")
@@ -356,7 +412,7 @@ def main():
     if world > 1:
         dist.broadcast(q, 0)
         dist.broadcast(planted, 0)
-    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c2,embed,rerank".split(",") if args.legs == "all" else args.legs.split(","))
+    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c1,c2,embed,rerank".split(",") if args.legs == "all" else args.legs.split(","))
     sample_host = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample_host = shard[:min(n_local, 2_000_000)].cpu().numpy()
@@ -481,6 +537,8 @@ def main():
                 leg["cpu_baseline"] = cpu
     index.close()
     torch.cuda.empty_cache()
+    if "c1" in legs:
+        secondary.append(leg_c1(args))
     if "embed" in legs:
         secondary.append(leg_embed(args))
     if "rerank" in legs and x1m is not None:
