@@ -574,6 +574,70 @@ __global__ __launch_bounds__(512) void k_gemm_ln(const bf16* __restrict__ A, con
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_gemm_small -- the same GEMM for a HANDFUL of tokens (one query through embed_query, a few short passages): with M <= 256
+// the tiled kernels above run one or two workgroups for 12-48 pipeline stages each (11-17 us per launch, 0.47 ms per forward
+// of a 16-token query), while the whole weight matrix is only 0.3-1.2 MB.  Here the FEATURES are spread over the chip: grid =
+// N / 32 workgroups of 4 waves; wave w owns the K quarter [w K/4, (w+1) K/4) of the workgroup's 32 features -- its weight rows
+// sit in registers as MFMA A fragments (K/64 of them), token fragments come straight from global memory (no LDS staging), the
+// four partial sums meet in LDS and all 256 threads run the epilogue (bias | + GELU | + residual).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SMALL_M = 256;                           // tokens (upper bound batch * max_len) up to which this path is taken
+template <int EPI, int K>
+__global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
+                                                    const bf16* __restrict__ resid, bf16* __restrict__ out, const int* __restrict__ cu,
+                                                    int batch, int N) {
+    constexpr int KW = K / 4, NF = KW / 16;
+    __shared__ float red[4][32][36];                   // [K quarter][token][feature (+4 pad)]
+    const int M = cu[batch];
+    const int n0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r31 = lane & 31, hh = lane >> 5;
+    bf16x8 wf[NF];
+    {
+        const bf16* wr = W + (int64_t)(n0 + r31) * K + w * KW + hh * 8;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wf[f] = *(const bf16x8*)(wr + f * 16);
+    }
+    const int et = threadIdx.x >> 3, ef = (threadIdx.x & 7) * 4;       // epilogue: token et, features ef .. ef + 3
+    const f32x4 bv = *(const f32x4*)(bias + n0 + ef);
+    for (int t0 = 0; t0 < M; t0 += 32) {
+        const int tok = min(t0 + r31, M - 1);
+        const bf16* xr = A + (int64_t)tok * K + w * KW + hh * 8;
+        bf16x8 xf[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) xf[f] = *(const bf16x8*)(xr + f * 16);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f], xf[f], acc, 0, 0, 0);
+        // acc[4 q + e] = feature 8 q + 4 hh + e of token r31, summed over this wave's K quarter
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(f32x4*)&red[w][r31][q * 8 + hh * 4] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        __syncthreads();
+        const int m = t0 + et;
+        if (m < M) {
+            f32x4 v = bv;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) v += *(const f32x4*)&red[ww][et][ef];
+            if (EPI == EPI_GELU) v = gelu_poly4(v);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+            const int64_t off = (int64_t)m * N + n0 + ef;
+            if (EPI == EPI_RESID) {
+                const bf16x4 rv = *(const bf16x4*)(resid + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(bf2f(o[e]) + bf2f(rv[e]));
+            }
+            *(bf16x4*)(out + off) = o;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Fused FFN block: out = LayerNorm( GELU(h1 . W1^T + b1) . W2^T + b2 + h1 ) for a tile of 128 tokens.
 //
 // Unfused, the 1536-wide intermediate makes two HBM round trips per layer (3.2 GB written by FFN1, read again by FFN2),
@@ -1810,6 +1874,12 @@ static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, con
 template <int EPI>
 static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
                         int batch, int64_t m_cap, int N, int K, hipStream_t s) {
+    static const bool small_ok = !(getenv("RMU_GEMM_SMALL") && atoi(getenv("RMU_GEMM_SMALL")) == 0);
+    if (small_ok && m_cap <= SMALL_M && (K == H || K == FF)) {
+        if (K == H) hipLaunchKernelGGL((k_gemm_small<EPI, H>), dim3((unsigned)(N / 32)), dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N);
+        else hipLaunchKernelGGL((k_gemm_small<EPI, FF>), dim3((unsigned)(N / 32)), dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N);
+        return;
+    }
     static const int cfg = getenv("RMU_GEMM_CFG") ? atoi(getenv("RMU_GEMM_CFG")) : 0;
     switch (cfg) {
         case 1: return launch_gemm_cfg<EPI, 2, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
@@ -1926,7 +1996,7 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     const dim3 at_grid(NH, (unsigned)batch);   // one workgroup per (head, sequence)
     for (const BertLayer& L : m->layers) {
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
-        if (g3_mask & 1) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
+        if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         static const bool attn2 = getenv("RMU_ATTN2") && atoi(getenv("RMU_ATTN2")) != 0;   // opt-in: measured 7% slower than k_attention at L ~ 128
         if (attn2) {
@@ -1953,7 +2023,12 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
             hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
             continue;
         }
-        static const bool fused_ffn = !(getenv("RMU_FUSED_FFN") && atoi(getenv("RMU_FUSED_FFN")) == 0);
+        // The fused kernel gives each 128-token tile to ONE workgroup, which then streams all 2.36 MB of FFN weights through one
+        // CU (~100 us per layer whatever the batch): below ~128 tiles most CUs would idle and the GEMM pair, whose feature tiles
+        // spread over the chip, is faster (measured: 8k tokens 0.82 vs 0.95 ms per forward, one 16-token query 0.44 vs 0.63 ms;
+        // 32k tokens 1.70 vs 1.45).  RMU_FUSED_FFN=0 / 1 forces either path.
+        static const int fused_env = getenv("RMU_FUSED_FFN") ? atoi(getenv("RMU_FUSED_FFN")) : -1;
+        const bool fused_ffn = fused_env < 0 ? cap > 16384 : fused_env != 0;
         if (fused_ffn) {          // FFN1 + GELU + FFN2 + residual + LayerNorm in one kernel: the 1536-wide intermediate stays on chip
             launch_ffn_fused(m->h1, L, eps, m->h, m->cu, batch, cap, s);
             continue;

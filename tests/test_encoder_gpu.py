@@ -48,8 +48,12 @@ def test_padding_and_batch_composition_do_not_matter(bi):
     wide = np.concatenate([ids, np.full((12, 37), 7, np.int32)], axis=1)       # garbage in the padding
     b = enc.encode_ids(wide, lens, None, mode=0).cpu().numpy()
     assert np.array_equal(a, b)
+    halves = np.concatenate([enc.encode_ids(ids[i:i + 6], lens[i:i + 6], None, mode=0).cpu().numpy() for i in (0, 6)])
+    assert np.array_equal(halves, a)                                            # a sequence's result ignores its batch (same kernels)
+    # one sequence alone takes the small-M kernels (k_gemm_small: K split over four waves, another fp32 summation order):
+    # the same embedding up to bf16 rounding noise, not bit for bit
     one = np.stack([enc.encode_ids(ids[i:i + 1, :lens[i]], lens[i:i + 1], None, mode=0).cpu().numpy()[0] for i in range(12)])
-    assert np.abs(one - a).max() < 1e-6                                         # a sequence's result ignores its batch
+    assert np.abs(one - a).max() < 2e-3 and (one * a).sum(1).min() > 0.9999
 
 
 def test_cross_encoder_logits_vs_oracle(cross):
