@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for g in "$@"; do
-  RMU_GEMM3=$g TAG=g2_$g timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p$g -o x -- python $R/tools/enc_smoke.py ${ENC_N:-8192} 5 > /tmp/log$g 2>&1
+  RMU_GEMM3=$g TAG=g2_$g timeout 200 env ${EXTRA_ENV:-X=0} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p$g -o x -- python $R/tools/enc_smoke.py ${ENC_N:-8192} 5 > /tmp/log$g 2>&1
   grep RATE /tmp/log$g
   python - <<PY
 import csv,glob
