@@ -10,7 +10,10 @@
  *   - never throws; the caller owns every in/out buffer; the library owns what *_create made.
  *   - device pointers are plain HIP device addresses (e.g. torch.Tensor.data_ptr()).
  *   - hip_stream: 0 = an internal per-thread stream, results complete on return;
- *                 non-zero = a hipStream_t the work is ordered on (caller synchronises).
+ *                 non-zero = a hipStream_t the work is ordered on (caller synchronises).  Scratch space belongs to the
+ *                 calling THREAD: a call that returns with work in flight marks its end with an event, and the thread's
+ *                 next call on any other stream (or stream 0) is ordered behind it -- consecutive calls from one thread
+ *                 never overlap on the device, whichever streams they name; use one thread per concurrent stream.
  *   - thread-safe: searches on one index run concurrently (shared lock); add/remove are exclusive.
  *   - row ids are int64 row numbers in insertion order; pk/metadata mapping stays in the host language.
  */
@@ -169,9 +172,17 @@ typedef struct rmu_bert_cfg {
  * ragmeup_amd/bert.py (WEIGHT_ORDER).  The library converts them to bf16 MFMA operand layout once. */
 int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const void* const* weight_ptrs, int n_weights);
 int rmu_bert_free(rmu_bert_t* m);
-/* ids/type_ids: device int32 [batch, max_len] (row padded), lens: device int32 [batch].
- * mode 0: masked mean-pool + L2-normalise -> out_dev fp32 [batch, out_stride] (first `hidden` cols).
- * mode 1: pooler tanh + Linear(hidden,1) logit -> out_dev fp32 [batch]. */
+/* What rmu_bert_encode writes (`mode`): the head behind the transformer as the checkpoint declares it --
+ * sentence-transformers `1_Pooling/config.json` (pooling_mode_mean_tokens | pooling_mode_cls_token) and `modules.json`
+ * (Normalize present or not) for the bi-encoder, BertForSequenceClassification(num_labels = 1) for the cross-encoder. */
+#define RMU_BERT_POOL_MEAN 0   /* masked mean over the tokens (+ L2 normalise) -> out_dev fp32 [batch, out_stride] (first `hidden` cols) */
+#define RMU_BERT_CE_LOGIT 1    /* pooler tanh + Linear(hidden, 1) logit        -> out_dev fp32 [batch] */
+#define RMU_BERT_POOL_CLS 2    /* first token's state (+ L2 normalise)         -> out_dev fp32 [batch, out_stride] */
+#define RMU_BERT_TOKENS 3      /* final hidden state of every real token (sentence-transformers output_value="token_embeddings"):
+                                * packed rows, sequence b at rows [sum(len[<b]), +len[b]), len = min(lens, max_len)
+                                *                                              -> out_dev fp32 [sum len, out_stride] */
+#define RMU_BERT_NO_NORMALIZE 0x100 /* OR-ed into POOL_MEAN / POOL_CLS: the checkpoint has no Normalize module */
+/* ids/type_ids: device int32 [batch, max_len] (row padded), lens: device int32 [batch]. */
 int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens,
                     int batch, int max_len, int mode, float* out_dev, int64_t out_stride,
                     uint64_t hip_stream);

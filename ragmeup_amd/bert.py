@@ -1,8 +1,9 @@
 """BertEncoder -- Python handle on the hand-written BERT-6x384 forward in librmu.so (rmu_bert_*).
 
 Serves the two transformer forwards on the reference's hot path:
-  * sentence-transformers bi-encoder: BertModel -> masked mean pool -> L2 normalise   (mode 0)
-  * CrossEncoder: BertForSequenceClassification(num_labels=1) logit                    (mode 1)
+  * sentence-transformers bi-encoder: BertModel -> Pooling (masked mean | CLS token) -> [Normalize]   (MODE_MEAN / MODE_CLS)
+  * CrossEncoder: BertForSequenceClassification(num_labels=1) logit                                     (MODE_CE)
+  * the final hidden state of every token (ST output_value="token_embeddings"; what the parity tests compare)  (MODE_TOKENS)
 PyTorch is used only to hold the weight / id tensors on the device; every FLOP runs in our kernels.
 """
 from __future__ import annotations
@@ -14,6 +15,10 @@ from typing import Mapping
 import numpy as np
 
 from . import _native as N
+
+
+MODE_MEAN, MODE_CE, MODE_CLS, MODE_TOKENS = 0, 1, 2, 3      # include/rmu.h RMU_BERT_*
+NO_NORMALIZE = 0x100
 
 
 class BertCfg(ctypes.Structure):
@@ -94,19 +99,18 @@ class BertEncoder:
                    ffn=c.intermediate_size, ln_eps=c.layer_norm_eps, device=device)
 
     @classmethod
-    def from_pretrained_dir(cls, path: str, device: int = 0) -> "BertEncoder":
-        """HF checkpoint directory (config.json + model.safetensors | pytorch_model.bin)."""
-        import json
-        cfg = json.load(open(os.path.join(path, "config.json")))
-        st = os.path.join(path, "model.safetensors")
-        if os.path.exists(st):
-            from safetensors.numpy import load_file
-            state = load_file(st)
-        else:
-            import torch
-            state = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
-        return cls(state, layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"],
-                   ffn=cfg["intermediate_size"], ln_eps=cfg.get("layer_norm_eps", 1e-12), device=device)
+    def from_pretrained_dir(cls, path: str, device: int = 0, head: bool | None = None) -> "BertEncoder":
+        """HF checkpoint directory (config.json + model.safetensors | pytorch_model.bin); the architecture is validated
+        by ragmeup_amd.checkpoint (anything this build does not execute raises)."""
+        from . import checkpoint as C
+        spec = C._common(path)
+        return cls.from_spec(spec, device=device, head=head)
+
+    @classmethod
+    def from_spec(cls, spec, device: int = 0, head: bool | None = None) -> "BertEncoder":
+        from . import checkpoint as C
+        a = spec.arch
+        return cls(C.load_state(spec), layers=a.layers, heads=a.heads, ffn=a.ffn, ln_eps=a.ln_eps, has_head=head, device=device)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -121,16 +125,25 @@ class BertEncoder:
 
     # ---- forward ------------------------------------------------------------------------------------------
     def encode_ids(self, ids, lens, type_ids=None, mode: int = 0, out=None):
-        """ids [B, L] int (numpy or torch, padded), lens [B].  mode 0 -> [B, 384] unit-norm fp32 (torch CUDA);
-        mode 1 -> [B] fp32 logits.  `out` may be a pre-allocated CUDA tensor (e.g. a slice of a corpus matrix)."""
+        """ids [B, L] int (numpy or torch, padded), lens [B].  mode = MODE_MEAN / MODE_CLS (| NO_NORMALIZE) -> [B, 384] fp32
+        (torch CUDA); MODE_CE -> [B] fp32 logits; MODE_TOKENS -> [sum(min(lens, L)), 384] fp32, sequences packed in batch order.
+        `out` may be a pre-allocated CUDA tensor (e.g. a slice of a corpus matrix)."""
         torch = self._torch
         ids_t = torch.as_tensor(ids).to(self.device, torch.int32).contiguous()
         lens_t = torch.as_tensor(lens).to(self.device, torch.int32).contiguous()
         tt_t = None if type_ids is None else torch.as_tensor(type_ids).to(self.device, torch.int32).contiguous()
         B, L = ids_t.shape
+        kind = mode & 0xff
         if out is None:
-            out = torch.empty((B, self.HIDDEN) if mode == 0 else (B,), dtype=torch.float32, device=self.device)
-        stride = out.stride(0) if mode == 0 else 1
+            if kind == MODE_CE:
+                shape = (B,)
+            elif kind == MODE_TOKENS:
+                n_tok = int(np.minimum(np.maximum(np.asarray(lens.cpu() if torch.is_tensor(lens) else lens, dtype=np.int64), 0), L).sum())
+                shape = (n_tok, self.HIDDEN)
+            else:
+                shape = (B, self.HIDDEN)
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        stride = 1 if kind == MODE_CE else out.stride(0)
         torch.cuda.current_stream(self.device).synchronize()
         N.check(self._lib.rmu_bert_encode(self._h, ids_t.data_ptr(), tt_t.data_ptr() if tt_t is not None else None,
                                           lens_t.data_ptr(), int(B), int(L), int(mode), out.data_ptr(), int(stride), 0),

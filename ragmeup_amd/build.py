@@ -36,7 +36,9 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, debug_kernels: bool = False) -> str:
+    """debug_kernels: also compile the cycle-counter / ablation instantiations (-DRMU_DEBUG_KERNELS: RMU_FFN_DBG, RMU_G3_DBG,
+    RMU_GEMM_DBG); the product library carries none of them.  Switching the flag needs force=True."""
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = _sources()
     hdrs = _headers()
@@ -46,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, *(["-DRMU_DEBUG_KERNELS"] if debug_kernels else []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -65,4 +67,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv or "--debug-kernels" in sys.argv, verbose=True, debug_kernels="--debug-kernels" in sys.argv))

@@ -427,153 +427,6 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// GEMM + bias + residual + LayerNorm for N = 384 (out-proj, FFN2): out = LN(A . W^T + bias + resid) * g + b.
-// Tile = 128 tokens x ALL 384 features (8 waves: 4 token groups x 2 feature halves, each 32 x 192), so a
-// workgroup owns whole rows: the pre-LN sum is parked in LDS as bf16 (the same rounding the unfused path applied
-// when it wrote y to HBM) and normalised from there -- no y round trip through HBM, no separate LN launch.
-// ------------------------------------------------------------------------------------------------------------
-template <int BK, int ST>
-__global__ __launch_bounds__(512) void k_gemm_ln(const bf16* __restrict__ A, const bf16* __restrict__ W,
-                                                 const float* __restrict__ bias, const bf16* __restrict__ resid,
-                                                 const float* __restrict__ g, const float* __restrict__ bta, float eps,
-                                                 bf16* __restrict__ out, const int* __restrict__ cu, int batch, int K) {
-    constexpr int BM = 128, BNF = H, NWV = 8, NTH = 512;
-    constexpr int UPR = BK / 8;
-    constexpr int NITA = BM * UPR / NTH, NITW = BNF * UPR / NTH;
-    constexpr int SLABA = BM * BK * 2, SLABW = BNF * BK * 2;
-    constexpr int KS = BK / 32;
-    constexpr int TSTR = H * 2 + 16;               // bytes per token row of the pre-LN tile in LDS
-    static_assert(NITA >= 1, "tile/thread mismatch");
-    const int M = cu[batch];
-    const int m0 = blockIdx.x * BM;
-    if (m0 >= M) return;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = w >> 1, wn = w & 1;             // wave -> tokens [32wm, +32) x features [192wn, +192)
-    char* As = gsm;
-    char* Ws = gsm + ST * SLABA;
-    auto swz = [](int row) { return UPR == 8 ? (row & 7) : ((row >> 2) & 3); };
-    int arow[NITA], acol[NITA], wrow[NITW], wcol[NITW];
-#pragma unroll
-    for (int it = 0; it < NITA; ++it) {
-        const int f = (it * NWV + w) * 64 + lane;
-        const int row = f / UPR, p = f % UPR;
-        acol[it] = (p ^ swz(row)) * 8;
-        arow[it] = min(m0 + row, M - 1);
-    }
-#pragma unroll
-    for (int it = 0; it < NITW; ++it) {
-        const int f = (it * NWV + w) * 64 + lane;
-        const int row = f / UPR, p = f % UPR;
-        wcol[it] = (p ^ swz(row)) * 8;
-        wrow[it] = row;
-    }
-    const int nk = K / BK;
-    auto stage = [&](int kt) {
-        const int buf = kt % ST;
-        const int k0 = (kt < nk ? kt : nk - 1) * BK;
-#pragma unroll
-        for (int it = 0; it < NITA; ++it)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)arow[it] * K + k0 + acol[it]),
-                                             (__attribute__((address_space(3))) void*)(As + buf * SLABA + (it * NWV + w) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int it = 0; it < NITW; ++it)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (int64_t)wrow[it] * K + k0 + wcol[it]),
-                                             (__attribute__((address_space(3))) void*)(Ws + buf * SLABW + (it * NWV + w) * 1024), 16, 0, 0);
-    };
-    f32x4 acc[12][2];                              // [feature tile][token tile]
-#pragma unroll
-    for (int i = 0; i < 12; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int p = 0; p < ST - 1; ++p) stage(p);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NITA + NITW) * (ST - 2)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        stage(kt + ST - 1);
-        const char* as = As + (kt % ST) * SLABA;
-        const char* ws = Ws + (kt % ST) * SLABW;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 af[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wm * 32 + j * 16 + fr;
-                af[j] = *(const bf16x8*)(as + (row * UPR + ((ks * 4 + kg) ^ swz(row))) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const int row = wn * 192 + i * 16 + fr;
-                const bf16x8 wf = *(const bf16x8*)(ws + (row * UPR + ((ks * 4 + kg) ^ swz(row))) * 16);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                               // ring is dead: reuse LDS for the [128][384] pre-LN tile
-    char* tile = gsm;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tr = wm * 32 + j * 16 + fr;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int n = wn * 192 + i * 16 + kg * 4;
-            const f32x4 bv = *(const f32x4*)(bias + n);
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][j][e] + bv[e]);
-            *(bf16x4*)(tile + tr * TSTR + n * 2) = o;
-        }
-    }
-    __syncthreads();
-    // each wave normalises 16 token rows; lane owns columns {2l, 2l+1} + 128*jj (coalesced 4-B accesses)
-    float gg[6], bb[6];
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-        gg[2 * jj] = g[128 * jj + 2 * lane]; gg[2 * jj + 1] = g[128 * jj + 2 * lane + 1];
-        bb[2 * jj] = bta[128 * jj + 2 * lane]; bb[2 * jj + 1] = bta[128 * jj + 2 * lane + 1];
-    }
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    for (int r = 0; r < 16; ++r) {
-        const int tr = w * 16 + r;
-        const int m = m0 + tr;
-        if (m >= M) break;                         // uniform per wave
-        float v[6];
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            const bf16x2 a2 = *(const bf16x2*)(tile + tr * TSTR + (128 * jj + 2 * lane) * 2);
-            const bf16x2 r2 = *(const bf16x2*)(resid + (int64_t)m * H + 128 * jj + 2 * lane);
-            // y = bf16(gemm + bias + resid): same rounding point as the unfused y tensor
-            v[2 * jj] = bf2f((bf16)(bf2f(a2[0]) + bf2f(r2[0])));
-            v[2 * jj + 1] = bf2f((bf16)(bf2f(a2[1]) + bf2f(r2[1])));
-        }
-        float sm = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sm += v[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-        const float mu = sm * (1.0f / H);
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { const float d = v[i] - mu; q = fmaf(d, d, q); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-        const float rs = rsqrtf(q * (1.0f / H) + eps);
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) {
-            bf16x2 o2;
-            o2[0] = (bf16)((v[2 * jj] - mu) * rs * gg[2 * jj] + bb[2 * jj]);
-            o2[1] = (bf16)((v[2 * jj + 1] - mu) * rs * gg[2 * jj + 1] + bb[2 * jj + 1]);
-            *(bf16x2*)(out + (int64_t)m * H + 128 * jj + 2 * lane) = o2;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // k_gemm_small -- the same GEMM for a HANDFUL of tokens (one query through embed_query, a few short passages): with M <= 256
 // the tiled kernels above run one or two workgroups for 12-48 pipeline stages each (11-17 us per launch, 0.47 ms per forward
 // of a 16-token query), while the whole weight matrix is only 0.3-1.2 MB.  Here the FEATURES are spread over the chip: grid =
@@ -1439,188 +1292,17 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// attention, second form: ONE WAVE per (sequence, head), v_mfma_f32_32x32x16_bf16, no cross-wave traffic at all.
-//
-// The first kernel (above) is issue-bound: ~1000 instructions per wave for 32 small MFMAs (per-element masking, 4-lane
-// shuffles for every row maximum / sum, per-element divides, 2-byte stores).  Here the operands are swapped twice:
-//   * S^T = K . Q^T  (A = K rows from LDS, B = Q fragments straight from global memory): lane (query = lane & 31, half h) holds
-//     the scores of ITS query against 16 keys per 32-key tile -- a row maximum / sum is a chain over the lane's own registers
-//     plus ONE exchange with lane ^ 32;
-//   * O^T = V^T . P^T  (A = V^T from LDS, B = P^T): the accumulator layout of S^T (registers 8s .. 8s+7 <-> keys
-//     {4h+e, 8+4h+e} of the 16-key block s) IS a k-permuted B fragment, so P never leaves the registers; V^T is written to
-//     LDS with the same key permutation when it is staged (that transpose is the only scattered LDS traffic);
-//   * exp2 with log2(e)/sqrt(d) folded into Wq, masking only in the last key tile, one reciprocal per query, 8-byte stores.
-// Workgroup = 4 waves = 4 consecutive heads of one sequence (256 contiguous bytes of every token row between them); the three
-// workgroups of a sequence run on one XCD.  KT = key tiles of 32 (sequence length <= 32 KT); NW = waves per workgroup.
-// ------------------------------------------------------------------------------------------------------------
-template <int KT, int NW>
-__global__ __launch_bounds__(64 * NW) void k_attention2(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch,
-                                                        bf16* __restrict__ ctx) {
-    constexpr int LP = KT * 32;                    // padded keys
-    constexpr int VSTR = LP * 2 + 16;              // bytes per V^T row (dim): +16 spreads the 32 dims over the banks
-    constexpr int KBYTES = LP * 64, WBYTES = KBYTES + 32 * VSTR;
-    constexpr bool CACHEK = KT <= 4;               // K fragments of the whole sequence stay in registers across query tiles
-    constexpr int HG = NH / NW;                    // head groups (workgroups) per sequence
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int seq, hg;
-    {
-        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-        seq = (idx / HG) * 8 + xcd;                // the HG workgroups of a sequence share an XCD (same token rows through one L2)
-        hg = idx % HG;
-    }
-    if (seq >= batch) return;
-    const int head = hg * NW + w;
-    const int t0 = cu[seq], L = cu[seq + 1] - t0;
-    if (L <= 0) return;
-    const int c31 = lane & 31, hh = lane >> 5;
-    char* ks = gsm + w * WBYTES;                   // [LP keys][4 units of 16 B], unit u of key r at u ^ ((r >> 2) & 3)
-    char* vt = ks + KBYTES;                        // [32 dims][VSTR]: V^T, keys in GEMM-slot order inside every 16-block
-    const int nkt = (L + 31) >> 5;                 // key tiles in use
-    const int64_t rs = 3 * H;                      // qkv row stride (elements)
-    const bf16* base = qkv + (int64_t)t0 * rs + head * DH;
-
-    // ---- stage K (row-major, swizzled) and V^T (transposed, key-permuted); rows >= L are zero -------------------------
-    for (int p0 = 0; p0 < nkt * 32 * 4; p0 += 128) {       // 2 x 64 pieces of 16 B per iteration: both loads in flight
-        uint4 kv[2], vv[2];
-#pragma unroll
-        for (int u2 = 0; u2 < 2; ++u2) {
-            const int p = p0 + u2 * 64 + lane, r = p >> 2, u = p & 3;
-            kv[u2] = uint4{0u, 0u, 0u, 0u};
-            vv[u2] = uint4{0u, 0u, 0u, 0u};
-            if (r < L) {
-                kv[u2] = *(const uint4*)(base + (int64_t)r * rs + H + u * 8);
-                vv[u2] = *(const uint4*)(base + (int64_t)r * rs + 2 * H + u * 8);
-            }
-        }
-#pragma unroll
-        for (int u2 = 0; u2 < 2; ++u2) {
-            const int p = p0 + u2 * 64 + lane, r = p >> 2, u = p & 3;
-            *(uint4*)(ks + r * 64 + ((u ^ ((r >> 2) & 3)) * 16)) = kv[u2];
-            // key r -> slot inside its 16-block: keys 0-3 -> 0-3, 4-7 -> 8-11, 8-11 -> 4-7, 12-15 -> 12-15
-            const int r16 = r & 15, slot = (r & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
-            const unsigned short* ve = (const unsigned short*)&vv[u2];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) *(unsigned short*)(vt + (u * 8 + e) * VSTR + slot * 2) = ve[e];
-        }
-    }
-    // (one wave owns this LDS region: program order + the compiler's lgkmcnt waits are all the synchronisation needed)
-
-    // K fragments: key tile kt, k-step s (dims 16 s .. 16 s + 15): lane (key c31, half hh) reads unit 2 s + hh of key 32 kt + c31
-    auto kfrag = [&](int kt, int s2) -> bf16x8 {
-        const int r = kt * 32 + c31;
-        return *(const bf16x8*)(ks + r * 64 + (((2 * s2 + hh) ^ ((r >> 2) & 3)) * 16));
-    };
-    bf16x8 kc[CACHEK ? KT : 1][2];
-    if (CACHEK) {
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-            if (kt < nkt) { kc[kt][0] = kfrag(kt, 0); kc[kt][1] = kfrag(kt, 1); }
-    }
-    // key index of accumulator register r of this lane inside a 32-key tile
-    const int nq_tiles = (L + 31) >> 5;
-    bf16x8 qf[2];                                  // Q fragments (B operand): query c31 of the tile, dims 16 s + 8 hh ..
-    {
-        const int q = min(c31, L - 1);
-        qf[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
-        qf[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
-    }
-    for (int qt = 0; qt < nq_tiles; ++qt) {
-        bf16x8 qn[2] = {qf[0], qf[1]};
-        if (qt + 1 < nq_tiles) {                   // next tile's Q in flight while this tile computes
-            const int q = min((qt + 1) * 32 + c31, L - 1);
-            qn[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
-            qn[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
-        }
-        // ---- S^T tiles: st[kt][r] = score of query (qt, c31) against key 32 kt + (r & 3) + 8 (r >> 2) + 4 hh, log2 domain ---
-        f32x16 st[KT];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt < nkt) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CACHEK ? kc[kt][0] : kfrag(kt, 0), qf[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CACHEK ? kc[kt][1] : kfrag(kt, 1), qf[1], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(acc[r], acc[r + 1]));
-                st[kt] = acc;
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));        // the other half of this query's keys
-        // Keys >= L (padding of the last tile) need no per-element mask: their K rows are zero, so each scores exactly 0, their
-        // V rows are zero too (no contribution to O), and their share of the row sum is n_pad * exp2(0 - mx), subtracted below.
-        // They can only distort the MAXIMUM -- when every real score of a query is <= 0 the shift would be the padding's 0
-        // instead of the true maximum (harmless unless the real scores are far below 0): that case takes the masked re-scan.
-        const int n_pad = nkt * 32 - L;
-        if (n_pad > 0 && __any(mx == 0.f)) {
-            float mm = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt < nkt) {
-                    const int lim = L - kt * 32 - 4 * hh;      // register r is a real key iff (r & 3) + 8 (r >> 2) < lim
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mm = fmaxf(mm, ((r & 3) + 8 * (r >> 2) < lim) ? st[kt][r] : -INFINITY);
-                }
-            }
-            mm = fmaxf(mm, __shfl_xor(mm, 32));
-            mx = (mx == 0.f) ? mm : mx;            // (a query whose true maximum is exactly 0 gets the same value back)
-        }
-        float sum = 0.f;
-        f32x16 ot;                                 // O^T tile: dims (r & 3) + 8 (r >> 2) + 4 hh of query c31
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt < nkt) {
-                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                u32x4 pu[2];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float p0 = __builtin_amdgcn_exp2f(st[kt][r] - mx);       // exp2(-inf) = 0 for masked keys
-                    const float p1 = __builtin_amdgcn_exp2f(st[kt][r + 1] - mx);
-                    sum += p0 + p1;
-                    bf16x2 pb;
-                    pb[0] = (bf16)p0; pb[1] = (bf16)p1;
-                    pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
-                }
-                // registers 8 s .. 8 s + 7 of the tile = the B fragment of k-step s (keys 32 kt + 16 s + {4hh+e, 8+4hh+e})
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 vf = *(const bf16x8*)(vt + c31 * VSTR + (kt * 32 + s2 * 16 + hh * 8) * 2);
-                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pu[s2]), ot, 0, 0, 0);
-                }
-            }
-        }
-        sum += __shfl_xor(sum, 32);
-        sum -= (float)n_pad * __builtin_amdgcn_exp2f(-mx);        // the padded keys' share (each is exp2(0 - mx))
-        const float inv = __builtin_amdgcn_rcpf(sum);
-        const int q = qt * 32 + c31;
-        if (q < L) {
-            bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 4;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                bf16x4 o4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (bf16)(ot[4 * g4 + e] * inv);
-                *(bf16x4*)(dst + 8 * g4) = o4;
-            }
-        }
-        qf[0] = qn[0];
-        qf[1] = qn[1];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // pooling heads
 // ------------------------------------------------------------------------------------------------------------
-// sentence-transformers Pooling(mean) + Normalize: one wave per sequence
-__global__ __launch_bounds__(64) void k_meanpool_l2(const bf16* __restrict__ h, const int* __restrict__ cu,
-                                                    float* __restrict__ out, int64_t out_stride) {
+// sentence-transformers Pooling + Normalize: one wave per sequence.  pool_cls = 0: masked mean over the sequence's tokens
+// (`pooling_mode_mean_tokens`: sum(mask h) / max(sum(mask), 1e-9)); 1: the first token's state (`pooling_mode_cls_token`,
+// the bge / GIST family the reference's .env.template:3 names).  normalize: the checkpoint's Normalize module
+// (x / max(|x|, 1e-12)); without it the pooled vector is written as it is.
+__global__ __launch_bounds__(64) void k_pool(const bf16* __restrict__ h, const int* __restrict__ cu, float* __restrict__ out,
+                                             int64_t out_stride, int pool_cls, int normalize) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int t0 = cu[b], L = cu[b + 1] - t0;
+    const int t0 = cu[b], Lr = cu[b + 1] - t0;
+    const int L = pool_cls ? min(Lr, 1) : Lr;
     const bool act = lane < 48;                        // 16-byte row pieces, four rows in flight
     const int c0 = lane * 8;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1642,13 +1324,13 @@ __global__ __launch_bounds__(64) void k_meanpool_l2(const bf16* __restrict__ h, 
             for (int i = 0; i < 8; ++i) s[i] += bf2f(v[i]);
         }
     }
-    const float inv = 1.0f / fmaxf((float)L, 1e-9f);
+    const float inv = pool_cls ? 1.0f : 1.0f / fmaxf((float)L, 1e-9f);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] *= inv; q = fmaf(s[i], s[i], q); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rn = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+    const float rn = normalize ? 1.0f / fmaxf(sqrtf(q), 1e-12f) : 1.0f;
     if (act) {
         float* dst = out + (int64_t)b * out_stride + c0;
         if ((((uintptr_t)out | (uintptr_t)(out_stride * 4)) & 15) == 0) {   // any caller stride is legal: wide stores when aligned
@@ -1659,6 +1341,21 @@ __global__ __launch_bounds__(64) void k_meanpool_l2(const bf16* __restrict__ h, 
             for (int i = 0; i < 8; ++i) dst[i] = s[i] * rn;
         }
     }
+}
+
+// final hidden states of every real token as fp32 rows (sentence-transformers' output_value = "token_embeddings"; the
+// parity tests compare them with the fp64 oracle token by token): packed row cu[b] + pos -> out[(cu[b] + pos) * stride ..]
+__global__ __launch_bounds__(256) void k_tokens_out(const bf16* __restrict__ h, const int* __restrict__ cu, int batch,
+                                                    float* __restrict__ out, int64_t out_stride) {
+    const int64_t M = cu[batch];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per 8 features
+    const int64_t row = i / (H / 8);
+    const int c0 = (int)(i % (H / 8)) * 8;
+    if (row >= M) return;
+    const bf16x8 v = *(const bf16x8*)(h + row * H + c0);
+    float* dst = out + row * out_stride + c0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = bf2f(v[e]);
 }
 
 // BertForSequenceClassification(num_labels=1): logit = wc . tanh(Wp h_cls + bp) + bc ; one block per sequence
@@ -1861,14 +1558,18 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
 template <int EPI, int WM, int BK, int ST>
 static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
                             int batch, int64_t m_cap, int N, int K, hipStream_t s) {
-    static bool attr = false;
     constexpr int BM = 64 * WM;
-    const int ring = ST * (BM * BK * 2 + BN * BK * 2), stagebuf = 2 * WM * 64 * 144;
-    const int lds = ring > stagebuf ? ring : stagebuf;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm<EPI, WM, BK, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    constexpr int ring = ST * (BM * BK * 2 + BN * BK * 2), stagebuf = 2 * WM * 64 * 144;
+    constexpr int lds = ring > stagebuf ? ring : stagebuf;
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm<EPI, WM, BK, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)attr_rc;
     const int64_t mt = ((m_cap + BM - 1) / BM + 7) / 8 * 8;     // token tiles, padded to a multiple of 8 (XCD map)
     const dim3 grid((unsigned)(mt * (N / BN)));
-    static const int dbg = getenv("RMU_GEMM_DBG") ? atoi(getenv("RMU_GEMM_DBG")) : 0;
+#ifdef RMU_DEBUG_KERNELS
+    static const int dbg = getenv("RMU_GEMM_DBG") ? atoi(getenv("RMU_GEMM_DBG")) : 0;   // timing ablations: 1 no stores, 2 no main loop
+#else
+    constexpr int dbg = 0;
+#endif
     hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg);
 }
 template <int EPI>
@@ -1882,46 +1583,26 @@ static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const b
     }
     // few tiles (latency-bound: every workgroup walks K alone): 128 x 128 tiles in 64-k stages halve the stage count and double
     // the workgroups -- 4k tokens 0.70 -> 0.60 ms per forward, 16k tokens 1.12 -> 1.07; big batches keep 256 x 128 / 32-k stages
-    static const int cfg_env = getenv("RMU_GEMM_CFG") ? atoi(getenv("RMU_GEMM_CFG")) : -1;
-    const int cfg = cfg_env >= 0 ? cfg_env : (m_cap <= 32768 ? 1 : 0);
-    switch (cfg) {
-        case 1: return launch_gemm_cfg<EPI, 2, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
-        case 2: return launch_gemm_cfg<EPI, 4, 64, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
-        case 3: return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
-        case 4: return launch_gemm_cfg<EPI, 4, 32, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
-        case 5: return launch_gemm_cfg<EPI, 2, 32, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
-        case 6: return launch_gemm_cfg<EPI, 2, 64, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
-        case 7: return launch_gemm_cfg<EPI, 4, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
-        default: return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);   // best measured
-    }
+    // (best of the seven tile / stage / ring combinations measured in round 2)
+    if (m_cap <= 32768) return launch_gemm_cfg<EPI, 2, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+    return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
 }
 
-static void launch_gemm_ln(const bf16* A, const bf16* W, const float* bias, const bf16* resid, const float* g, const float* b,
-                           float eps, bf16* out, const int* cu, int batch, int64_t m_cap, int K, hipStream_t s) {
-    static bool attr = false;
-    constexpr int BK = 32, ST = 2;
-    const int ring = ST * (128 * BK * 2 + H * BK * 2), tile = 128 * (H * 2 + 16);
-    const int lds = ring > tile ? ring : tile;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_ln<BK, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
-    hipLaunchKernelGGL((k_gemm_ln<BK, ST>), dim3((unsigned)((m_cap + 127) / 128)), dim3(512), lds, s, A, W, bias, resid, g, b, eps, out,
-                       cu, batch, K);
-}
-
+// The cycle-counter / ablation instantiations (k_ffn_fused<true>, k_gemm3<*, true>: RMU_FFN_DBG, RMU_G3_DBG) exist only in a
+// build with -DRMU_DEBUG_KERNELS (python -m ragmeup_amd.build --debug-kernels): the product library carries one instantiation
+// of every kernel it can actually take.
 static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
-    static const bool want_dbg = getenv("RMU_FFN_DBG") != nullptr;
-    static const hipError_t attr_rc = hipFuncSetAttribute(want_dbg ? (const void*)k_ffn_fused<true> : (const void*)k_ffn_fused<false>,
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, ffn::LDS_BYTES);
-    (void)attr_rc;
-    static unsigned long long* dbg = nullptr;
-    if (want_dbg && !dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
     const dim3 grid((unsigned)((m_cap + ffn::TOK - 1) / ffn::TOK));
+#ifdef RMU_DEBUG_KERNELS
+    static const bool want_dbg = getenv("RMU_FFN_DBG") != nullptr;
     if (want_dbg) {
+        static const hipError_t attr_dbg = hipFuncSetAttribute((const void*)k_ffn_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn::LDS_BYTES);
+        (void)attr_dbg;
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
         static const unsigned long long fl = getenv("RMU_FFN_FLAGS") ? strtoull(getenv("RMU_FFN_FLAGS"), nullptr, 10) : 0ull;
         (void)hipMemcpyAsync(dbg + 7, &fl, 8, hipMemcpyHostToDevice, s);
-    }
-    if (want_dbg) hipLaunchKernelGGL(k_ffn_fused<true>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
-    else hipLaunchKernelGGL(k_ffn_fused<false>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
-    if (want_dbg) {
+        hipLaunchKernelGGL(k_ffn_fused<true>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
         unsigned long long h[5];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, dbg, 40, hipMemcpyDeviceToHost);
@@ -1929,50 +1610,48 @@ static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16
         fprintf(stderr, "[ffn dbg] waves=%llu  cycles/wave: total=%.0f  wait(slab+barrier)=%.0f (%.1f%%)  gemm1=%.0f (per slab %.0f)  gemm2+gelu=%.0f (per slab %.0f)\n",
                 h[2], (double)h[1] / (double)h[2], (double)h[0] / (double)h[2], 100.0 * (double)h[0] / (double)h[1], (double)h[3] / (double)h[2],
                 (double)h[3] / (double)h[2] / 72.0, (double)h[4] / (double)h[2], (double)h[4] / (double)h[2] / 48.0);
+        return;
     }
+#endif
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_ffn_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn::LDS_BYTES);
+    (void)attr_rc;
+    hipLaunchKernelGGL(k_ffn_fused<false>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
+                       (unsigned long long*)nullptr);
 }
 
 template <int EPI>
 static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu, int batch,
                          int N, int K, hipStream_t s) {
-    static const bool want_dbg = getenv("RMU_G3_DBG") != nullptr;
-    static const hipError_t attr_rc = hipFuncSetAttribute(want_dbg ? (const void*)k_gemm3<EPI, true> : (const void*)k_gemm3<EPI, false>,
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
-    (void)attr_rc;
     static const int n_wg = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus / 8 * 8; }();
-    if (!want_dbg) {
-        hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, 0);
+#ifdef RMU_DEBUG_KERNELS
+    static const bool want_dbg = getenv("RMU_G3_DBG") != nullptr;
+    if (want_dbg) {
+        static const hipError_t attr_dbg = hipFuncSetAttribute((const void*)k_gemm3<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
+        (void)attr_dbg;
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
+        static const int dflags = getenv("RMU_G3_FLAGS") ? atoi(getenv("RMU_G3_FLAGS")) : 0;   // 1: no DMA in the loop, 2: no fragment reads, 4: no epilogue (timing only)
+        hipLaunchKernelGGL((k_gemm3<EPI, true>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, dbg, dflags);
+        unsigned long long h[6];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, dbg, 48, hipMemcpyDeviceToHost);
+        (void)hipMemset(dbg, 0, 64);
+        const double nw = (double)h[0], stages = (double)h[5] / nw * (K / 32);
+        fprintf(stderr, "[gemm3<%d> N=%d K=%d dbg] waves=%llu tiles/wg=%.1f ticks/wave: prologue=%.0f loop=%.0f (per stage %.0f; of which vmcnt+barrier %.0f, epilogue %.0f)\n",
+                EPI, N, K, h[0], (double)h[5] / nw, h[1] / nw, h[2] / nw, h[2] / nw / stages, h[4] / nw / stages, h[3] / nw / stages);
         return;
     }
-    static unsigned long long* dbg = nullptr;
-    if (!dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
-    static const int dflags = getenv("RMU_G3_FLAGS") ? atoi(getenv("RMU_G3_FLAGS")) : 0;   // 1: no DMA in the loop, 2: no fragment reads, 4: no epilogue (timing only)
-    hipLaunchKernelGGL((k_gemm3<EPI, true>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, dbg, dflags);
-    unsigned long long h[6];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(h, dbg, 48, hipMemcpyDeviceToHost);
-    (void)hipMemset(dbg, 0, 64);
-    const double nw = (double)h[0], stages = (double)h[5] / nw * (K / 32);
-    fprintf(stderr, "[gemm3<%d> N=%d K=%d dbg] waves=%llu tiles/wg=%.1f ticks/wave: prologue=%.0f loop=%.0f (per stage %.0f; of which vmcnt+barrier %.0f, epilogue %.0f)\n",
-            EPI, N, K, h[0], (double)h[5] / nw, h[1] / nw, h[2] / nw, h[2] / nw / stages, h[4] / nw / stages, h[3] / nw / stages);
-}
-
-template <int KT, int NW>
-static void launch_attn2(int batch, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
-    constexpr int lds = NW * (KT * 32 * 64 + 32 * (KT * 32 * 2 + 16));
-    static const hipError_t attr_rc =
-        hipFuncSetAttribute((const void*)k_attention2<KT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#endif
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm3<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
     (void)attr_rc;
-    const int hgs = NH / NW;
-    const unsigned grid = (unsigned)(((batch + 7) / 8) * 8 * hgs);
-    hipLaunchKernelGGL((k_attention2<KT, NW>), dim3(grid), dim3(64 * NW), lds, s, qkv, cu, batch, ctx);
+    hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, 0);
 }
 
 template <int MAXT>
 static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
-    static bool attr = false;
-    const int lds = MAXT * 16 * 80 + DH * (MAXT * 16 * 2 + 8);
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_attention<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+    constexpr int lds = MAXT * 16 * 80 + DH * (MAXT * 16 * 2 + 8);
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_attention<MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)attr_rc;
     hipLaunchKernelGGL(k_attention<MAXT>, grid, dim3(256), lds, s, qkv, cu, ctx);
 }
 
@@ -1981,9 +1660,12 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     if (!m || !ids || !lens || !out_dev) return bfail(RMU_E_INVALID, "rmu_bert_encode: null argument");
     if (batch < 1 || batch > 65535 || max_len < 1 || max_len > m->cfg.max_pos)
         return bfail(RMU_E_INVALID, "rmu_bert_encode: 1 <= batch <= 65535, 1 <= max_len <= max_pos");
-    if (mode != 0 && mode != 1) return bfail(RMU_E_INVALID, "rmu_bert_encode: mode must be 0 or 1");
-    if (mode == 1 && !m->cfg.has_head) return bfail(RMU_E_INVALID, "rmu_bert_encode: model has no classification head");
-    if (mode == 0 && out_stride < H) return bfail(RMU_E_INVALID, "rmu_bert_encode: out_stride < hidden");
+    const int kind = mode & 0xff;
+    const bool normalize = !(mode & RMU_BERT_NO_NORMALIZE);
+    if ((mode & ~(0xff | RMU_BERT_NO_NORMALIZE)) || kind > RMU_BERT_TOKENS)
+        return bfail(RMU_E_INVALID, "rmu_bert_encode: mode must be RMU_BERT_POOL_MEAN / CE_LOGIT / POOL_CLS / TOKENS (| RMU_BERT_NO_NORMALIZE)");
+    if (kind == RMU_BERT_CE_LOGIT && !m->cfg.has_head) return bfail(RMU_E_INVALID, "rmu_bert_encode: model has no classification head");
+    if (kind != RMU_BERT_CE_LOGIT && out_stride < H) return bfail(RMU_E_INVALID, "rmu_bert_encode: out_stride < hidden");
     std::lock_guard<std::mutex> lk(m->mu);
     const int64_t cap = (int64_t)batch * max_len;
     int rc = ensure_ws(m, cap, batch);
@@ -2001,25 +1683,12 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
         if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
-        static const bool attn2 = getenv("RMU_ATTN2") && atoi(getenv("RMU_ATTN2")) != 0;   // opt-in: measured 7% slower than k_attention at L ~ 128
-        if (attn2) {
-            if (max_len <= 128) launch_attn2<4, 4>(batch, m->qkv, m->cu, m->ctx, s);
-            else if (max_len <= 256) launch_attn2<8, 4>(batch, m->qkv, m->cu, m->ctx, s);
-            else launch_attn2<16, 2>(batch, m->qkv, m->cu, m->ctx, s);
-        } else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
+        if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
-        // measured: the fused 128x384 kernel (one workgroup per CU, serial LN pass) is 12% slower than GEMM + LN launches
-        static const bool fuse_ln = getenv("RMU_FUSED_LN") != nullptr;
-        if (g3_mask & 2) {
-            launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
-            hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
-        } else if (fuse_ln) {
-            launch_gemm_ln(m->ctx, L.wo, L.bo, m->h, L.ln1g, L.ln1b, eps, m->h1, m->cu, batch, cap, H, s);
-        } else {
-            launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
-            hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
-        }
+        if (g3_mask & 2) launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
+        else launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
+        hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
         if (g3_mask & 4) {
             launch_gemm3<EPI_GELU>(m->h1, L.w1_t, L.b1, nullptr, m->mid, m->cu, batch, FF, H, s);
             launch_gemm3<EPI_RESID>(m->mid, L.w2_t, L.b2, m->h1, m->y, m->cu, batch, H, FF, s);
@@ -2037,15 +1706,15 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
             continue;
         }
         launch_gemm<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, cap, FF, H, s);
-        if (fuse_ln) {
-            launch_gemm_ln(m->mid, L.w2, L.b2, m->h1, L.ln2g, L.ln2b, eps, m->h, m->cu, batch, cap, FF, s);
-        } else {
-            launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
-            hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
-        }
+        launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
+        hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
     }
-    if (mode == 0)
-        hipLaunchKernelGGL(k_meanpool_l2, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)m->h, (const int*)m->cu, out_dev, out_stride);
+    if (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)
+        hipLaunchKernelGGL(k_pool, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)m->h, (const int*)m->cu, out_dev, out_stride,
+                           kind == RMU_BERT_POOL_CLS ? 1 : 0, normalize ? 1 : 0);
+    else if (kind == RMU_BERT_TOKENS)
+        hipLaunchKernelGGL(k_tokens_out, dim3((unsigned)((cap * (H / 8) + 255) / 256)), dim3(256), 0, s, (const bf16*)m->h, (const int*)m->cu, batch,
+                           out_dev, out_stride);
     else
         hipLaunchKernelGGL(k_cls_head, dim3((unsigned)batch), dim3(128), 0, s, (const bf16*)m->h, (const int*)m->cu, m->wp, m->bp, m->wc, m->bc, out_dev);
     B_TRY(hipGetLastError());

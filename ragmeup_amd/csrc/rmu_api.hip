@@ -95,19 +95,39 @@ struct Tls {
     float scan_ms = -1.f, search_ms = -1.f;
     int grid = 0, block = 0, lds = 0, passes = 0, screened = 0;
     int device = -1;
-    int ensure_stream() {
+    // A search / merge given a caller stream and device buffers returns with its kernels still in flight -- on workspaces
+    // (q, qsplit, partial, gthr, ckeys, flag, fb_*) that belong to this thread, not to that stream.  `pend_ev` marks the end
+    // of the last such call: the next user of the workspaces on ANY OTHER stream is ordered behind it (same stream: stream
+    // order already does that), so a second call can neither memset thresholds nor overwrite partials under running kernels.
+    hipEvent_t pend_ev = nullptr;
+    hipStream_t pend_stream = nullptr;
+    bool pending = false;
+    // `user`: the stream the caller's work will be enqueued on (nullptr = this thread's internal stream)
+    int ensure_stream(hipStream_t user = nullptr) {
         if (g_device >= 0 && device != g_device) { (void)hipSetDevice(g_device); device = g_device; }
         if (!stream) {
             if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return RMU_E_HIP;
             for (auto& e : ev)
                 if (hipEventCreate(&e) != hipSuccess) return RMU_E_HIP;
+            if (hipEventCreateWithFlags(&pend_ev, hipEventDisableTiming) != hipSuccess) return RMU_E_HIP;
         }
+        hipStream_t s = user ? user : stream;
+        if (pending && s != pend_stream && hipStreamWaitEvent(s, pend_ev, 0) != hipSuccess) return RMU_E_HIP;
         return RMU_OK;
+    }
+    // end of a call that used the workspaces on stream s: either it synchronised s (everything pending was ordered before
+    // its own work, so nothing is in flight any more) or it leaves work in flight there
+    void finished(hipStream_t s, bool drained) {
+        if (drained) { pending = false; return; }
+        if (hipEventRecord(pend_ev, s) == hipSuccess) { pend_stream = s; pending = true; }
+        else { (void)hipStreamSynchronize(s); pending = false; }
     }
     // A server that spawns a thread per request (Flask's threaded dev server, server/server.py:394) creates one of
     // these per request: everything it owns goes back when the thread exits.
     ~Tls() {
         if (g_runtime_down) return;
+        if (pending) (void)hipEventSynchronize(pend_ev);
+        if (pend_ev) (void)hipEventDestroy(pend_ev);
         if (stream) (void)hipStreamSynchronize(stream);
         for (Buf* b : {&q, &partial, &out_s, &out_r, &in_s, &in_r, &qn, &gthr, &mscratch, &qsplit, &ckeys, &flag, &nrm, &fbq, &fb_s,
                        &fb_r, &fb_i})
@@ -698,7 +718,8 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
     if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
         t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.ensure_events(2 * nl))
         return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
-    const int sflags = share | ((getenv("RMU_SCREEN_NOFILTER") != nullptr) ? 2 : 0);
+    static const int nofilter = getenv("RMU_SCREEN_NOFILTER") != nullptr ? 2 : 0;
+    const int sflags = share | nofilter;
     HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
     int rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
     if (rc) return fail(rc, "rmu_index_search: query conversion");
@@ -727,10 +748,11 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
 }
 
 static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
-    static const int screen_min_nq = getenv("RMU_SCREEN_MIN_NQ") ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
+    static const bool min_nq_set = getenv("RMU_SCREEN_MIN_NQ") != nullptr;
+    static const int screen_min_nq = min_nq_set ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
     // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays for the
     // ladder's launches and merges per batch, which only pays off on a large enough corpus
-    const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || getenv("RMU_SCREEN_MIN_NQ");
+    const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || min_nq_set;
     return idx->split && idx->screen_enabled && idx->dpad == 384 && idx->dim == 384 && idx->metric != RMU_METRIC_L2SQ &&
            nb >= screen_min_nq && screen_pays && k <= 24 && idx->n > 0 && idx->xnorm_max > 0.f &&
            idx->xnorm_max < 500.f;   // fp16(64*x) must not overflow
@@ -742,7 +764,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
     if (nq < 1) return fail(RMU_E_INVALID, "rmu_index_search: nq must be >= 1");
     if (k < 1 || k > RMU_MAX_K) return fail(RMU_E_INVALID, "rmu_index_search: k must be in [1, 112]");
     Tls& t = g_tls;
-    int rc = t.ensure_stream();
+    int rc = t.ensure_stream((hipStream_t)hip_stream);
     if (rc) return fail(rc, "rmu_index_search: stream");
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : t.stream;
     const bool q_dev = flags & RMU_F_Q_DEVICE, out_dev = flags & RMU_F_OUT_DEVICE;
@@ -892,6 +914,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // device outputs and a single block nothing here waits: the work is merely ordered on that stream.
         const bool drained = !hip_stream || q0 + nb < nq || !out_dev;
         if (drained) HIP_TRY(hipStreamSynchronize(s));
+        t.finished(s, drained);
         if (screened) {   // the count of re-run queries is unknown while a caller's stream still runs: reported as 0 then
             any_screened = true;
             if (drained) rerun_total += *t.hflag;
@@ -981,7 +1004,7 @@ extern "C" int rmu_topk_merge(const float* scores, const int64_t* rows, int part
     if (!scores || !rows || !out_scores || !out_rows) return fail(RMU_E_INVALID, "rmu_topk_merge: null pointer");
     if (parts < 1 || nq < 1 || k < 1 || k > 128) return fail(RMU_E_INVALID, "rmu_topk_merge: parts/nq >= 1, k in [1,128]");
     Tls& t = g_tls;
-    int rc = t.ensure_stream();
+    int rc = t.ensure_stream((hipStream_t)hip_stream);
     if (rc) return fail(rc, "rmu_topk_merge: stream");
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : t.stream;
     const bool in_dev = flags & RMU_F_Q_DEVICE, out_dev = flags & RMU_F_OUT_DEVICE;
@@ -1010,6 +1033,8 @@ extern "C" int rmu_topk_merge(const float* scores, const int64_t* rows, int part
         HIP_TRY(hipMemcpyAsync(out_scores, os, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(out_rows, orr, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     }
-    if (!hip_stream || !out_dev || !in_dev) HIP_TRY(hipStreamSynchronize(s));
+    const bool drained = !hip_stream || !out_dev || !in_dev;
+    if (drained) HIP_TRY(hipStreamSynchronize(s));
+    t.finished(s, drained);
     return RMU_OK;
 }

@@ -89,8 +89,20 @@ extern "C" int rmu_comm_unique_id(void* id_out) {
     return RMU_OK;
 }
 
+// Every entry point runs on the communicator's device, whichever device is current for the calling thread (a Flask or pool
+// worker thread starts on device 0: on ranks > 0 the pack / merge kernels and the buffers would land on the wrong GPU).
+struct CommDeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit CommDeviceScope(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~CommDeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
 extern "C" int rmu_comm_free(rmu_comm_t* c) {
     if (!c) return RMU_OK;
+    CommDeviceScope dev(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     for (void* p : {c->send, c->recv, (void*)c->in_s, (void*)c->in_r, (void*)c->out_s, (void*)c->out_r})
@@ -109,7 +121,8 @@ extern "C" int rmu_comm_init(rmu_comm_t** out, const void* id, int world, int ra
     if (!c) return cfail(RMU_E_OOM, "rmu_comm_init: host alloc");
     c->world = world; c->rank = rank;
     if (hipGetDevice(&c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
+        c->comm = nullptr;
+        rmu_comm_free(c);                            // one cleanup path (a created stream goes back too)
         return cfail(RMU_E_HIP, "rmu_comm_init: stream");
     }
     ncclUniqueId uid;
@@ -137,6 +150,7 @@ extern "C" int rmu_shard_allgather_topk(rmu_comm_t* c, const float* scores, cons
     if (nq < 1 || k < 1 || k > 128) return cfail(RMU_E_INVALID, "rmu_shard_allgather_topk: nq >= 1, k in [1,128]");
     const RcclApi& api = rccl();
     std::lock_guard<std::mutex> lk(c->mu);
+    CommDeviceScope dev(c->device);
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const bool in_dev = flags & RMU_F_Q_DEVICE, out_dev = flags & RMU_F_OUT_DEVICE;
     const int64_t n = nq * k;

@@ -3,62 +3,100 @@ builds at server/RAGHelper_local.py:107-117 (HuggingFaceEmbeddings) and server/R
 (HuggingFaceCrossEncoder), with the forwards running in librmu.so.
 
 Behaviour restated from the pinned dependencies:
-  * embed_documents: "\\n" -> " ", tokenize (truncate to max_seq_length = 256), BERT, masked mean pool,
-    L2 normalise, -> list[list[float]];  embed_query(t) = embed_documents([t])[0].
+  * embed_documents: "\\n" -> " " (langchain-huggingface), tokenize (truncate to the checkpoint's max_seq_length), BERT,
+    the checkpoint's Pooling (masked mean | CLS) and Normalize if its modules.json lists one, -> list[list[float]];
+    embed_query(t) = embed_documents([t])[0].
   * score(pairs): tokenize pair ([CLS] q [SEP] p [SEP], token types 0/1, longest-first truncation to 512),
-    BertForSequenceClassification logit (num_labels = 1), -> list[float].
+    BertForSequenceClassification logit (num_labels = 1), the checkpoint's activation (Identity for the ms-marco
+    models, Sigmoid when the config names none), -> list[float].
+What the checkpoint directory declares is read by `ragmeup_amd.checkpoint`, never assumed; with a bare `encoder=`
+(no directory) the all-MiniLM-L6-v2 settings BASELINE.json names apply: mean pooling, Normalize, max_seq_length 256.
+
 Sequences are length-sorted and batched by a token budget (sentence-transformers sorts by length too); the
-packed-token kernels spend no FLOPs on padding.
+packed-token kernels spend no FLOPs on padding.  Token ids stay in numpy arrays from `rmu_tok_encode` to
+`rmu_bert_encode`: no per-text Python lists on the indexing path.
 
 A tokenizer needs a vocabulary, which does not exist offline in the build image: pass `tokenizer=` (any
 callable HF-style tokenizer) or a `model_dir` containing tokenizer files.  `embed_ids` / `score_ids` take
-pre-tokenised input and are what the benchmarks use.
+pre-tokenised input and are what the kernel benchmarks use.
 """
 from __future__ import annotations
 
-from typing import Any, Sequence
+from typing import Any, Optional, Sequence
 
 import numpy as np
 
+from . import bert as B
 from ._lc import CROSS_ENCODER_BASES, Embeddings
 from .bert import BertEncoder
 
 
-def _pad(seqs: Sequence[Sequence[int]], pad: int = 0):
-    L = max(1, max(len(s) for s in seqs))
-    ids = np.full((len(seqs), L), pad, dtype=np.int32)
-    lens = np.zeros(len(seqs), dtype=np.int32)
+def _pad(seqs: Sequence[Sequence[int]], pad: int = 0, max_len: Optional[int] = None):
+    """list of id lists -> (ids [n, L] int32, lens [n] int32); sequences longer than max_len keep their head."""
+    n = len(seqs)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int32, count=n)
+    if max_len is not None:
+        np.minimum(lens, max_len, out=lens)
+    L = max(1, int(lens.max(initial=0)))
+    ids = np.full((n, L), pad, dtype=np.int32)
     for i, s in enumerate(seqs):
-        ids[i, :len(s)] = s
-        lens[i] = len(s)
+        ids[i, :lens[i]] = s[:lens[i]]
     return ids, lens
 
 
 class _EncoderBase:
+    _default_max_seq_length = 256
+
     def __init__(self, encoder: BertEncoder | None = None, model_dir: str | None = None, tokenizer: Any = None,
-                 max_seq_length: int = 256, token_budget: int = 262144, device: int = 0):
+                 max_seq_length: int | None = None, token_budget: int = 262144, device: int = 0):
+        self.spec = None
         if encoder is None:
             if model_dir is None:
                 raise ValueError("pass a BertEncoder or a checkpoint directory")
-            encoder = BertEncoder.from_pretrained_dir(model_dir, device=device)
+            self.spec = self._read_spec(model_dir)
+            encoder = BertEncoder.from_spec(self.spec, device=device, head=self._wants_head)
         self.encoder = encoder
-        if tokenizer is None and model_dir is not None:
-            import os
-            vocab = os.path.join(model_dir, "vocab.txt")
-            if os.path.exists(vocab):       # BERT WordPiece checkpoints: the native host tokenizer (rmu_tok_*)
-                from .tokenizer import WordPieceTokenizer
-                lower = True
-                cfg = os.path.join(model_dir, "tokenizer_config.json")
-                if os.path.exists(cfg):
-                    import json
-                    lower = bool(json.load(open(cfg)).get("do_lower_case", True))
-                tokenizer = WordPieceTokenizer(vocab, do_lower_case=lower)
-            else:
-                from transformers import AutoTokenizer
-                tokenizer = AutoTokenizer.from_pretrained(model_dir)
+        self._text_lower = False
+        if self.spec is not None:
+            self._text_lower = self.spec.st_lower_case
+            if tokenizer is None:
+                if self.spec.vocab_file:        # BERT WordPiece checkpoints: the native host tokenizer (rmu_tok_*)
+                    from .tokenizer import WordPieceTokenizer
+                    tokenizer = WordPieceTokenizer(self.spec.vocab_file, do_lower_case=self.spec.tok_lower_case)
+                else:
+                    from transformers import AutoTokenizer
+                    tokenizer = AutoTokenizer.from_pretrained(model_dir)
+            if max_seq_length is None:
+                max_seq_length = self.spec.max_seq_length
+        if max_seq_length is None:
+            max_seq_length = self._default_max_seq_length
         self.tokenizer = tokenizer
         self.max_seq_length = min(int(max_seq_length), encoder.max_pos)
         self.token_budget = int(token_budget)
+
+    _wants_head: bool | None = None
+
+    def _read_spec(self, model_dir):      # overridden
+        raise NotImplementedError
+
+    # ---- tokenisation: texts -> padded numpy arrays ---------------------------------------------------------------
+    def _tokenize_arrays(self, texts_a: list[str], texts_b: list[str] | None = None, want_types: bool = False):
+        """-> ids [n, L] int32, type_ids [n, L] int32 | None, lens [n] int32 (host numpy)."""
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer: give model_dir/tokenizer, or call embed_ids / score_ids with token ids")
+        from .tokenizer import WordPieceTokenizer
+        if isinstance(self.tokenizer, WordPieceTokenizer):
+            ids, tt, lens = self.tokenizer.encode(texts_a, texts_b, max_len=self.max_seq_length)
+            L = max(1, int(lens.max(initial=1)))
+            return ids[:, :L], (tt[:, :L] if want_types else None), lens
+        if texts_b is None:
+            enc = self.tokenizer(texts_a, truncation=True, max_length=self.max_seq_length, padding=False, add_special_tokens=True)
+        else:
+            enc = self.tokenizer(texts_a, texts_b, truncation="longest_first", max_length=self.max_seq_length, padding=False,
+                                 return_token_type_ids=True)
+        ids, lens = _pad(enc["input_ids"], max_len=self.max_seq_length)
+        tt = _pad(enc["token_type_ids"], max_len=self.max_seq_length)[0] if want_types else None
+        return ids, tt, lens
 
     def _batches(self, lens: np.ndarray):
         """Length-sorted batches under a token budget: yields index arrays (into the original order)."""
@@ -70,16 +108,26 @@ class _EncoderBase:
             yield order[i:i + n]
             i += n
 
-    def _run(self, seqs, types, mode: int):
+    def _run_arrays(self, ids: np.ndarray, types: np.ndarray | None, lens: np.ndarray, mode: int, out=None):
+        """Padded id arrays -> torch CUDA [n, 384] (pooling modes) | [n] (cross-encoder), rows in input order."""
         import torch
-        lens = np.asarray([len(s) for s in seqs], dtype=np.int32)
-        out = torch.empty((len(seqs), 384) if mode == 0 else (len(seqs),), dtype=torch.float32, device=self.encoder.device)
+        n = ids.shape[0]
+        if out is None:
+            out = torch.empty((n, 384) if (mode & 0xff) != B.MODE_CE else (n,), dtype=torch.float32, device=self.encoder.device)
+        if n == 0:
+            return out
+        lens = np.minimum(np.asarray(lens, dtype=np.int32), min(ids.shape[1], self.max_seq_length))
         for idx in self._batches(lens):
-            ids, ln = _pad([seqs[i] for i in idx])
-            tt = None if types is None else _pad([types[i] for i in idx])[0]
-            res = self.encoder.encode_ids(ids, ln, tt, mode=mode)
+            L = max(1, int(lens[idx[0]]))                          # length-sorted: the first is the longest
+            res = self.encoder.encode_ids(np.ascontiguousarray(ids[idx, :L]), lens[idx],
+                                          None if types is None else np.ascontiguousarray(types[idx, :L]), mode=mode)
             out[torch.as_tensor(idx, device=out.device, dtype=torch.long)] = res
         return out
+
+    def _run(self, seqs, types, mode: int):
+        ids, lens = _pad(seqs, max_len=self.max_seq_length)
+        tt = None if types is None else _pad(types, max_len=self.max_seq_length)[0]
+        return self._run_arrays(ids, tt, lens, mode)
 
 
 class MI355XEmbeddings(_EncoderBase, Embeddings):
@@ -90,38 +138,60 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
     #: texts per pipeline block: while the GPU encodes block i the host tokenises block i+1.  Both the
     #: tokenizer (rmu_tok_encode) and the encoder (rmu_bert_encode) run in librmu.so with the GIL released.
     pipeline_block = 8192
+    _wants_head = False
 
-    def _tokenize(self, texts: list[str]) -> list[list[int]]:
-        if self.tokenizer is None:
-            raise RuntimeError("no tokenizer: give model_dir/tokenizer, or call embed_ids with token ids")
-        enc = self.tokenizer([t.replace("\n", " ") for t in texts], truncation=True, max_length=self.max_seq_length,
-                             padding=False, add_special_tokens=True)
-        return [list(x) for x in enc["input_ids"]]
+    def __init__(self, *a, pooling: str | None = None, normalize: bool | None = None, **kw):
+        super().__init__(*a, **kw)
+        from . import checkpoint as C
+        spec = self.spec
+        self.pooling = pooling if pooling is not None else (spec.pooling if spec is not None else C.POOL_MEAN)
+        self.normalize = bool(normalize) if normalize is not None else (spec.normalize if spec is not None else True)
+        if self.pooling not in (C.POOL_MEAN, C.POOL_CLS):
+            raise ValueError(f"pooling={self.pooling!r}: 'mean' or 'cls'")
+        self._mode = (B.MODE_MEAN if self.pooling == C.POOL_MEAN else B.MODE_CLS) | (0 if self.normalize else B.NO_NORMALIZE)
+
+    def _read_spec(self, model_dir):
+        from . import checkpoint as C
+        return C.read_sentence_transformer(model_dir)
+
+    def _prep(self, texts: list[str]) -> list[str]:
+        out = [t.replace("\n", " ") for t in texts]                 # langchain-huggingface embed_documents
+        if self._text_lower:
+            out = [t.lower() for t in out]                           # sentence_bert_config.json do_lower_case
+        return out
+
+    def _tokenize(self, texts: list[str]):
+        ids, _, lens = self._tokenize_arrays(self._prep(texts))
+        return ids, lens
 
     def embed_ids(self, seqs: Sequence[Sequence[int]]):
-        """Pre-tokenised sequences (already carrying [CLS]/[SEP]) -> torch CUDA [n, 384] unit-norm fp32."""
-        seqs = [list(s)[:self.max_seq_length] for s in seqs]
-        return self._run(seqs, None, mode=0)
+        """Pre-tokenised sequences (already carrying [CLS]/[SEP]) -> torch CUDA [n, 384] fp32."""
+        return self._run(seqs, None, mode=self._mode)
 
-    def embed_documents_device(self, texts: list[str]):
-        """texts -> torch CUDA [n, 384] unit-norm fp32, rows in text order.  The vector store appends this tensor to
+    def embed_id_arrays(self, ids: np.ndarray, lens: np.ndarray, out=None):
+        """Padded [n, L] id array + lengths -> torch CUDA [n, 384] fp32 (rows in input order)."""
+        return self._run_arrays(np.asarray(ids), None, np.asarray(lens), self._mode, out=out)
+
+    def embed_documents_device(self, texts: list[str], out=None):
+        """texts -> torch CUDA [n, 384] fp32, rows in text order.  The vector store appends this tensor to
         the HBM-resident corpus device-to-device (`rmu_index_add(is_device=1)`): embeddings never visit the host."""
         import torch
         texts = list(texts)
         blk = max(1, int(self.pipeline_block))
         if len(texts) <= blk:
-            return self.embed_ids(self._tokenize(texts))
+            return self.embed_id_arrays(*self._tokenize(texts), out=out)
         # two-stage pipeline over blocks of texts: a worker thread tokenises the next block while this thread encodes
         from concurrent.futures import ThreadPoolExecutor
-        out = torch.empty((len(texts), 384), dtype=torch.float32, device=self.encoder.device)
+        if out is None:
+            out = torch.empty((len(texts), 384), dtype=torch.float32, device=self.encoder.device)
         starts = list(range(0, len(texts), blk))
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(self._tokenize, texts[starts[0]:starts[0] + blk])
             for i, lo in enumerate(starts):
-                seqs = fut.result()
+                ids, lens = fut.result()
                 if i + 1 < len(starts):
                     fut = pool.submit(self._tokenize, texts[starts[i + 1]:starts[i + 1] + blk])
-                out[lo:lo + len(seqs)] = self.embed_ids(seqs)
+                self.embed_id_arrays(ids, lens, out=out[lo:lo + ids.shape[0]])
         return out
 
     def embed_documents_array(self, texts: list[str]) -> np.ndarray:
@@ -133,26 +203,43 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
     def embed_query(self, text: str) -> list[float]:
         return self.embed_documents([text])[0]
 
+    def token_embeddings_ids(self, ids: np.ndarray, lens: np.ndarray):
+        """Final hidden state of every token (sentence-transformers output_value="token_embeddings"): one batch, packed
+        [sum(lens), 384] fp32 torch CUDA in input order."""
+        return self.encoder.encode_ids(np.asarray(ids), np.asarray(lens), None, mode=B.MODE_TOKENS)
+
 
 class MI355XCrossEncoder(_EncoderBase, *CROSS_ENCODER_BASES):
     """Drop-in for langchain_community.cross_encoders.HuggingFaceCrossEncoder: `.score(text_pairs)`; an instance of every
     importable `BaseCrossEncoder` (the type of the reranker's `model` field, server/ScoredCrossEncoderReranker.py:15)."""
 
-    def __init__(self, *a, max_seq_length: int = 512, **kw):
-        super().__init__(*a, max_seq_length=max_seq_length, **kw)
+    _default_max_seq_length = 512
+    _wants_head = True
+
+    def __init__(self, *a, activation: str | None = None, **kw):
+        super().__init__(*a, **kw)
         if not self.encoder.has_head:
             raise ValueError("checkpoint has no pooler/classifier head")
+        # bare encoder: Identity, the ms-marco cross-encoders' configured activation (BASELINE.json configs[4])
+        self.activation = activation if activation is not None else (self.spec.activation if self.spec is not None else "identity")
+        if self.activation not in ("identity", "sigmoid"):
+            raise ValueError(f"activation={self.activation!r}: 'identity' or 'sigmoid'")
+
+    def _read_spec(self, model_dir):
+        from . import checkpoint as C
+        return C.read_cross_encoder(model_dir)
+
+    def _activate(self, logits):
+        return logits if self.activation == "identity" else logits.sigmoid()
 
     def score_ids(self, seqs: Sequence[Sequence[int]], type_ids: Sequence[Sequence[int]]):
-        seqs = [list(s)[:self.max_seq_length] for s in seqs]
-        types = [list(t)[:self.max_seq_length] for t in type_ids]
-        return self._run(seqs, types, mode=1)
+        return self._activate(self._run(seqs, type_ids, mode=B.MODE_CE))
+
+    def score_id_arrays(self, ids: np.ndarray, type_ids: np.ndarray, lens: np.ndarray):
+        return self._activate(self._run_arrays(np.asarray(ids), np.asarray(type_ids), np.asarray(lens), B.MODE_CE))
 
     def score(self, text_pairs: list[tuple[str, str]]) -> list[float]:
         if not text_pairs:
             return []
-        if self.tokenizer is None:
-            raise RuntimeError("no tokenizer: give model_dir/tokenizer, or call score_ids with token ids")
-        enc = self.tokenizer([p[0] for p in text_pairs], [p[1] for p in text_pairs], truncation="longest_first",
-                             max_length=self.max_seq_length, padding=False, return_token_type_ids=True)
-        return self.score_ids(enc["input_ids"], enc["token_type_ids"]).cpu().numpy().astype(np.float64).tolist()
+        ids, tt, lens = self._tokenize_arrays([p[0] for p in text_pairs], [p[1] for p in text_pairs], want_types=True)
+        return self.score_id_arrays(ids, tt, lens).cpu().numpy().astype(np.float64).tolist()

@@ -89,8 +89,14 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> tuple[int, int]:
 class ShardedSearcher:
     def __init__(self, index=None, row_base: int = 0, group=None,
                  local_search: Callable | None = None, merge: Callable | None = None, force_collective: bool = False,
-                 comm: NativeComm | None = None):
+                 comm: NativeComm | None = None, smaller_better: bool | None = None):
         self.index = index
+        # distance lists (an RMU_METRIC_L2SQ index: smaller = better) must be merged the other way round; by default the
+        # index's own metric decides
+        if smaller_better is None:
+            from . import _native as N
+            smaller_better = getattr(index, "metric", None) == N.METRIC_L2SQ
+        self.smaller_better = bool(smaller_better)
         self.row_base = int(row_base)
         self.group = group
         self.comm = comm                       # the C-ABI RCCL path when given (else torch.distributed)
@@ -114,7 +120,7 @@ class ShardedSearcher:
         Returns (scores [B,k] f32, rows [B,k] i64) -- identical on every rank."""
         s, r = self._search(q, k)
         if self.comm is not None and (self.comm.world > 1 or self.force_collective):
-            return self.comm.allgather_topk(torch.as_tensor(s), torch.as_tensor(r))
+            return self.comm.allgather_topk(torch.as_tensor(s), torch.as_tensor(r), smaller_better=self.smaller_better)
         w = self.world
         if w == 1 and not (self.force_collective and dist.is_initialized()):
             return s, r
@@ -131,4 +137,4 @@ class ShardedSearcher:
         recv = recv.view(w, nb_s + nb_r)
         ps = recv[:, :nb_s].contiguous().view(torch.float32).view(w, nq, k)
         pr = recv[:, nb_s:].contiguous().view(torch.int64).view(w, nq, k)
-        return self._merge(ps, pr)
+        return self._merge(ps, pr, smaller_better=True) if self.smaller_better else self._merge(ps, pr)

@@ -92,6 +92,9 @@ class MI355XRetriever(VectorStoreRetriever):
             thr = self.search_kwargs.get("score_threshold")
             kw2 = {k: v for k, v in self.search_kwargs.items() if k != "score_threshold"}
             pairs = self.vectorstore.similarity_search_with_relevance_scores(query, **kw2)
+            # a native-L2 store ranks by DISTANCE (smaller = better): the threshold is an upper bound there
+            if getattr(self.vectorstore, "metric", "ip") == "l2":
+                return [d for d, s in pairs if thr is None or s <= thr]
             return [d for d, s in pairs if thr is None or s >= thr]
         return self.vectorstore.similarity_search(query, **self.search_kwargs)
 
@@ -104,6 +107,20 @@ class MI355XRetriever(VectorStoreRetriever):
 
 
 _METRICS = {"ip": N.METRIC_IP, "cosine": N.METRIC_COSINE, "l2": N.METRIC_L2SQ}
+
+
+def _json_default(o):
+    """Metadata values loaders produce that JSON does not know (numpy scalars, datetimes, bytes, Paths): stored as plain
+    numbers where they are numbers, else as their string form -- persist() must not fail on them."""
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.floating):
+        return float(o)
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    if isinstance(o, (bytes, bytearray)):
+        return o.decode("utf-8", "replace")
+    return str(o)
 
 
 class MI355XVectorStore(VectorStore):
@@ -147,6 +164,14 @@ class MI355XVectorStore(VectorStore):
             ref = weakref.ref(self)
             atexit.register(lambda: (lambda s: s is not None and s._dirty and s._persist_quietly())(ref()))
 
+    def __del__(self):
+        # a dirty "atexit" store that is collected BEFORE interpreter exit would otherwise never be written
+        try:
+            if self.auto_persist == "atexit" and self._dirty and self._index is not None and self._persist_paths():
+                self._persist_quietly()
+        except Exception:   # noqa: BLE001 - partially constructed object / interpreter teardown
+            pass
+
     @property
     def embeddings(self):
         """The `Embeddings` object (a read-only property on LangChain's VectorStore)."""
@@ -165,8 +190,14 @@ class MI355XVectorStore(VectorStore):
                             drop_old=drop_old, **kw)
                 cls._collections[key] = store
                 # vector_store_initial_load=False: re-open what an earlier run persisted (RAGHelper.py:391, :417)
-                if not drop_old and store._persist_paths() and all(os.path.exists(p) for p in store._persist_paths()):
+                paths = store._persist_paths()
+                if not drop_old and paths and all(os.path.exists(p) for p in paths):
                     store.load()
+                elif not drop_old and paths and os.path.exists(paths[0]) and os.path.exists(paths[1][:-len(".json")] + ".pkl"):
+                    # a store written before the JSON format: re-opening it EMPTY would silently drop the collection
+                    cls._collections.pop(key, None)
+                    raise RuntimeError(f"{paths[1][:-len('.json')]}.pkl is a pre-JSON metadata file this version does not read: "
+                                       f"re-index (vector_store_initial_load=True) or convert it to {paths[1]}")
         if documents:
             store.add_documents(documents, ids=ids)
         return store
@@ -202,17 +233,26 @@ class MI355XVectorStore(VectorStore):
             with open(paths[1] + ".tmp", "w", encoding="utf-8") as f:
                 json.dump({"format": 1, "n": len(self._texts), "dim": self._dim, "metric": self.metric,
                            "score_mode": self.score_mode, "texts": self._texts, "metas": self._metas, "pks": self._pks,
-                           "alive": [1 if a else 0 for a in self._alive]}, f)
+                           "alive": [1 if a else 0 for a in self._alive]}, f, default=_json_default)
             os.replace(paths[0] + ".tmp", paths[0])
             os.replace(paths[1] + ".tmp", paths[1])
             self._dirty = False
         return True
 
     def _persist_quietly(self):
+        """The atexit / finalizer hook: a failure cannot propagate at interpreter shutdown, so it is REPORTED (stderr), the
+        half-written temporaries are removed and the previous pair of files stays as it was."""
         try:
             self.persist()
-        except Exception:   # noqa: BLE001 - interpreter shutdown: nothing useful to do with it
-            pass
+        except Exception as e:   # noqa: BLE001
+            import sys
+            print(f"ragmeup_amd: persisting collection {self.collection_name!r} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            for p in self._persist_paths() or ():
+                try:
+                    if os.path.exists(p + ".tmp"):
+                        os.remove(p + ".tmp")
+                except OSError:
+                    pass
 
     def load(self) -> bool:
         paths = self._persist_paths()
@@ -308,11 +348,19 @@ class MI355XVectorStore(VectorStore):
                 self._alive.append(True)
             try:
                 first = self._index.add(vecs)
-                if first != n0:
-                    raise RuntimeError(f"index rows ({first}) and host records ({n0}) out of step")
             except Exception:
                 del self._texts[n0:], self._metas[n0:], self._pks[n0:], self._alive[n0:]
                 raise
+            if first != n0:
+                # the rows ARE in the index now (and so is whatever made the counts differ): every index row from n0 on is
+                # tombstoned and gets a dead placeholder record, so row numbers and records stay in step
+                end = first + len(keep)
+                self._index.remove_rows(list(range(min(n0, first), end)))
+                for r in range(min(n0, first), len(self._alive)):
+                    self._alive[r] = False
+                while len(self._texts) < end:
+                    self._texts.append(""); self._metas.append({}); self._pks.append(""); self._alive.append(False)
+                raise RuntimeError(f"index rows ({first}) and host records ({n0}) out of step: the batch was rolled back")
             # the new copies are in: only now retire the rows they replace (a failed add loses nothing)
             stale = [self._pk_to_row[ids[i]] for i in keep
                      if ids[i] in self._pk_to_row and self._alive[self._pk_to_row[ids[i]]]]

@@ -8,7 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O  # noqa: E402
-from tests.helpers import bert_weights_numpy, make_bert, synth_tokens  # noqa: E402
+from tests.helpers import bert_weights_numpy, centred_cosine, make_bert, synth_tokens, token_rel_error  # noqa: E402
 from ragmeup_amd.bert import BertEncoder  # noqa: E402
 
 m = make_bert(seed=0, layers=6)
@@ -18,8 +18,14 @@ enc = BertEncoder(w, layers=6)
 ids, tt, lens = synth_tokens(300, seed=11, lmin=3, lmax=250, mean=128, std=60)
 got = enc.encode_ids(ids, lens, None, mode=0).cpu().numpy()
 sel = np.arange(0, 300, 10)                      # the oracle is fp64 numpy: compare a sample of 30 sequences
-ref = O.embed_pool(O.bert_hidden(w, ids[sel], np.zeros_like(ids[sel]), lens[sel]), lens[sel])
+hid = O.bert_hidden(w, ids[sel], np.zeros_like(ids[sel]), lens[sel])
+ref = O.embed_pool(hid, lens[sel])
+tok = enc.encode_ids(ids, lens, None, mode=3).cpu().numpy()          # RMU_BERT_TOKENS: every token's final hidden state
+cu = np.concatenate([[0], np.cumsum(lens)])
+rel = token_rel_error(np.concatenate([tok[cu[b]:cu[b + 1]] for b in sel]), hid, lens[sel])
 g = got[sel]
 cos = (g * ref).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(ref, axis=1)
 print("RESULT " + json.dumps({"min_cos": float(cos.min()), "finite": bool(np.isfinite(got).all()),
+                              "max_tok_rel": float(rel.max()), "mean_tok_rel": float(rel.mean()),
+                              "min_centred_cos": float(centred_cosine(g, ref).min()),
                               "norm_err": float(np.abs(np.linalg.norm(got, axis=1) - 1).max())}))

@@ -1,13 +1,21 @@
 """GPU parity of the BERT-6x384 forwards against the fp64 oracle (itself pinned on transformers' BertModel in
 tests/test_oracle_cpu.py).  Weights are architecture-exact and synthetic (no checkpoints exist offline).
 
-Tolerance (bf16 MFMA vs fp32/fp64 reference): cosine(embedding, oracle) >= 0.999;
-cross-encoder logit within 2e-2 * (1 + |logit|)."""
+Tolerances (bf16 MFMA activations vs the fp64 oracle).  Random-init BERT mean-pools ~100 random tokens into
+nearly one direction (pairwise cosine 0.98-0.996 between DIFFERENT chunks), so cosine >= 0.999 alone barely discriminates;
+the bars that do:
+  * per-token final hidden state: |h - h_oracle| / |h_oracle| <= 2e-2 for EVERY token (a numpy model of the kernels' bf16
+    rounding points predicts mean 0.8e-2, max 1.0e-2; a dropped head or a mis-rounded LayerNorm is >= 1e-1);
+  * mean-centred cosine >= 0.99 (batch mean vector removed on both sides: another chunk's vector scores < 0.5);
+  * cross-encoder logit within 8e-3 (1 + |logit|) at the 0.02 init (model: 2.6e-3), and on a 3x-scaled weight set -- where
+    logits spread by 0.17 instead of collapsing to 3e-3 -- within 3e-2 with Pearson r >= 0.99 (model: 1e-2)."""
 import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.helpers import bert_weights_numpy, make_bert, synth_tokens
+from tests.helpers import bert_weights_numpy, centred_cosine, make_bert, synth_tokens, token_rel_error
+
+MODE_TOKENS = 3
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +47,24 @@ def test_embeddings_vs_oracle(bi, n, lmax, mean):
     cos = (got * ref).sum(1) / np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1)
     assert cos.min() >= 0.999, cos
     assert np.allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)          # unit norm (ST Normalize)
+    if n >= 5:
+        assert centred_cosine(got, ref).min() >= 0.99
+
+
+@pytest.mark.parametrize("n,lmax,mean", [(1, 16, 8), (9, 40, 24), (33, 128, 90), (5, 256, 200), (3, 512, 400), (160, 128, 100)])
+def test_token_hidden_states_vs_oracle(bi, n, lmax, mean):
+    """Every token's final hidden state against the fp64 oracle (the small-batch kernels, the GEMM pair and -- 160 x ~100
+    tokens > 16384 -- the fused FFN kernel)."""
+    enc, w = bi
+    ids, tt, lens = synth_tokens(n, seed=13 + n, lmin=2, lmax=lmax, mean=mean, std=max(2, mean // 3))
+    got = enc.encode_ids(ids, lens, None, mode=MODE_TOKENS).cpu().numpy()
+    sel = np.arange(n) if n <= 40 else np.arange(0, n, 5)                     # the oracle is fp64 numpy: sample big batches
+    ref = O.bert_hidden(w, ids[sel], np.zeros_like(ids[sel]), lens[sel])
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    rows = np.concatenate([got[cu[b]:cu[b + 1]] for b in sel])
+    rel = token_rel_error(rows, ref, lens[sel])
+    assert rel.max() <= 2e-2, (float(rel.max()), float(rel.mean()))
+    assert got.shape == (int(lens.sum()), 384)
 
 
 def test_padding_and_batch_composition_do_not_matter(bi):
@@ -60,12 +86,33 @@ def test_cross_encoder_logits_vs_oracle(cross):
     enc, w = cross
     ids, tt, lens = synth_tokens(14, seed=5, lmax=160, mean=120, std=25, pair=True)
     got = enc.encode_ids(ids, lens, tt, mode=1).cpu().numpy()
-    ref = O.cross_encoder_logit(w, O.bert_hidden(w, ids, tt, lens))
-    assert np.all(np.abs(got - ref) <= 2e-2 * (1 + np.abs(ref))), (got, ref)
+    hid = O.bert_hidden(w, ids, tt, lens)
+    ref = O.cross_encoder_logit(w, hid)
+    assert np.all(np.abs(got - ref) <= 8e-3 * (1 + np.abs(ref))), (got, ref)
+    rel = token_rel_error(enc.encode_ids(ids, lens, tt, mode=MODE_TOKENS).cpu().numpy(), hid, lens)
+    assert rel.max() <= 2e-2, float(rel.max())                                # token types 0/1 included
     # rerank order identical up to near-ties
     order_g, order_r = np.argsort(-got, kind="stable"), np.argsort(-ref, kind="stable")
     for a, b in zip(order_g, order_r):
         assert a == b or abs(ref[a] - ref[b]) < 1e-2
+
+
+def test_cross_encoder_logits_on_weights_that_do_not_collapse():
+    """At the 0.02 init all pairs land within 3e-3 of one logit -- the size of the bf16 noise -- so a value check there says
+    little.  With every Linear weight x3 the logits spread by ~0.17: held to |d| <= 3e-2 and Pearson r >= 0.99."""
+    from ragmeup_amd.bert import BertEncoder
+    w = bert_weights_numpy(make_bert(seed=1, layers=6, head=True, scale=3.0))
+    enc = BertEncoder(w, layers=6)
+    ids, tt, lens = synth_tokens(48, seed=5, lmax=160, mean=100, std=40, pair=True)
+    got = enc.encode_ids(ids, lens, tt, mode=1).cpu().numpy()
+    hid = O.bert_hidden(w, ids, tt, lens)
+    ref = O.cross_encoder_logit(w, hid)
+    assert ref.std() > 0.08, float(ref.std())                                  # the weight set does what it is for
+    assert np.abs(got - ref).max() <= 3e-2, float(np.abs(got - ref).max())
+    assert np.corrcoef(got, ref)[0, 1] >= 0.99
+    rel = token_rel_error(enc.encode_ids(ids, lens, tt, mode=MODE_TOKENS).cpu().numpy(), hid, lens)
+    assert rel.max() <= 2.5e-2, float(rel.max())
+    enc.close()
 
 
 def test_embeddings_object_and_reranker_pipeline(bi, cross):
@@ -161,6 +208,9 @@ def test_embeddings_4096_chunk_sample_vs_transformers(bi):
             ref[sel] = torch.nn.functional.normalize(pooled, p=2, dim=1).numpy()
     cos = (got * ref).sum(1)
     assert cos.min() >= 0.999, (float(cos.min()), int(cos.argmin()), int(lens[cos.argmin()]))
+    cc = centred_cosine(got, ref)
+    assert cc.min() >= 0.99, (float(cc.min()), int(cc.argmin()), int(lens[cc.argmin()]))
+    assert centred_cosine(np.roll(ref, 1, axis=0), ref).max() < 0.9           # ... a bar another chunk's vector fails
     assert np.abs(np.linalg.norm(got, axis=1) - 1.0).max() < 1e-5
 
 
@@ -174,12 +224,11 @@ def test_cross_encoder_100_pairs_tolerance_1e2(cross):
     order_g, order_r = np.argsort(-got, kind="stable"), np.argsort(-ref, kind="stable")
     for a, b in zip(order_g[:10], order_r[:10]):
         assert a == b or abs(ref[a] - ref[b]) < 1e-2, (a, b, ref[a], ref[b])
-    assert np.abs(got - ref).max() <= 2e-2 * (1 + np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 8e-3 * (1 + np.abs(ref).max())
 
 
-@pytest.mark.parametrize("env", [{"RMU_GEMM3": "0"}, {"RMU_GEMM3": "7"}, {"RMU_GEMM3": "2", "RMU_FUSED_FFN": "0"},
-                                 {"RMU_ATTN2": "1"}, {"RMU_FUSED_LN": "1", "RMU_FUSED_FFN": "0"}],
-                         ids=["k_gemm_only", "k_gemm3_everywhere", "unfused_ffn", "attention2", "gemm_ln"])
+@pytest.mark.parametrize("env", [{"RMU_GEMM3": "0"}, {"RMU_GEMM3": "7"}, {"RMU_GEMM3": "2", "RMU_FUSED_FFN": "0"}],
+                         ids=["k_gemm_only", "k_gemm3_everywhere", "unfused_ffn"])
 def test_every_switchable_kernel_variant_keeps_parity(env):
     """The opt-in kernels (kept for the measurements DESIGN.md quotes) are held to the same bar as the default path."""
     import json
@@ -192,3 +241,4 @@ def test_every_switchable_kernel_variant_keeps_parity(env):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["finite"] and res["min_cos"] >= 0.999 and res["norm_err"] < 1e-5, res
+    assert res["max_tok_rel"] <= 2e-2 and res["min_centred_cos"] >= 0.99, res

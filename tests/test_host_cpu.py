@@ -230,6 +230,50 @@ def test_persist_and_reopen(tmp_path):
         MI355XVectorStore._index_factory = None
 
 
+def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, capsys):
+    """metadata values that JSON does not know (numpy scalars, datetimes, bytes -- what loaders produce) must not
+    make persist() raise; a persist that does fail at exit is reported, leaves no .tmp behind and keeps the previous files; a
+    dirty store that is garbage-collected before exit is written; a pre-JSON .meta.pkl is not silently re-opened empty."""
+    import datetime
+    import gc
+    MI355XVectorStore._index_factory = FakeIndex
+    try:
+        MI355XVectorStore._collections.clear()
+        uri = str(tmp_path / "data.db")
+        docs = _chunks(4)
+        docs[0].metadata.update(page=np.int64(3), score=np.float32(0.5), when=datetime.datetime(2025, 1, 3), raw=b"ab", arr=np.arange(2))
+        a = MI355XVectorStore.from_documents(docs, HashEmbeddings(), drop_old=True, connection_args={"uri": uri}, collection_name="c",
+                                             ids=[d.metadata["id"] for d in docs])
+        assert a.persist()
+        import json as _json
+        md = _json.load(open(uri + ".c.meta.json"))["metas"][0]
+        assert md["page"] == 3 and md["score"] == 0.5 and md["when"].startswith("2025-01-03") and md["raw"] == "ab" and md["arr"] == [0, 1]
+        # a failing write at exit: reported, no temporaries, previous files intact
+        before = open(uri + ".c.meta.json").read()
+        a._dirty = True
+        real_save = a._index.save
+        a._index.save = lambda p: (open(p, "wb").write(b"partial"), (_ for _ in ()).throw(OSError("disk full")))
+        a._persist_quietly()
+        a._index.save = real_save
+        assert "disk full" in capsys.readouterr().err
+        assert not os.path.exists(uri + ".c.rmu.tmp") and not os.path.exists(uri + ".c.meta.json.tmp")
+        assert open(uri + ".c.meta.json").read() == before
+        # collected before exit while dirty -> written by the finalizer
+        a.add_documents(_chunks(2, "late.pdf"), ids=["l0", "l1"])
+        assert a._dirty
+        del a
+        MI355XVectorStore._collections.clear()
+        gc.collect()
+        assert _json.load(open(uri + ".c.meta.json"))["n"] == 6
+        # legacy pickle metadata next to a matrix file
+        os.rename(uri + ".c.meta.json", uri + ".c.meta.pkl")
+        with pytest.raises(RuntimeError, match="pre-JSON"):
+            MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False, connection_args={"uri": uri}, collection_name="c")
+    finally:
+        MI355XVectorStore._index_factory = None
+        MI355XVectorStore._collections.clear()
+
+
 def test_add_texts_upsert_duplicates_and_failed_add(store):
     """duplicate ids inside one batch leave ONE live row (the last wins); a failing index.add loses nothing and
     leaves host records and index in step; host records exist before the rows become searchable."""
@@ -249,6 +293,21 @@ def test_add_texts_upsert_duplicates_and_failed_add(store):
     store._index.add = real_add
     assert len(store) == 3 and len(store._texts) == len(store._index) == 3
     assert {d.metadata["pk"] for d in store.similarity_search("chunk", k=10)} == {"k0", "k1", "k2"}
+
+    # an index that reports another first row than the records expect: the rows ARE in the index -- they are tombstoned there
+    # too, so a later search cannot return a row whose record describes something else
+    def shifted(v):
+        real_add(np.zeros((1, 384), np.float32))                         # some foreign row slipped in
+        return real_add(v)
+    store._index.add = shifted
+    with pytest.raises(RuntimeError, match="out of step"):
+        store.add_documents(_chunks(2, "x.pdf"), ids=["x0", "x1"])
+    store._index.add = real_add
+    assert len(store) == 3
+    assert {d.metadata["pk"] for d in store.similarity_search("chunk number 0 of x.pdf", k=10)} <= {"k0", "k1", "k2"}
+    assert len(store._texts) == len(store._index) == 6                   # dead placeholders keep rows and records aligned
+    del store._texts[3:], store._metas[3:], store._pks[3:], store._alive[3:]                    # (test hygiene for what follows)
+    store._index.x, store._index.alive = store._index.x[:3], store._index.alive[:3]
 
     seen = []
     def spy(v):

@@ -710,7 +710,20 @@ def test_native_comm_world1(rmu, corpus50k):
     N.check(N.lib().rmu_shard_allgather_topk(comm._h, ls.ctypes.data, lr.ctypes.data, 7, 5, 0, out_s.ctypes.data, out_r.ctypes.data, 0),
             "rmu_shard_allgather_topk")
     assert np.array_equal(out_s, ls) and np.array_equal(out_r, lr)
-    comm.close(); idx.close()
+    idx.close()
+    # distance lists (RMU_METRIC_L2SQ): the searcher takes the merge direction from the index -- a larger-is-better merge
+    # of even ONE ascending list would come back re-sorted the wrong way round
+    rng = np.random.default_rng(3)
+    xl = (rng.standard_normal((20_000, 384)) * rng.uniform(0.5, 2.0, (20_000, 1))).astype(np.float32)
+    ql = xl[:40] + 0.05 * rng.standard_normal((40, 384)).astype(np.float32)
+    il2 = rmu.FlatIndex(384, metric=N.METRIC_L2SQ)
+    il2.add(xl)
+    ss2 = ShardedSearcher(il2, row_base=0, comm=comm, force_collective=True)
+    assert ss2.smaller_better
+    d, r = ss2.search(torch.from_numpy(ql).cuda(), 10)
+    d0, r0 = il2.search(ql, 10)
+    assert np.array_equal(r.cpu().numpy(), r0) and np.allclose(d.cpu().numpy(), d0) and (np.diff(d0, axis=1) >= 0).all()
+    comm.close(); il2.close()
 
 
 def test_search_on_caller_stream_is_asynchronous_and_correct(rmu):
@@ -733,4 +746,33 @@ def test_search_on_caller_stream_is_asynchronous_and_correct(rmu):
     st.synchronize()
     assert_topk_parity(out_s.cpu().numpy(), out_r.cpu().numpy(), *O.flat_search(q, xd, 12))
     assert list(out_r[0].cpu().numpy()) == [5] + list(range(40_000, 40_009))
+    idx.close()
+
+
+def test_back_to_back_searches_on_different_caller_streams_do_not_share_scratch(rmu):
+    """The per-thread scratch (query image, partial lists, thresholds, candidate keys) of an un-drained caller-stream
+    search is still in use when the same thread issues the next search on ANOTHER stream (or stream 0): the library
+    orders the second behind the first (rmu.h stream contract).  Without that the second call's memsets and partial
+    lists land under the first call's kernels."""
+    import torch
+    from ragmeup_amd import _native as N
+    x = O.make_corpus(300_000)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    qa, _ = O.make_queries(x, 512, seed=1)
+    qb, _ = O.make_queries(x, 512, seed=2)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    da, db = torch.from_numpy(qa).cuda(), torch.from_numpy(qb).cuda()
+    outs = [(torch.empty((512, 10), dtype=torch.float32, device="cuda"), torch.empty((512, 10), dtype=torch.int64, device="cuda")) for _ in range(3)]
+    torch.cuda.synchronize()
+    lib = N.lib()
+    fl = N.F_Q_DEVICE | N.F_OUT_DEVICE
+    for rep in range(3):
+        N.check(lib.rmu_index_search(idx._h, da.data_ptr(), 512, 10, fl, 0, outs[0][0].data_ptr(), outs[0][1].data_ptr(), sa.cuda_stream), "a")
+        N.check(lib.rmu_index_search(idx._h, db.data_ptr(), 512, 10, fl, 0, outs[1][0].data_ptr(), outs[1][1].data_ptr(), sb.cuda_stream), "b")
+        s0, r0 = idx.search(qa[:64], 10)                                      # stream 0 (internal), host buffers, drained
+        sa.synchronize(); sb.synchronize()
+        assert_topk_parity(outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy(), *O.flat_search(qa, x, 12))
+        assert_topk_parity(outs[1][0].cpu().numpy(), outs[1][1].cpu().numpy(), *O.flat_search(qb, x, 12))
+        assert_topk_parity(s0, r0, *O.flat_search(qa[:64], x, 12))
     idx.close()

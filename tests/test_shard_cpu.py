@@ -27,6 +27,35 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _worker_l2(rank, world, port, n, nq, k, q_out):
+    """Distance lists (RMU_METRIC_L2SQ: smaller = better): the cross-shard merge must keep the SMALLEST distances."""
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((n, 48)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)     # un-normalised rows
+    q = x[rng.permutation(n)[:nq]] + 0.05 * rng.standard_normal((nq, 48)).astype(np.float32)
+    lo, hi = shard_bounds(n, world, rank)
+
+    def local_search(qq, kk):
+        s, r = O.flat_search(np.asarray(qq), x[lo:hi], kk, metric=O.METRIC_L2SQ)               # similarity = -distance
+        return torch.from_numpy((-s).astype(np.float32)), torch.from_numpy(np.where(r >= 0, r + lo, -1))
+
+    def merge(ps, pr, smaller_better=False):
+        assert smaller_better
+        s, r = O.merge_topk(-ps.numpy(), pr.numpy(), ps.shape[2])
+        return torch.from_numpy((-s).astype(np.float32)), torch.from_numpy(r)
+
+    ss = ShardedSearcher(local_search=local_search, merge=merge, smaller_better=True)
+    s, r = ss.search(torch.from_numpy(q), k)
+    gs, gr = O.flat_search(q, x, k, metric=O.METRIC_L2SQ)
+    ok = bool(np.array_equal(r.numpy(), gr) and np.allclose(s.numpy(), -gs, atol=1e-4) and (np.diff(s.numpy(), axis=1) >= 0).all())
+    q_out.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, n, nq, k, q_out):
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -66,3 +95,31 @@ def test_two_rank_sharded_search_equals_global(n, nq, k):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_two_rank_sharded_l2_search_keeps_the_smallest_distances():
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_l2, args=(r, 2, port, 3000, 7, 10, q_out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q_out.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_sharded_searcher_takes_the_merge_direction_from_the_index_metric():
+    from ragmeup_amd import _native as N
+
+    class Idx:
+        metric = N.METRIC_L2SQ
+
+        def search(self, q, k, row_base=0):
+            raise AssertionError
+
+    assert ShardedSearcher(index=Idx(), merge=lambda *a, **k: None).smaller_better is True
+    Idx.metric = N.METRIC_IP
+    assert ShardedSearcher(index=Idx(), merge=lambda *a, **k: None).smaller_better is False
