@@ -37,10 +37,24 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 IMG_ROW_BYTES = 768            # fp16 screening image of a 384-d row
 # HBM bytes per step from rocprofv3 PMC passes of exactly these configurations (2 x FETCH_SIZE [gfx950 correction] +
-# WRITE_SIZE, summed over the launches of a step; profiles/r02_summary.md).  None = not measured for that configuration.
-TRAFFIC = {("screen", 10_000_000, 1024): 1.3665e10, ("screen", 10_000_000, 32): 7.691e9, ("screen", 10_000_000, 1): 7.687e9,
-           ("exact", 10_000_000, 1024): 1.6185e10}
-TRAFFIC_SOURCE = "profiles/r02_pmc_means.csv (sum per bench step of FETCH_SIZE x 1024 x 2 [+ WRITE_SIZE x 1024]; profiles/r02_summary.md)"
+# WRITE_SIZE, summed over the launches of a step).  Read from the newest profiles/rNN_traffic.json, which
+# tools/summarize_profiles.py writes from the round's own PMC passes (tools/profile.sh); a configuration it does not hold
+# reports null.
+
+
+def _load_traffic():
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    if not files:
+        return {}, None
+    d = json.load(open(files[-1]))
+    return {(e["path"], int(e["rows"]), int(e["batch"])): float(e["bytes_per_step"]) for e in d["entries"]}, \
+        f"profiles/{os.path.basename(files[-1])} ({d.get('source', 'rocprofv3 PMC passes')})"
+
+
+
+
+TRAFFIC, TRAFFIC_SOURCE = _load_traffic()
 
 
 def make_shard(n_rows: int, d: int, seed: int, device) -> "torch.Tensor":
@@ -172,7 +186,7 @@ def encoder_flops(lens) -> float:
 
 
 def encoder_roofline(tf: float) -> dict:
-    return {"kernel": "whole forward: k_ffn_fused (bf16 MFMA 32x32x16: FFN1+GELU+FFN2+residual+LayerNorm), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj), k_attention, k_layernorm", "bound": "mfma", "achieved": round(tf, 2),
+    return {"kernel": "whole forward: k_ffn2 (bf16 MFMA 32x32x16: LayerNorm1 + FFN1 + GELU + FFN2 + residual + LayerNorm2), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj + residual), k_attn3 (32x32x16, two-pass softmax off the MFMA accumulator), k_embed_ln, k_pool", "bound": "mfma", "achieved": round(tf, 2),
             "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
             "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches)"}
 
@@ -251,6 +265,183 @@ def leg_c1(args) -> dict:
     return leg
 
 
+def synth_vocab_and_words(seed=0):
+    """A 30522-entry WordPiece vocabulary (all-MiniLM's size; no real vocab.txt exists offline): specials, letters, ~24k random
+    lower-case words of 3-8 letters, ~6k '##' continuation pieces.  Returns (vocab list, the whole words)."""
+    rng = np.random.default_rng(seed)
+    letters = [chr(c) for c in range(ord("a"), ord("z") + 1)]
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + letters + ["##" + c for c in letters]
+    seen = set(toks)
+    lens = rng.integers(3, 9, 40000)
+    chars = rng.integers(0, 26, (40000, 8))
+    words = []
+    for i in range(40000):
+        w = "".join(letters[c] for c in chars[i, :lens[i]])
+        if w not in seen and len(toks) + len(words) < 24000:
+            seen.add(w); words.append(w)
+    toks += words
+    i = 0
+    while len(toks) < 30522:
+        pcs = "##" + "".join(letters[c] for c in chars[39999 - (i % 40000), :1 + (i % 3)]) + (str(i) if i >= 40000 else "")
+        i += 1
+        if pcs not in seen:
+            seen.add(pcs); toks.append(pcs)
+    return toks, words
+
+
+def synth_texts(words, n, seed=1, wmin=60, wmax=110):
+    """n chunk-like texts of wmin..wmax words (~512 characters, .env.template:74's chunk_size): about one token per word plus
+    a few sub-word splits, ~90 tokens."""
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, len(words), (n, wmax))
+    cnt = rng.integers(wmin, wmax + 1, n)
+    return [" ".join(words[j] for j in idx[i, :cnt[i]]) for i in range(n)]
+
+
+def leg_index(args) -> dict:
+    """BASELINE.json configs[2] END TO END, the way the reference runs it (server/RAGHelper.py:423-434): texts -> md5 ids ->
+    db.add_documents(documents, ids=ids) in 1000-document calls -> tokenizer (host C++) -> encoder -> pooled rows appended to the
+    HBM-resident corpus device-to-device.  Also as ONE call (the tokenizer of block i+1 overlaps the encoder of block i), the
+    tokenizer alone, and the encoder alone on the same token arrays (what the C3 leg times)."""
+    import hashlib
+    import tempfile
+    from ragmeup_amd.bert import BertEncoder
+    from ragmeup_amd.documents import Document
+    from ragmeup_amd.embeddings import MI355XEmbeddings
+    from ragmeup_amd.tokenizer import WordPieceTokenizer
+    from ragmeup_amd.vectorstore import MI355XVectorStore
+    n = int(args.index_texts)
+    toks, words = synth_vocab_and_words()
+    vdir = tempfile.mkdtemp()
+    vp = os.path.join(vdir, "vocab.txt")
+    open(vp, "w", encoding="utf-8").write("\n".join(toks) + "\n")
+    texts = synth_texts(words, n)
+    ids = [hashlib.md5(t.encode()).hexdigest() for t in texts]                    # RAGHelper.py:365: id = md5 of the chunk
+    docs = [Document(t, {"source": f"doc{i // 50}.pdf", "id": ids[i]}) for i, t in enumerate(texts)]
+    enc = BertEncoder(bert_weights(0, False), layers=6)
+    tok = WordPieceTokenizer(vp)
+    emb = MI355XEmbeddings(encoder=enc, tokenizer=tok, max_seq_length=256)
+    # tokenizer alone (host threads = hardware concurrency)
+    t0 = time.perf_counter()
+    tid, _, tlen = tok.encode([t.replace("\n", " ") for t in texts], None, 256)
+    tok_s = time.perf_counter() - t0
+    # encoder alone on those token arrays (device-resident ids, 8192-chunk batches: the C3 leg's measurement on this workload)
+    L = int(tlen.max())
+    blocks = [(torch.as_tensor(tid[i:i + 8192, :L]).cuda(), torch.as_tensor(tlen[i:i + 8192]).cuda()) for i in range(0, n, 8192)]
+    out = torch.empty((8192, 384), dtype=torch.float32, device="cuda")
+    enc.encode_ids(blocks[0][0], blocks[0][1], None, 0, out=out[:blocks[0][0].shape[0]])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for bi, bl in blocks:
+        enc.encode_ids(bi, bl, None, 0, out=out[:bi.shape[0]])
+    torch.cuda.synchronize()
+    enc_s = time.perf_counter() - t0
+    del blocks
+
+    def run(batch):
+        store = MI355XVectorStore(embeddings=emb, collection_name=f"bench{batch}", auto_persist=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(0, n, batch):
+            store.add_documents(docs[i:i + batch], ids=ids[i:i + batch])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert len(store) == len(set(ids))
+        store._index.close()
+        return dt
+
+    run(8192)                                                                      # warm-up (workspaces, first-touch)
+    one_s = run(n)
+    ref_s = run(1000)
+    fl = encoder_flops(tlen)
+    leg = {"name": "C3 end to end: texts -> add_documents -> tokenizer -> encoder -> HBM-resident corpus (BASELINE.json configs[2] as the reference runs it)",
+           "value": round(n / one_s, 1), "unit": "chunks/sec", "ms_per_step": round(one_s * 1e3, 1),
+           "config": {"workload": f"{n} synthetic texts of 60-110 words (~{float(tlen.mean()):.0f} tokens), 30522-entry synthetic WordPiece vocabulary, md5 ids, "
+                                  "random-init weights; ONE add_documents call (tokenizer of block i+1 overlaps the encoder of block i)",
+                      "tokens": int(tlen.sum())},
+           "reference_pattern_1000_doc_calls": {"chunks_per_sec": round(n / ref_s, 1), "seconds": round(ref_s, 3),
+                                                "note": "server/RAGHelper.py:423-434: each call tokenises, encodes and inserts its 1000 chunks before it returns"},
+           "encoder_only": {"chunks_per_sec": round(n / enc_s, 1), "seconds": round(enc_s, 3), "note": "encode_ids on pre-tokenised, device-resident 8192-chunk batches of the same texts"},
+           "tokenizer_only": {"texts_per_sec": round(n / tok_s, 1), "seconds": round(tok_s, 3), "threads": os.cpu_count(), "note": "rmu_tok_encode (host C++), all hardware threads"},
+           "end_to_end_over_encoder_only": round(enc_s / one_s, 3), "gpu_busy_fraction": round(enc_s / one_s, 3),
+           "roofline": encoder_roofline(fl / one_s / 1e12)}
+    if not args.no_cpu_baseline:
+        from transformers import BertConfig, BertModel, BertTokenizerFast
+        hf = BertTokenizerFast(vocab_file=vp, do_lower_case=True) if False else None
+        try:
+            from transformers import BertTokenizer
+            hf = BertTokenizer(vocab={t: i for i, t in enumerate(toks)}, do_lower_case=True)
+        except Exception:  # noqa: BLE001
+            hf = None
+        cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12, intermediate_size=1536,
+                         max_position_embeddings=512, layer_norm_eps=1e-12)
+        torch.manual_seed(0)
+        model = BertModel(cfg, add_pooling_layer=False).eval()
+        m = 256
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for b0 in range(0, m, 32):                                             # sentence-transformers' mini-batch of 32
+                if hf is not None:
+                    e = hf([t.replace("\n", " ") for t in texts[b0:b0 + 32]], padding=True, truncation=True, max_length=256, return_tensors="pt")
+                    ii, mk = e["input_ids"], e["attention_mask"]
+                else:
+                    ii = torch.from_numpy(tid[b0:b0 + 32, :int(tlen[b0:b0 + 32].max())].astype(np.int64))
+                    mk = (torch.arange(ii.shape[1])[None, :] < torch.from_numpy(tlen[b0:b0 + 32].astype(np.int64))[:, None]).long()
+                h = model(input_ids=ii, attention_mask=mk).last_hidden_state
+                mm = mk.unsqueeze(-1).float()
+                torch.nn.functional.normalize((h * mm).sum(1) / mm.sum(1).clamp(min=1e-9), dim=1)
+        dt = time.perf_counter() - t0
+        leg["cpu_baseline"] = {"value": round(m / dt, 2), "unit": "chunks/sec", "cores": torch.get_num_threads(), "kind": "reference",
+                               "sample": f"{m} of the texts: transformers BertTokenizer{'' if hf is not None else ' (unavailable: pre-tokenised ids)'} + BertModel fp32 "
+                                         f"+ sentence-transformers pooling on the host, mini-batch 32 ({dt:.2f} s); the vector-store insert is not timed"}
+    enc.close()
+    return leg
+
+
+def leg_mmr(args) -> dict:
+    """The reference's real /chat retrieval: ONE query per call through `db.as_retriever(search_type="mmr", search_kwargs={"k": K})`
+    (server/RAGHelper.py:497-499): embed_query -> dense top-fetch_k (20) -> fetch those vectors -> greedy MMR (host, langchain's
+    expression) -> k documents.  10k-chunk corpus (BASELINE.json configs[0]), text queries through the native tokenizer."""
+    import hashlib
+    import tempfile
+    from ragmeup_amd.bert import BertEncoder
+    from ragmeup_amd.documents import Document
+    from ragmeup_amd.embeddings import MI355XEmbeddings
+    from ragmeup_amd.tokenizer import WordPieceTokenizer
+    from ragmeup_amd.vectorstore import MI355XVectorStore
+    toks, words = synth_vocab_and_words()
+    vp = os.path.join(tempfile.mkdtemp(), "vocab.txt")
+    open(vp, "w", encoding="utf-8").write("\n".join(toks) + "\n")
+    enc = BertEncoder(bert_weights(0, False), layers=6)
+    emb = MI355XEmbeddings(encoder=enc, tokenizer=WordPieceTokenizer(vp), max_seq_length=256)
+    n, nq = 10_000, 64
+    texts = synth_texts(words, n, seed=3)
+    store = MI355XVectorStore(embeddings=emb, collection_name="bench_mmr", auto_persist=False)
+    store.add_documents([Document(t, {"source": f"d{i // 50}.pdf", "id": hashlib.md5(t.encode()).hexdigest()}) for i, t in enumerate(texts)],
+                        ids=[hashlib.md5(t.encode()).hexdigest() for t in texts])
+    retriever = store.as_retriever(search_type="mmr", search_kwargs={"k": 10})
+    queries = synth_texts(words, nq, seed=4, wmin=8, wmax=16)
+
+    def step():
+        for qy in queries:
+            docs = retriever.invoke(qy)
+        return docs
+
+    assert len(step()) == 10
+    ms = timed(step, steps=3, warmup=1)
+    per_q = ms / nq
+    bytes_q = 6 * (4 * 384 * 384 + 2 * 384 * 1536) * 2 + n * 384 * 4
+    leg = {"name": "C1 the reference's /chat retrieval: one query per call, retriever.invoke with search_type='mmr' (embed_query + dense top-20 + MMR -> 10)",
+           "value": round(nq / (ms * 1e-3), 1), "unit": "queries/sec", "ms_per_step": round(per_q, 4),
+           "config": {"workload": "10k x 384 corpus built from texts, 64 single-query calls per timed pass, 8-16-word text queries, k = 10, fetch_k = 20, lambda 0.5"},
+           "roofline": {"kernel": "tokenizer + encoder forward at batch 1 + scan over 10k rows + 20-row gather + host MMR (launch-latency-bound)", "bound": "hbm",
+                        "achieved": round(bytes_q / (per_q * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(bytes_q / (per_q * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                        "basis": "21.3 MB of encoder weights + 15.4 MB of corpus per query; not a bandwidth-bound regime"}}
+    store._index.close(); enc.close()
+    return leg
+
+
 def leg_rerank(args, x1m) -> dict:
     from ragmeup_amd import FlatIndex
     from ragmeup_amd.bert import BertEncoder
@@ -270,11 +461,20 @@ def leg_rerank(args, x1m) -> dict:
 
     ms = timed(step, steps=4, warmup=2)
     ms_ce = timed(lambda: ce.encode_ids(ids_t, lens_t, tt_t, mode=1), steps=4, warmup=1)
+    ms_dense = timed(lambda: idx.search(q, 100), steps=10, warmup=2)
+    idx.set_timing(True); idx.search(q, 100); kms = idx.last_scan_ms(); geom = idx.last_geometry(); idx.set_timing(False)
+    nrow = x1m.shape[0]
+    dense_bytes = nrow * 384 * 4 + nqr * 384 * 4 + nqr * 100 * 12
     fl = encoder_flops(lens)
     leg = {"name": "C5 retrieve-then-rerank (dense top-100 over 1M rows -> cross-encoder 100 pairs/query -> top-10)",
            "value": round(nqr / (ms * 1e-3), 1), "unit": "queries/sec", "ms_per_step": round(ms, 3),
            "config": {"workload": "64 queries/step, 1M x 384 corpus, pairs = 16 query + ~128 passage tokens", "pairs_per_step": nqr * 100},
            "pairs_per_sec": round(nqr * 100 / (ms * 1e-3), 1), "cross_encoder_ms": round(ms_ce, 3),
+           "dense_top100": {"ms_per_step": round(ms_dense, 4), "queries_per_sec": round(nqr / (ms_dense * 1e-3), 1),
+                            "roofline": {"kernel": "scan_topk_kernel<D=384,WQ=2,CAP=128> as a threshold ladder over growing row ranges (exact fp32, k = 100) + merge_wg_kernel",
+                                         "bound": "hbm", "achieved": round(dense_bytes / (kms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                         "frac": round(dense_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "kernel_ms": round(kms, 4),
+                                         "algorithmic_bytes": dense_bytes, "launch": geom}},
            "roofline": encoder_roofline(fl / (ms_ce * 1e-3) / 1e12)}
     if not args.no_cpu_baseline:
         leg["cpu_baseline"] = cpu_encoder_baseline(head=True)
@@ -358,7 +558,8 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c1,c2,embed,rerank")
+    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c1,mmr,c2,embed,index,rerank")
+    ap.add_argument("--index-texts", type=int, default=131072, help="texts pushed through add_documents by the `index` leg (BASELINE config 3 names 1M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-identity-check", action="store_true",
                     help="skip the post-run comparison with the exact fp32 scan (keeps rocprofv3 per-kernel statistics to the timed launches)")
@@ -412,7 +613,7 @@ def main():
     if world > 1:
         dist.broadcast(q, 0)
         dist.broadcast(planted, 0)
-    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c1,c2,embed,rerank".split(",") if args.legs == "all" else args.legs.split(","))
+    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c1,mmr,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
     sample_host = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample_host = shard[:min(n_local, 2_000_000)].cpu().numpy()
@@ -535,12 +736,20 @@ def main():
                 leg["cpu_baseline"] = cpu_single
             elif leg["unit"] == "queries/sec" and "cpu_baseline" not in leg and leg["config"]["workload"].startswith(f"{N}x"):
                 leg["cpu_baseline"] = cpu
+            elif leg["name"].startswith("C2 ") and "cpu_baseline" not in leg:
+                n2 = 1_000_000               # the same measured sample, scaled linearly to config 2's 1M rows instead of the headline's
+                leg["cpu_baseline"] = dict(cpu, value=round(cpu["value"] * N / n2, 3),
+                                           sample=cpu["sample"].replace(f"scaled linearly to {N} rows", f"scaled linearly to {n2} rows"))
     index.close()
     torch.cuda.empty_cache()
     if "c1" in legs:
         secondary.append(leg_c1(args))
+    if "mmr" in legs:
+        secondary.append(leg_mmr(args))
     if "embed" in legs:
         secondary.append(leg_embed(args))
+    if "index" in legs:
+        secondary.append(leg_index(args))
     if "rerank" in legs and x1m is not None:
         secondary.append(leg_rerank(args, x1m))
 

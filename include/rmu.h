@@ -47,6 +47,10 @@ extern "C" {
 #define RMU_OPT_SCREEN 1    /* 1 (default): searches may take the fp16 screening path; 0: always the exact fp32 scan.
                              * Results are identical either way (bench.py times both through this switch). */
 
+#define RMU_OPT_SCREEN_MIN_NQ 2 /* n > 0: take the screening path for every batch of >= n queries whatever the corpus size (by
+                             * default small batches over small corpora take the exact scan, which is faster there); 0: default.
+                             * Results are identical either way (the tests force the path through this switch). */
+
 #define RMU_MAX_K 112       /* largest k the fused scan keeps in LDS */
 #define RMU_MAX_DIM 768
 

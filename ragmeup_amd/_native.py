@@ -13,6 +13,7 @@ RMU_OK = 0
 METRIC_IP, METRIC_COSINE, METRIC_L2SQ = 0, 1, 2
 F_Q_DEVICE, F_OUT_DEVICE, F_SMALLER_BETTER = 1, 2, 4
 OPT_SCREEN = 1
+OPT_SCREEN_MIN_NQ = 2
 COMM_ID_BYTES = 128
 MAX_K = 112
 MAX_DIM = 768

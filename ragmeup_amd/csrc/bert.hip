@@ -832,6 +832,378 @@ __global__ __launch_bounds__(256) void k_ffn_fused(const bf16* __restrict__ h1, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_ffn2 -- the fused FFN block, second form (round 3): out = LN2( GELU(h1 . W1^T + b1) . W2^T + b2 + h1 ), optionally with
+// h1 = LN1(y) computed in the prologue (the out-proj GEMM's pre-LN sum comes in, no k_layernorm launch and no h1 round trip).
+//
+// Same ownership as k_ffn_fused (4 waves = 4 SIMDs, wave w keeps tokens [32w, +32) as B fragments and all 384 FFN2 accumulators
+// for the whole kernel, only weights stream through LDS), rebuilt around what bounded that kernel: a lone wave per SIMD issues at
+// most ~one instruction per 4 cycles, i.e. <= ~5 besides the MFMA in each 32-cycle MFMA slot (MI355X_MICROARCH.md), and the old
+// loop carried 7.9 (ISA count per 96-MFMA chunk: 369 VALU + 32 accvgpr reads, 104 ds_read, 102 s_waitcnt, ~100 SALU, 26 s_nop,
+// 24 DMA) with the activation lumped in 40-instruction blocks between two MFMAs.  Here:
+//   * GEMM2 runs ONE CHUNK BEHIND GEMM1: iteration c does GEMM1 of chunk c (48 MFMAs) and GEMM2 of chunk c-1 (48 MFMAs); the
+//     activation of chunk c-1 (8 groups of 4 values per lane) is cut into 7 stages of 2-4 instructions, one stage behind each
+//     MFMA of GEMM1(c) (and of the first GEMM2 slab for the last two groups): no MFMA ever waits for an activation, and no
+//     gap carries more than stage + fragment read + DMA;
+//   * GELU with the constants folded: gelu(v) = v (0.5 + vc Q(vc^2)), vc = clamp(v, +-3 sqrt 2), Q = the degree-7 erf fit
+//     rescaled (same 4.7e-5 |v| error as gelu_poly): 1 clamp + 10 packable ops per value instead of 2 + 13;
+//   * ring of 5 slots = the 5 slabs of a chunk, so every LDS address in the loop is base register + literal offset (no VALU),
+//     and the slab base pointers advance on the scalar unit once per slab;
+//   * fragment reads four ahead with ONE counted wait per two MFMAs.
+// Stream per iteration c: slots 0-2 = W1 rows [64 c, +64) x k [128 i, +128); slots 3-4 = W2p rows [0, 384) x k [64 (c-1) + 32 t,
+// +32).  Iteration 0 has no GEMM2, iteration NCH no GEMM1 (their slabs are loaded and ignored: 5 of 125 barriers).
+// ------------------------------------------------------------------------------------------------------------
+namespace ffn2 {
+constexpr int TOK = 128, CH = 64, NCH = FF / CH;
+constexpr int SLOT = 24 * 1024, NSLOT = 5;
+constexpr int TSTR = H * 2 + 16;
+constexpr int RING = NSLOT * SLOT;
+constexpr int B1_OFF = RING;
+constexpr int LDS_BYTES = B1_OFF + FF * 4;
+static_assert(RING >= TOK * TSTR && LDS_BYTES <= 160 * 1024, "LDS");
+// DMA instructions per wave that may still be in flight when slab i of an iteration must have landed (issue order per
+// iteration: S4 during slab 0; S0', S1', S2' of the next iteration during slab 3; S3' during slab 4; W1 slab = 4, W2 slab = 6)
+__host__ __device__ constexpr int wait_n(int i) { return i == 0 ? 14 : i == 1 ? 16 : i == 2 ? 12 : i == 3 ? 6 : 12; }
+// folded GELU polynomial Q(u), u = vc^2 (highest degree first)
+#define RMU_GQ0 -1.120145568e-09f
+#define RMU_GQ1 9.479557069e-08f
+#define RMU_GQ2 -3.475820744e-06f
+#define RMU_GQ3 7.333383917e-05f
+#define RMU_GQ4 -1.002580095e-03f
+#define RMU_GQ5 9.521000741e-03f
+#define RMU_GQ6 -6.597861542e-02f
+#define RMU_GQ7 3.987713536e-01f
+#define RMU_GCLAMP 4.2426406871f
+}  // namespace ffn2
+
+template <bool LN_IN, int GV, int PF>   // LN_IN: x is the pre-LayerNorm sum y, h1 = LN1(y) is formed here; GV: 0 packed / 1 scalar polynomial;
+                                        // PF: weight fragments read ahead of the MFMA that eats them (4 or 8)
+__global__ __launch_bounds__(256) void k_ffn2(const bf16* __restrict__ x, const bf16* __restrict__ W1, const float* __restrict__ b1,
+                                              const bf16* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ g,
+                                              const float* __restrict__ bta, float eps, bf16* __restrict__ out,
+                                              const int* __restrict__ cu, int batch, const float* __restrict__ g1,
+                                              const float* __restrict__ bta1) {
+    using namespace ffn2;
+    using ffn::static_for; using ffn::ds_read16; using ffn::sgpr_ptr;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const int M = cu[batch];
+    const int m0 = blockIdx.x * TOK;
+    if (m0 >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31, hh = lane >> 5;
+    char* ring = gsm;
+    float* b1s = (float*)(gsm + B1_OFF);
+
+    // ---- token rows as B fragments (k-step ks = k [16 ks, +16), lane half hh owns 8 of them); b1 into LDS.  All ordinary
+    // loads are issued and waited for BEFORE the first LDS-DMA. -------------------------------------------------------------
+    bf16x8 hf[24];
+    {
+        const int tok = min(m0 + 32 * w + r31, M - 1);
+        const bf16* row = x + (int64_t)tok * H + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) hf[ks] = *(const bf16x8*)(row + ks * 16);
+    }
+    for (int i = threadIdx.x; i < FF; i += 256) b1s[i] = b1[i];
+    if (LN_IN) {
+        // h1 = bf16(LN1(y)): the lane holds 192 of its token's 384 values, lane ^ 32 the others (same rounding point as the
+        // k_layernorm launch this replaces: statistics in fp32 over the bf16 y, two passes)
+        float sm = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm += bf2f(hf[ks][e]);
+        sm += __shfl_xor(sm, 32);
+        const float mu = sm * (1.0f / H);
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = bf2f(hf[ks][e]) - mu; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 32);
+        const float rs = rsqrtf(q * (1.0f / H) + eps);
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) {
+            const f32x4 ga = *(const f32x4*)(g1 + ks * 16 + hh * 8), gb = *(const f32x4*)(g1 + ks * 16 + hh * 8 + 4);
+            const f32x4 ba = *(const f32x4*)(bta1 + ks * 16 + hh * 8), bb = *(const f32x4*)(bta1 + ks * 16 + hh * 8 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (bf16)((bf2f(hf[ks][e]) - mu) * rs * ga[e] + ba[e]);
+                o[4 + e] = (bf16)((bf2f(hf[ks][4 + e]) - mu) * rs * gb[e] + bb[e]);
+            }
+            hf[ks] = o;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- slab stream -------------------------------------------------------------------------------------------------------
+    // per-lane byte offsets inside a slab's source (LDS unit f = (it * 4 + w) * 64 + lane: W1 row f >> 4, W2 row f >> 2; the
+    // swizzle term does not depend on `it`, so instruction `it` = offset of it 0 + a scalar stride: 16 W1 rows / 64 W2 rows)
+    u32 w1off0, w2off0;
+    {
+        const int f = w * 64 + lane;
+        const int row1 = f >> 4, p1 = f & 15;
+        w1off0 = (u32)((row1 * H + ((p1 ^ (row1 & 15)) * 8)) * 2);
+        const int row2 = f >> 2, p2 = f & 3;
+        w2off0 = (u32)((row2 * FF + ((p2 ^ ((row2 >> 2) & 3)) * 8)) * 2);
+    }
+    // DMA instruction `it` of slab i (compile time) of iteration ci (run time; chunk clamped), into slot i.  The weight
+    // matrices stay the scalar base of every load (the kernel-argument SGPR pair); a chunk / slab / instruction is a 32-bit
+    // offset: chunk part on the scalar unit, one v_add_u32 into the lane offset per instruction (a 64-bit scalar base per
+    // instruction cost s_add_u32 + s_addc_u32 + a VGPR copy + wait states behind the SGPR write).
+    auto issue_part = [&](int ci, auto ic, int it) {
+        constexpr int i = decltype(ic)::value;
+        char* slot = ring + i * SLOT;
+        if constexpr (i < 3) {
+            const u32 cc = (u32)(ci < NCH ? ci : NCH - 1);
+            const u32 o = w1off0 + (cc * (u32)(CH * H * 2) + (u32)(i * 256 + it * (16 * H * 2)));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W1 + o),
+                                             (__attribute__((address_space(3))) void*)(slot + (it * 4 + w) * 1024), 16, 0, 0);
+        } else {
+            const u32 cc = (u32)(ci < 1 ? 0 : (ci > NCH ? NCH - 1 : ci - 1));
+            const u32 o = w2off0 + (cc * (u32)(CH * 2) + (u32)((i - 3) * 64 + it * (64 * FF * 2)));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W2 + o),
+                                             (__attribute__((address_space(3))) void*)(slot + (it * 4 + w) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc2[12];
+#pragma unroll
+    for (int o = 0; o < 12; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[o][r] = 0.f;
+
+    // fragment addressing: W1 slab image [64 rows][16 units], unit u of row r at u ^ (r & 15); W2 slab image [384 rows][4 units],
+    // unit u ^ ((r >> 2) & 3).  Every address = one of these registers + a literal (slot, tile).
+    const u32 ring_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+    u32 a1[8], a2[2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) a1[ks] = ring_addr + (u32)(r31 * 256 + (((2 * ks + hh) ^ (r31 & 15)) * 16));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) a2[s2] = ring_addr + (u32)(3 * SLOT) + (u32)(r31 * 64 + (((2 * s2 + hh) ^ ((r31 >> 2) & 3)) * 16));
+    bf16x8 fq[PF];
+#pragma unroll
+    for (int m = 0; m < PF; ++m) fq[m] = bf16x8{};
+
+    f32x16 acc1[2];                                 // GEMM1 accumulators of the chunk in flight [feature tile of 32]
+    f32x16 prv[2];                                  // ... of the chunk before it (pre-activation, bias included): GELU source
+    u32x4 pfu[2][2];                                // [feature tile][k-step]: B fragments of GEMM2 (chunk c - 1)
+    f32x4 gc = {}, gu = {}, gp = {};                // the activation group in flight: clamped values, squares, polynomial
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prv[t][r] = 0.f;   // iteration 0 activates zeros: its GEMM2 adds W2 . 0
+
+    // GEMM1 accumulators start from the bias: register 4 q + e of lane half hh <-> feature 32 ft + 8 q + 4 hh + e
+    auto load_bias = [&](int cc) {
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4*)(b1s + cc * CH + ft * 32 + q * 8 + hh * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[ft][4 * q + e] = bv[e];
+            }
+    };
+
+    // one stage (of six) of the activation of group gi = 4 t + q of the finished chunk: values prv[t][4 q ..], result -> pfu
+    auto gelu_stage = [&](int gi, int st) {
+        const int t = gi >> 2, q = gi & 3;
+        auto sp = [](float c) { return f32x4{c, c, c, c}; };
+        auto fma4 = [&](f32x4 a, f32x4 b, f32x4 c) {
+            if (GV == 0) return __builtin_elementwise_fma(a, b, c);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[e]) : "v"(a[e]), "v"(b[e]), "v"(c[e]));
+            return r;
+        };
+        switch (st) {
+            case 0:
+                asm volatile("" : "+v"(gc));        // (program-order anchors: a stage stays in the MFMA gap it was given)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gc[e] = __builtin_amdgcn_fmed3f(prv[t][4 * q + e], -RMU_GCLAMP, RMU_GCLAMP);
+                asm volatile("" : "+v"(gc));
+                break;
+            case 1:
+                asm volatile("" : "+v"(gc));
+                gu = gc * gc;
+                gp = fma4(sp(RMU_GQ0), gu, sp(RMU_GQ1));
+                asm volatile("" : "+v"(gu), "+v"(gp));
+                break;
+            case 2:
+                asm volatile("" : "+v"(gp));
+                gp = fma4(gp, gu, sp(RMU_GQ2));
+                gp = fma4(gp, gu, sp(RMU_GQ3));
+                asm volatile("" : "+v"(gp));
+                break;
+            case 3:
+                asm volatile("" : "+v"(gp));
+                gp = fma4(gp, gu, sp(RMU_GQ4));
+                gp = fma4(gp, gu, sp(RMU_GQ5));
+                asm volatile("" : "+v"(gp));
+                break;
+            case 4:
+                asm volatile("" : "+v"(gp));
+                gp = fma4(gp, gu, sp(RMU_GQ6));
+                gp = fma4(gp, gu, sp(RMU_GQ7));
+                asm volatile("" : "+v"(gp));
+                break;
+            default: {
+                asm volatile("" : "+v"(gp));
+                gp = fma4(gc, gp, sp(0.5f));
+                const f32x4 pv = {prv[t][4 * q], prv[t][4 * q + 1], prv[t][4 * q + 2], prv[t][4 * q + 3]};
+                gp = pv * gp;
+                bf16x2 lo, hi;
+                lo[0] = (bf16)gp[0]; lo[1] = (bf16)gp[1]; hi[0] = (bf16)gp[2]; hi[1] = (bf16)gp[3];
+                u32 d0 = __builtin_bit_cast(u32, lo), d1 = __builtin_bit_cast(u32, hi);
+                asm volatile("" : "+v"(d0), "+v"(d1));
+                pfu[t][q >> 1][(q & 1) * 2] = d0;
+                pfu[t][q >> 1][(q & 1) * 2 + 1] = d1;
+            }
+        }
+    };
+
+    // prologue of the stream: slabs 0 .. 3 of iteration 0
+    static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int ni = i < 3 ? 4 : 6;
+#pragma unroll
+        for (int it = 0; it < ni; ++it) issue_part(0, ic, it);
+    });
+    load_bias(0);
+
+    // Iteration c: GEMM1 of chunk min(c, NCH - 1) (the last one recomputes a chunk whose result nobody reads), activation of
+    // chunk c - 1, GEMM2 of chunk c - 1 -- ONE body for all NCH + 1 iterations (two uniform variants of this loop made hipcc
+    // shuffle the 192 FFN2 accumulators between register ranges and spill them; 96 idle MFMAs of 2400 are the cheaper price).
+    for (int c = 0; c <= NCH; ++c) {
+        static_for<5>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(wait_n(i)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if constexpr (i == 0) asm volatile("" : "+a"(acc1[0]), "+a"(acc1[1]));   // the bias loads have landed (the wait above): no compiler wait later
+            if constexpr (i < 3) {
+                // ---- GEMM1 slab i: 8 k-steps x 2 feature tiles, n = 2 ks + ft; behind MFMA n: activation stage 16 i + n of chunk c - 1
+                static_for<PF>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    ds_read16<i * SLOT + (n & 1) * 8192>(fq[n], a1[n >> 1]);
+                });
+                static_for<16>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    // fragments n, n + 1 have landed once at most the PF - 2 younger reads (fewer near the slab's end) are in flight
+                    if constexpr (n % 2 == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"(n + PF <= 16 ? PF - 2 : 16 - 2 - n));
+                    acc1[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], hf[i * 8 + (n >> 1)], acc1[n & 1], 0, 0, 0);
+                    if constexpr (n + PF < 16) ds_read16<i * SLOT + ((n + PF) & 1) * 8192>(fq[n % PF], a1[(n + PF) >> 1]);
+                    else asm volatile("" : "+v"(fq[n % PF]));
+                    if constexpr (i == 0 && n % 2 == 1 && n / 2 < 6) issue_part(c, std::integral_constant<int, 4>{}, n / 2);
+                    gelu_stage((16 * i + n) / 6, (16 * i + n) % 6);
+                });
+            } else {
+                // ---- GEMM2 over feature tile t of chunk c - 1: 2 k-steps x 12 output tiles, n = 12 s + ot.  Slab 3 also moves the
+                // finished GEMM1 accumulators to `prv` (two values per step) and issues the next iteration's W1 slabs; slab 4 the
+                // next iteration's first W2 slab and, behind its last MFMA, the next chunk's bias. --------------------------------
+                constexpr int t = i - 3;
+                static_for<PF>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    ds_read16<t * SLOT + n * 2048>(fq[n], a2[0]);
+                });
+                static_for<24>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    if constexpr (n % 2 == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"(n + PF <= 24 ? PF - 2 : 24 - 2 - n));
+                    acc2[n % 12] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], __builtin_bit_cast(bf16x8, pfu[t][n / 12]), acc2[n % 12], 0, 0, 0);
+                    if constexpr (n + PF < 24) ds_read16<t * SLOT + ((n + PF) % 12) * 2048>(fq[n % PF], a2[(n + PF) / 12]);
+                    else asm volatile("" : "+v"(fq[n % PF]));
+                    if constexpr (t == 0) {
+                        if constexpr (n % 2 == 0) {          // S0', S1', S2' of iteration c + 1: 12 instructions over 24 steps
+                            constexpr int k = n / 2;
+                            if constexpr (k < 4) issue_part(c + 1, std::integral_constant<int, 0>{}, k);
+                            else if constexpr (k < 8) issue_part(c + 1, std::integral_constant<int, 1>{}, k - 4);
+                            else issue_part(c + 1, std::integral_constant<int, 2>{}, k - 8);
+                        }
+                        if constexpr (n >= 4 && n < 20) {    // (the last GEMM1 MFMAs have retired by step 4)
+                            constexpr int e0 = 2 * (n - 4);
+                            float m0v = acc1[e0 >> 4][e0 & 15], m1v = acc1[(e0 + 1) >> 4][(e0 + 1) & 15];
+                            asm volatile("" : "+v"(m0v), "+v"(m1v));
+                            prv[e0 >> 4][e0 & 15] = m0v;
+                            prv[(e0 + 1) >> 4][(e0 + 1) & 15] = m1v;
+                        }
+                    } else {
+                        if constexpr (n % 4 == 0) issue_part(c + 1, std::integral_constant<int, 3>{}, n / 4);
+                    }
+                });
+                if constexpr (t == 1) load_bias(c + 1 < NCH ? c + 1 : NCH - 1);
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the tail reloads: the ring becomes the pre-LN tile
+    __syncthreads();
+    char* tile = gsm;
+    {
+        // acc2[ot][4 q + e] = output feature n = 32 ot + 8 q + 4 hh + e of token 32 w + r31; the residual h1[token][n] sits in
+        // hf[2 ot + (q >> 1)] of this lane ((q & 1) == hh) or of lane ^ 32 (see k_ffn_fused).  y = bf16(bf16(acc + b2) + resid).
+        const int tr = 32 * w + r31;
+        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int ot = 0; ot < 12; ++ot)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const u32x4 hv = __builtin_bit_cast(u32x4, hf[2 * ot + qq]);
+                const u32x2 own = hh ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]};
+                const u32x2 oth = hh ? u32x2{hv[0], hv[1]} : u32x2{hv[2], hv[3]};
+                u32x2 rcv;
+                rcv[0] = (u32)__shfl_xor((int)oth[0], 32);
+                rcv[1] = (u32)__shfl_xor((int)oth[1], 32);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int q = 2 * qq + qb;
+                    const u32x2 rs2 = (qb == hh) ? own : rcv;
+                    const bf16x4 res = __builtin_bit_cast(bf16x4, rs2);
+                    const int n = ot * 32 + q * 8 + hh * 4;
+                    const f32x4 bv = *(const f32x4*)(b2 + n);
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16)(bf2f((bf16)(acc2[ot][4 * q + e] + bv[e])) + bf2f(res[e]));
+                    *(bf16x4*)(tile + tr * TSTR + n * 2) = v;
+                }
+            }
+    }
+    __syncthreads();
+    {
+        const bool act = lane < 48;
+        const int c0 = (act ? lane : 0) * 8;
+        float gg[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gg[i] = g[c0 + i]; bb[i] = bta[c0 + i]; }
+        for (int r = 0; r < 32; ++r) {
+            const int tr = w * 32 + r;
+            const int m = m0 + tr;
+            if (m >= M) break;
+            const bf16x8 yv = *(const bf16x8*)(tile + tr * TSTR + c0 * 2);
+            float v[8];
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] = act ? bf2f(yv[i]) : 0.f; sm += v[i]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            const float mu = sm * (1.0f / H);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = act ? v[i] - mu : 0.f; q = fmaf(d, d, q); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rs = rsqrtf(q * (1.0f / H) + eps);
+            bf16x8 ov;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] = (bf16)((v[i] - mu) * rs * gg[i] + bb[i]);
+            if (act) *(bf16x8*)(out + (int64_t)m * H + c0) = ov;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_gemm3 -- persistent big-tile GEMM for the encoder's shapes: out[m, n] = epi( sum_k A[m, k] W[n, k] + bias[n] ).
 //
 // What the cycle counters of k_gemm / k_ffn_fused and tools/ubench/fill.hip say about a CU's memory pipeline (all 256 CUs busy,
@@ -1292,6 +1664,196 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_attn3 -- attention, third form (round 3; default).  k_attention above is VALU-bound: 38 VALU per MFMA = ~19 wave
+// instructions per score (per-element masks, a v_sub and a v_add per score, 4-lane shuffles, a branch skeleton per key tile),
+// 0.073 of the bf16 roof.  Here the matrix pipe does everything that is linear and the VALU keeps only max, exp2 and the bf16
+// pack (~3 instructions per score):
+//   * S^T = K . Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q straight from global memory): lane (query =
+//     lane & 31, half h) holds ITS query's scores against 16 keys of every 32-key tile -- row max / sum are chains over the
+//     lane's own registers plus ONE exchange with lane ^ 32;
+//   * TWO passes over the key tiles instead of a score strip in registers: pass 1 only takes the row maximum; pass 2 recomputes
+//     S^T with the accumulator INITIALISED to -max (the C operand is a separate 16-register tuple), so the MFMA output is
+//     already s - max and goes straight into v_exp_f32 -- no subtraction, and padding keys are masked by the same operand (the
+//     last tile's C tuple carries -inf in the padded key slots) -- no compare / select per score;
+//   * O^T = V^T . P^T: the accumulator layout of S^T (registers 8 s .. 8 s + 7 <-> keys {4h+e, 8+4h+e} of the 16-key block s) IS
+//     a k-permuted B fragment, so P never leaves the registers; V^T is staged with the same key permutation;
+//   * row sums with v_dot2_f32_bf16 on the PACKED bf16 pairs against (1, 1): half the adds, and the sum is taken over exactly
+//     the rounded probabilities the P.V product uses;
+//   * ~120 registers per wave: four waves per SIMD hide the LDS / exp latencies (k_attention holds the whole strip: one).
+// Workgroup = (sequence, head), 4 waves; wave w takes the 32-query tiles w, w + 4, ...; the heads of a sequence share an XCD.
+// KT = key tiles of 32 (L <= 32 KT).  What bounds it (measured, 8192 sequences of ~128 tokens, 0.90 ms per layer at four waves
+// per SIMD, 1.13 at three): with the staging AND all but one key tile removed 0.45 ms remain -- 98k workgroups each paying a
+// cold round trip for 64-byte row pieces, i.e. latency x occupancy, not arithmetic.  One workgroup per SEQUENCE walking its 12
+// heads (every second 64-byte piece an L2 hit, one launch per sequence) measured SLOWER, 1.15 ms: the heads then wait for each
+// other's loads in series.
+// ------------------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch, bf16* __restrict__ ctx) {
+    constexpr int LP = KT * 32;
+    constexpr int VSTR = LP * 2 + 16;              // bytes per V^T row (dim): +16 spreads the 32 dims over the banks
+    constexpr int KBYTES = LP * 64;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    char* ks = gsm;                                // [LP keys][4 units of 16 B], unit u of key r at u ^ ((r >> 2) & 3)
+    char* vt = gsm + KBYTES;                       // [32 dims][VSTR]: V^T, keys in GEMM-slot order inside every 16-block
+    // block -> (sequence, head): the 12 heads of a sequence run on ONE XCD (block x lands on XCD x % 8), so the 128-byte lines
+    // that hold two neighbouring heads' 64-byte K / V / Q pieces are fetched from HBM once
+    int b, head;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        b = (idx / NH) * 8 + xcd;
+        head = idx % NH;
+    }
+    if (b >= batch) return;
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    if (L <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c31 = lane & 31, hh = lane >> 5;
+    const int nkt = (L + 31) >> 5;                 // key tiles (= query tiles) in use
+    const int64_t rs = 3 * H;                      // qkv row stride (elements)
+    // accumulator init of the LAST key tile: 0 for real keys, -inf for the padding (register r <-> key 32 (nkt-1) + 8 (r>>2) + 4 hh + (r&3))
+    f32x16 maskc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) maskc[r] = ((nkt - 1) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3) < L) ? 0.f : -INFINITY;
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    const bf16* base = qkv + (int64_t)t0 * rs + head * DH;
+
+    // Q fragments of this wave's first tile (B operand: query c31, dims 16 s + 8 hh ..): in flight across the staging
+    bf16x8 qf[2] = {bf16x8{}, bf16x8{}};
+    if (w < nkt) {
+        const int q = min(w * 32 + c31, L - 1);
+        qf[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
+        qf[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
+    }
+    // ---- stage K (row-major, swizzled) and V^T (transposed, key-permuted); rows [L, 32 nkt) are zero ------------------------
+    for (int p0 = 0; p0 < nkt * 128; p0 += 512) {  // 2 x 256 pieces of 16 B per iteration: both loads in flight
+        uint4 kv[2], vv[2];
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+            const int p = p0 + u2 * 256 + tid, r = p >> 2, u = p & 3;
+            kv[u2] = uint4{0u, 0u, 0u, 0u};
+            vv[u2] = uint4{0u, 0u, 0u, 0u};
+            if (r < L) {
+                kv[u2] = *(const uint4*)(base + (int64_t)r * rs + H + u * 8);
+                vv[u2] = *(const uint4*)(base + (int64_t)r * rs + 2 * H + u * 8);
+            }
+        }
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+            const int p = p0 + u2 * 256 + tid, r = p >> 2, u = p & 3;
+            if (p < nkt * 128) {
+                *(uint4*)(ks + r * 64 + ((u ^ ((r >> 2) & 3)) * 16)) = kv[u2];
+                // key r -> slot inside its 16-block: keys 0-3 -> 0-3, 4-7 -> 8-11, 8-11 -> 4-7, 12-15 -> 12-15
+                const int r16 = r & 15, slot = (r & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
+                const unsigned short* ve = (const unsigned short*)&vv[u2];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *(unsigned short*)(vt + (u * 8 + e) * VSTR + slot * 2) = ve[e];
+            }
+        }
+    }
+    __syncthreads();
+
+    // K fragment (key tile kt, k-step s = dims 16 s ..): lane (key c31, half hh) reads unit 2 s + hh of key 32 kt + c31
+    const u32 kaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ks + (u32)(c31 * 64);
+    const u32 ksw = (u32)((c31 >> 2) & 3);
+    auto kfrag = [&](int kt, int s2) -> bf16x8 {
+        return *(const bf16x8*)((const __attribute__((address_space(3))) char*)(uintptr_t)(kaddr + (u32)(kt * 2048) + (((u32)(2 * s2 + hh) ^ ksw) * 16)));
+    };
+
+    for (int qt = w; qt < nkt; qt += 4) {
+        bf16x8 qn[2] = {qf[0], qf[1]};
+        if (qt + 4 < nkt) {                         // next tile's Q in flight while this tile computes
+            const int q = min((qt + 4) * 32 + c31, L - 1);
+            qn[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
+            qn[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
+        }
+        // ---- pass 1: row maximum (log2 domain: log2(e) / sqrt(d) is folded into W_q).  Run-time loops over the key tiles (the
+        // last one, whose accumulator starts from the padding mask, peeled): unrolled over KT hipcc kept every K fragment of
+        // pass 1 alive for pass 2 (208 registers at KT = 8: two waves per SIMD instead of four). ---------------------------------
+        float mx = -INFINITY;
+        auto pass1 = [&](int kt, const f32x16& c0) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 0), qf[0], c0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 1), qf[1], acc, 0, 0, 0);
+            float m3 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r + 1 < 16; r += 2) m3 = fmaxf(fmaxf(m3, acc[r]), acc[r + 1]);
+            mx = fmaxf(mx, fmaxf(m3, acc[15]));
+        };
+#pragma unroll 1
+        for (int kt = 0; kt < nkt - 1; ++kt) pass1(kt, zero16);
+        pass1(nkt - 1, maskc);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));        // the other half of this query's keys (every query has >= 1 real key: finite)
+        f32x16 negm, negmm;                        // C operands of pass 2: -max, and -max with the padding mask
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { negm[r] = -mx; negmm[r] = maskc[r] - mx; }
+        // ---- pass 2: P = exp2(S - max) straight off the MFMA, O^T += V^T . P^T ---------------------------------------------------
+        f32x16 ot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+        float sum = 0.f;
+        const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+        auto pass2 = [&](int kt, const f32x16& c0) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 0), qf[0], c0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 1), qf[1], acc, 0, 0, 0);
+            u32x4 pu[2];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                bf16x2 pb;
+                pb[0] = (bf16)__builtin_amdgcn_exp2f(acc[r]);           // exp2(-inf) = 0 for the padding
+                pb[1] = (bf16)__builtin_amdgcn_exp2f(acc[r + 1]);
+                sum = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, sum, false);
+                pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
+            }
+            // registers 8 s .. 8 s + 7 of the tile = the B fragment of k-step s (keys 32 kt + 16 s + {4hh+e, 8+4hh+e})
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 vf = *(const bf16x8*)(vt + c31 * VSTR + (kt * 32 + s2 * 16 + hh * 8) * 2);
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pu[s2]), ot, 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int kt = 0; kt < nkt - 1; ++kt) pass2(kt, negm);
+        pass2(nkt - 1, negmm);
+        sum += __shfl_xor(sum, 32);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        // ot[4 g + e] = dim 8 g + 4 hh + e of query c31.  Lane halves trade two 8-byte pieces so that each stores 16 consecutive
+        // dims: half 0 keeps g = 0, 1 (dims 0-3, 8-11) and receives dims 4-7, 12-15; half 1 keeps g = 2, 3 and receives 16-19, 24-27.
+        {
+            union { bf16x4 v; int i[2]; } pc[4], rcv[2];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pc[g4].v[e] = (bf16)(ot[4 * g4 + e] * inv);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int snd0 = hh ? pc[j].i[0] : pc[2 + j].i[0], snd1 = hh ? pc[j].i[1] : pc[2 + j].i[1];
+                rcv[j].i[0] = __shfl_xor(snd0, 32);
+                rcv[j].i[1] = __shfl_xor(snd1, 32);
+            }
+            const int q = qt * 32 + c31;
+            if (q < L) {
+                bf16x8 o0, o1;                     // dims [16 hh, +8) and [16 hh + 8, +8)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = hh ? rcv[0].v[e] : pc[0].v[e];
+                    o0[4 + e] = hh ? pc[2].v[e] : rcv[0].v[e];
+                    o1[e] = hh ? rcv[1].v[e] : pc[1].v[e];
+                    o1[4 + e] = hh ? pc[3].v[e] : rcv[1].v[e];
+                }
+                bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 16;
+                *(bf16x8*)dst = o0;
+                *(bf16x8*)(dst + 8) = o1;
+            }
+        }
+        qf[0] = qn[0];
+        qf[1] = qn[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // pooling heads
 // ------------------------------------------------------------------------------------------------------------
 // sentence-transformers Pooling + Normalize: one wave per sequence.  pool_cls = 0: masked mean over the sequence's tokens
@@ -1619,6 +2181,23 @@ static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16
                        (unsigned long long*)nullptr);
 }
 
+template <bool LN_IN, int GV, int PF>
+static void launch_ffn2_t(const bf16* x, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_ffn2<LN_IN, GV, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn2::LDS_BYTES);
+    (void)attr_rc;
+    const dim3 grid((unsigned)((m_cap + ffn2::TOK - 1) / ffn2::TOK));
+    hipLaunchKernelGGL((k_ffn2<LN_IN, GV, PF>), grid, dim3(256), ffn2::LDS_BYTES, s, x, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
+                       L.ln1g, L.ln1b);
+}
+// x = h1 (ln_in false) or the pre-LN out-proj sum y (ln_in true: LN1 happens in the kernel's prologue)
+static void launch_ffn2(const bf16* x, bool ln_in, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
+    static const int gv = getenv("RMU_FFN_GELU") ? atoi(getenv("RMU_FFN_GELU")) : 0;   // 1: scalar v_fma_f32 polynomial (A/B measurement)
+    static const int pf = getenv("RMU_FFN_PF") ? atoi(getenv("RMU_FFN_PF")) : 4;       // 8: eight weight fragments read ahead (A/B measurement)
+    if (pf == 8 && ln_in && !gv) return launch_ffn2_t<true, 0, 8>(x, L, eps, out, cu, batch, m_cap, s);
+    if (ln_in) { if (gv) launch_ffn2_t<true, 1, 4>(x, L, eps, out, cu, batch, m_cap, s); else launch_ffn2_t<true, 0, 4>(x, L, eps, out, cu, batch, m_cap, s); }
+    else { if (gv) launch_ffn2_t<false, 1, 4>(x, L, eps, out, cu, batch, m_cap, s); else launch_ffn2_t<false, 0, 4>(x, L, eps, out, cu, batch, m_cap, s); }
+}
+
 template <int EPI>
 static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu, int batch,
                          int N, int K, hipStream_t s) {
@@ -1645,6 +2224,15 @@ static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const 
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm3<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
     (void)attr_rc;
     hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, 0);
+}
+
+template <int KT>
+static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
+    constexpr int lds = KT * 32 * 64 + 32 * (KT * 32 * 2 + 16);
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_attn3<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)attr_rc;
+    const dim3 grid((unsigned)((batch + 7) / 8 * 8 * NH));
+    hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx);
 }
 
 template <int MAXT>
@@ -1678,16 +2266,35 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
                        (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
                        m->cfg.type_vocab, m->h);
     const dim3 ln_grid((unsigned)((cap + 4 * LN_ROWS - 1) / (4 * LN_ROWS)));
-    const dim3 at_grid(NH, (unsigned)batch);   // one workgroup per (head, sequence)
+    const dim3 at_grid(NH, (unsigned)batch);   // k_attention: one workgroup per (head, sequence); k_attn3: one per sequence
     for (const BertLayer& L : m->layers) {
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
         if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
-        if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
+        static const int attn_v = getenv("RMU_ATTN_V") ? atoi(getenv("RMU_ATTN_V")) : 3;   // 1: the round-1/2 kernel k_attention (A/B)
+        if (attn_v == 3) {
+            if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, s);
+            else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, s);
+            else launch_attn3<16>(batch, m->qkv, m->cu, m->ctx, s);
+        } else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
         if (g3_mask & 2) launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
         else launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
+        // The fused kernels give each 128-token tile to ONE workgroup, which then streams all 2.36 MB of FFN weights through one
+        // CU (~100 us per layer whatever the batch): below ~128 tiles most CUs would idle and the GEMM pair, whose feature tiles
+        // spread over the chip, is faster (measured: 8k tokens 0.82 vs 0.95 ms per forward, one 16-token query 0.44 vs 0.63 ms;
+        // 32k tokens 1.70 vs 1.45).  RMU_FUSED_FFN=0 / 1 forces either path.
+        static const int fused_env = getenv("RMU_FUSED_FFN") ? atoi(getenv("RMU_FUSED_FFN")) : -1;
+        const bool fused_ffn = !(g3_mask & 4) && (fused_env < 0 ? cap > 16384 : fused_env != 0);
+        // k_ffn2 (default) also takes LayerNorm 1 into its prologue: the out-proj sum y goes straight in (RMU_FFN_LNIN=0: separate
+        // k_layernorm launch; RMU_FFN_V=1: the round-2 kernel k_ffn_fused, kept this round for the A/B numbers in DESIGN.md)
+        static const int ffn_v = getenv("RMU_FFN_V") ? atoi(getenv("RMU_FFN_V")) : 2;
+        static const bool ln_in = !(getenv("RMU_FFN_LNIN") && atoi(getenv("RMU_FFN_LNIN")) == 0);
+        if (fused_ffn && ffn_v == 2 && ln_in) {
+            launch_ffn2(m->y, true, L, eps, m->h, m->cu, batch, cap, s);
+            continue;
+        }
         hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
         if (g3_mask & 4) {
             launch_gemm3<EPI_GELU>(m->h1, L.w1_t, L.b1, nullptr, m->mid, m->cu, batch, FF, H, s);
@@ -1695,14 +2302,9 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
             hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
             continue;
         }
-        // The fused kernel gives each 128-token tile to ONE workgroup, which then streams all 2.36 MB of FFN weights through one
-        // CU (~100 us per layer whatever the batch): below ~128 tiles most CUs would idle and the GEMM pair, whose feature tiles
-        // spread over the chip, is faster (measured: 8k tokens 0.82 vs 0.95 ms per forward, one 16-token query 0.44 vs 0.63 ms;
-        // 32k tokens 1.70 vs 1.45).  RMU_FUSED_FFN=0 / 1 forces either path.
-        static const int fused_env = getenv("RMU_FUSED_FFN") ? atoi(getenv("RMU_FUSED_FFN")) : -1;
-        const bool fused_ffn = fused_env < 0 ? cap > 16384 : fused_env != 0;
         if (fused_ffn) {          // FFN1 + GELU + FFN2 + residual + LayerNorm in one kernel: the 1536-wide intermediate stays on chip
-            launch_ffn_fused(m->h1, L, eps, m->h, m->cu, batch, cap, s);
+            if (ffn_v == 2) launch_ffn2(m->h1, false, L, eps, m->h, m->cu, batch, cap, s);
+            else launch_ffn_fused(m->h1, L, eps, m->h, m->cu, batch, cap, s);
             continue;
         }
         launch_gemm<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, cap, FF, H, s);

@@ -303,6 +303,7 @@ struct rmu_index {
     float xnorm_max = 0.f;          // max row norm (bounds the screening error)
     float dx_max = 0.f;             // max row norm of (x - screening image): the measured rounding error
     bool screen_enabled = true;     // RMU_OPT_SCREEN: searches may take the screening path (when `split` exists)
+    int64_t screen_min_nq = 0;      // RMU_OPT_SCREEN_MIN_NQ: > 0 = screen every batch of at least this many queries, whatever the corpus size
     std::vector<uint8_t> alive;
     std::shared_mutex mu;
 };
@@ -748,14 +749,30 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
 }
 
 static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
-    static const bool min_nq_set = getenv("RMU_SCREEN_MIN_NQ") != nullptr;
-    static const int screen_min_nq = min_nq_set ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
+    // (read once: the per-index switch is rmu_index_set_option(RMU_OPT_SCREEN_MIN_NQ))
+    static const bool env_set = getenv("RMU_SCREEN_MIN_NQ") != nullptr;
+    static const int env_min_nq = env_set ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
+    const bool min_nq_set = env_set || idx->screen_min_nq > 0;
+    const int64_t screen_min_nq = idx->screen_min_nq > 0 ? idx->screen_min_nq : env_min_nq;
     // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays for the
     // ladder's launches and merges per batch, which only pays off on a large enough corpus
     const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || min_nq_set;
     return idx->split && idx->screen_enabled && idx->dpad == 384 && idx->dim == 384 && idx->metric != RMU_METRIC_L2SQ &&
            nb >= screen_min_nq && screen_pays && k <= 24 && idx->n > 0 && idx->xnorm_max > 0.f &&
            idx->xnorm_max < 500.f;   // fp16(64*x) must not overflow
+}
+
+// deep k (the 128-deep candidate geometry) over a large corpus takes the exact scan as a threshold ladder (see rmu_index_search)
+static bool deep_applies(const rmu_index* idx, int k) {
+    static const bool off = getenv("RMU_DEEP") && atoi(getenv("RMU_DEEP")) == 0;
+    return !off && k > 32 && idx->n >= 262144;
+}
+static std::vector<int64_t> deep_bounds(int64_t n) {
+    static const int first = getenv("RMU_DEEP_FIRST") ? atoi(getenv("RMU_DEEP_FIRST")) : 8192;
+    static const int ratio = getenv("RMU_DEEP_RATIO") ? atoi(getenv("RMU_DEEP_RATIO")) : 4;
+    std::vector<int64_t> b{n};
+    for (int64_t c = n / ratio / 128 * 128; c >= first && b.size() < 8; c = c / ratio / 128 * 128) b.insert(b.begin(), c);
+    return b;
 }
 
 extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, int k, unsigned flags, int64_t row_base,
@@ -821,20 +838,21 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // (optional) makes both launches conditional on the device-side count of flagged queries; `scatter` redirects
         // result row i to batch row scatter[i]. ------------------------------------------------------------------------
         size_t need_partial = 0, need_gthr = 0;
-        auto plan_exact = [&](const float* qd, int64_t nqq, const RmuCond* cond, ScanLaunch* L) -> int {
+        auto plan_exact = [&](const float* qd, int64_t nqq, const RmuCond* cond, ScanLaunch* L, int kk = 0) -> int {
             *L = ScanLaunch{};
-            L->x = idx->x; L->n_rows = idx->n; L->dpad = dpad; L->q = qd; L->nq = (int)nqq; L->k = k; L->dbg = g_dbg;
+            if (kk <= 0) kk = k;
+            L->x = idx->x; L->n_rows = idx->n; L->dpad = dpad; L->q = qd; L->nq = (int)nqq; L->k = kk; L->dbg = g_dbg;
             if (cond) L->cond = *cond;
             const int rc2 = rmu_scan_plan(L);
             if (rc2) return fail(rc2, "rmu_index_search: no scan geometry for this (dim, k)");
-            need_partial = std::max(need_partial, (size_t)L->parts * nqq * k * sizeof(u64));
+            need_partial = std::max(need_partial, (size_t)L->parts * nqq * kk * sizeof(u64));
             // shared per-query thresholds: padded to whole 128-query tiles, zero = no bound yet
             need_gthr = std::max(need_gthr, (size_t)((nqq + 127) / 128 * 128 + 64) * sizeof(u32));
             return RMU_OK;
         };
         auto run_exact = [&](ScanLaunch& L, float* os, int64_t* orr, const int64_t* scatter, bool time_it) -> int {
             const bool has_cond = L.cond.p != nullptr;
-            const size_t pbytes = (size_t)L.parts * L.nq * k * sizeof(u64);
+            const size_t pbytes = (size_t)L.parts * L.nq * L.k * sizeof(u64);
             const size_t gbytes = (size_t)((L.nq + 127) / 128 * 128 + 64) * sizeof(u32);
             L.partial = (u64*)t.partial.p;
             L.gthr = (u32*)t.gthr.p;
@@ -850,7 +868,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             } else {
                 HIP_TRY(hipMemsetAsync(L.partial, 0, pbytes, s));
             }
-            rc2 = rmu_merge_final_launch(L.partial, L.parts, L.nq, k, row_base, l2 ? 1 : 0, l2 ? (const float*)t.qn.p : nullptr, os, orr,
+            rc2 = rmu_merge_final_launch(L.partial, L.parts, L.nq, L.k, row_base, l2 ? 1 : 0, l2 ? (const float*)t.qn.p : nullptr, os, orr,
                                          scatter, has_cond ? &L.cond : nullptr, s);
             if (rc2) return fail(rc2, "rmu_index_search: merge launch");
             if (g_dbg && !has_cond) dbg_dump("exact", idx->n, s);
@@ -900,6 +918,52 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, t.lev[(size_t)(2 * l)], t.lev[(size_t)(2 * l + 1)]) == hipSuccess) scan_total += ms;
                 }
+        } else if (deep_applies(idx, k)) {
+            // ---- deep k (32 < k <= 112) over a large corpus (BASELINE config 5's dense top-100): the 128-deep scan is slow COLD --
+            // k ln(rows / k) appends per query and chunk, each stalling a barrier-coupled workgroup -- not per byte.  So the
+            // threshold ladder of the screening path, with exact arithmetic: the corpus is scanned in row ranges of growing size
+            // (~8k rows, then x4), after each range the candidates are merged with the running top-k (keys) and its k-th best
+            // seeds the shared per-query thresholds of the next launch; the last merge writes the results.  Every launch is
+            // the exact fp32 scan, every bound is a real k-th best: results are those of the single launch, bit for bit.
+            const std::vector<int64_t> bounds = deep_bounds(idx->n);
+            const int nl = (int)bounds.size();
+            std::vector<ScanLaunch> lv((size_t)nl);
+            int slots = nl - 1;
+            size_t gthr_need = 0;
+            for (int l = 0; l < nl; ++l) {
+                ScanLaunch& S = lv[(size_t)l];
+                S = ScanLaunch{};
+                S.row0 = l ? bounds[(size_t)l - 1] : 0;
+                S.x = idx->x + S.row0 * dpad; S.n_rows = bounds[(size_t)l] - S.row0; S.dpad = dpad; S.q = qdev; S.nq = (int)nb; S.k = k; S.dbg = g_dbg;
+                if ((rc = rmu_scan_plan(&S))) return fail(rc, "rmu_index_search: no scan geometry for this (dim, k)");
+                slots += S.parts;
+                gthr_need = std::max(gthr_need, (size_t)((nb + 127) / 128 * 128 + 64) * sizeof(u32));
+            }
+            const size_t part_keys = (size_t)nb * k;
+            if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.gthr.ensure(gthr_need))
+                return fail(RMU_E_OOM, "rmu_index_search: ladder workspace");
+            HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gthr_need, s));
+            u64* base = (u64*)t.partial.p;
+            int cursor = 0;
+            if (timed) HIP_TRY(hipEventRecord(t.ev[2], s));
+            for (int l = 0; l < nl; ++l) {
+                ScanLaunch& S = lv[(size_t)l];
+                const int first = cursor;           // slot of the running top-k (l > 0), else of this range's first part
+                if (l > 0) cursor += 1;
+                S.partial = base + (size_t)cursor * part_keys; S.gthr = (u32*)t.gthr.p; S.share_thr = share;
+                rc = rmu_scan_launch(&S, s);
+                if (rc) return fail(rc, std::string("rmu_index_search: scan launch: ") + hipGetErrorString(hipGetLastError()));
+                cursor += S.parts;
+                if (l + 1 < nl)
+                    rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, k, base + (size_t)cursor * part_keys,
+                                                  (u32*)t.gthr.p, s);
+                else
+                    rc = rmu_merge_final_launch(base + (size_t)first * part_keys, cursor - first, nb, k, row_base, l2 ? 1 : 0,
+                                                l2 ? (const float*)t.qn.p : nullptr, d_s, d_r, nullptr, nullptr, s);
+                if (rc) return fail(rc, "rmu_index_search: ladder merge");
+            }
+            if (timed) { HIP_TRY(hipEventRecord(t.ev[3], s)); exact_timed = true; }
+            t.grid = lv.back().grid; t.block = 256; t.lds = lv.back().lds_bytes; t.passes += nl;
         } else {
             ScanLaunch L{};
             if ((rc = plan_exact(qdev, nb, nullptr, &L))) return rc;
@@ -990,6 +1054,7 @@ extern "C" int rmu_index_set_option(rmu_index_t* idx, int option, int64_t value)
     std::unique_lock<std::shared_mutex> lk(idx->mu);
     switch (option) {
         case RMU_OPT_SCREEN: idx->screen_enabled = value != 0; return RMU_OK;
+        case RMU_OPT_SCREEN_MIN_NQ: idx->screen_min_nq = value > 0 ? value : 0; return RMU_OK;
         default: return fail(RMU_E_INVALID, "rmu_index_set_option: unknown option");
     }
 }

@@ -104,7 +104,8 @@ struct RmuCond {
 struct ScanLaunch {
     const float* x;        // [n_rows, dpad] fp32 row-major, HBM resident
     int64_t n_rows;
-    int64_t row0;          // screening scan only: first row of the range (rows [row0, row0 + n_rows) of the image)
+    int64_t row0;          // first row of the scanned range: screening scan rows [row0, row0 + n_rows) of the image `x`; exact scan: `x`
+                           // already points at row row0 and row0 is only added to the row ids of the keys
     int dpad;              // row stride in floats (multiple of 96)
     const float* q;        // [nq, dpad] fp32 device (padded like the rows)
     int nq;

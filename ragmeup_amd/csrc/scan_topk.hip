@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const ScanLaunch a) {
     // lane stores, the non-passing ones into their private trash slot.
     const u32 trash_addr = lds_addr(smem + C::TRASH_OFF) + threadIdx.x * 8u;
     auto slow_slot_r = [&](const f32x16& prev, int r, int64_t rbase) {
-        const u64 key = rmu_make_key(prev[r] + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+        const u64 key = rmu_make_key(prev[r] + 0.0f, (u32)(a.row0 + rbase + (r & 3) + 8 * (r >> 2)));
         const bool pass = (pmask >> r) & 1u;   // r is a compile-time constant after unrolling
         lds_store_b64_nofence(pass ? wr_addr : trash_addr, key);
         wr_addr += pass ? 8u : 0u;

@@ -176,10 +176,13 @@ __global__ __launch_bounds__(1024) void merge_wg_kernel(const u64* __restrict__ 
 //   C. enumeration rank among those; rank < k -> output position rank.
 // The wave-serial sort/merge rounds of merge_wg_kernel (27 dependent 64-bit shuffle steps per 64 keys) made a ladder merge
 // cost 40 us -- six of them were 0.24 ms of a 1.7 ms HBM-bound batch; this form is a few LDS sweeps.
-template <int BLOCK>
+// k <= 128 (round 3: the deep-k ladder's merges and every final merge of a k > 32 search): the same selection with a 3072-key
+// array -- the k parts whose heads reach tau rarely hold more than a few keys >= tau each.  If they do (count > CAPM: up to
+// k x k = 16k keys in the worst case) the query's first wave folds the part lists with the bitonic stream merge instead.
+template <int BLOCK, int CAPM>
 __global__ __launch_bounds__(BLOCK) void merge_select_kernel(const u64* __restrict__ partial, int parts, int64_t nq, int k,
                                                              MergeOut o, RmuCond cond) {
-    constexpr int CAPM = 1024, MAXP = 1024;
+    constexpr int MAXP = 1024;
     __shared__ u64 heads[MAXP];
     __shared__ u64 cand[CAPM];
     __shared__ u64 tau_s;
@@ -247,6 +250,16 @@ __global__ __launch_bounds__(BLOCK) void merge_select_kernel(const u64* __restri
             o.rows[qo * k + e] = r;
         }
     };
+    if (CAPM < 128 * 128 && count > (u32)CAPM) {    // (k <= 32: k x k <= 1024 keys, cannot happen)
+        if (w == 0) {
+            u64 top[2];
+            merge_stream_slabs_pf<2>(top, parts, k, lane, [&](int part, int pos) { return base[(int64_t)part * pstride + pos]; });
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (lane + 64 * p < k) emit(lane + 64 * p, top[p]);
+        }
+        return;
+    }
     for (u32 i = tid; i < m; i += BLOCK) {
         const u64 mine = cand[i];
         u32 rank = 0;
@@ -301,8 +314,13 @@ static int merge_wg_launch(const u64* partial, int parts, int64_t nq, int k, con
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
     static const int use_select = getenv("RMU_MERGE_SELECT") ? atoi(getenv("RMU_MERGE_SELECT")) : 1;
     if (use_select && k <= 32 && parts <= 1024) {          // selection merge: one workgroup per query
-        if (nq <= 512) hipLaunchKernelGGL(merge_select_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, s, partial, parts, nq, k, o, cond);
-        else hipLaunchKernelGGL(merge_select_kernel<256>, dim3((unsigned)nq), dim3(256), 0, s, partial, parts, nq, k, o, cond);
+        if (nq <= 512) hipLaunchKernelGGL((merge_select_kernel<1024, 1024>), dim3((unsigned)nq), dim3(1024), 0, s, partial, parts, nq, k, o, cond);
+        else hipLaunchKernelGGL((merge_select_kernel<256, 1024>), dim3((unsigned)nq), dim3(256), 0, s, partial, parts, nq, k, o, cond);
+        return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+    }
+    if (use_select && parts <= 1024) {                     // 32 < k <= 128
+        if (nq <= 512) hipLaunchKernelGGL((merge_select_kernel<1024, 3072>), dim3((unsigned)nq), dim3(1024), 0, s, partial, parts, nq, k, o, cond);
+        else hipLaunchKernelGGL((merge_select_kernel<256, 3072>), dim3((unsigned)nq), dim3(256), 0, s, partial, parts, nq, k, o, cond);
         return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
     }
     // waves per query: ~16 parts per wave, and at least ~2k waves in flight when the batch is small

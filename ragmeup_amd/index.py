@@ -147,6 +147,11 @@ class FlatIndex:
         """RMU_OPT_SCREEN: allow (default) or forbid the fp16 screening path; results are identical either way."""
         N.check(self._lib.rmu_index_set_option(self._h, N.OPT_SCREEN, 1 if on else 0), "rmu_index_set_option")
 
+    def set_screen_min_batch(self, n: int = 0):
+        """RMU_OPT_SCREEN_MIN_NQ: n > 0 sends every batch of >= n queries through the screening path whatever the corpus size
+        (0 restores the default heuristics); results are identical either way."""
+        N.check(self._lib.rmu_index_set_option(self._h, N.OPT_SCREEN_MIN_NQ, int(n)), "rmu_index_set_option")
+
     def screen_candidates(self, q):
         """Test hook (rmu_index_screen_candidates): per query the screening pass's 32 candidates ->
         (approx scores [nq,32], rows [nq,32], exact fp32 scores of the same rows [nq,32], EPS [nq])."""

@@ -335,17 +335,32 @@ class MI355XVectorStore(VectorStore):
             raise ValueError("texts, metadatas and ids must have equal lengths")
         # upsert semantics of the replaced stores: one row per pk -- inside a batch the LAST occurrence wins
         last = {pk: i for i, pk in enumerate(ids)}
-        keep = sorted(last.values())
-        vecs = self._embed_docs_for_index([texts[i] for i in keep])
+        if len(last) == len(ids):                    # the usual case (md5 ids of distinct chunks): nothing to drop
+            keep = range(len(ids))
+            sel_texts, sel_ids = texts, ids
+        else:
+            keep = sorted(last.values())
+            sel_texts, sel_ids = [texts[i] for i in keep], [ids[i] for i in keep]
+        # The host records are prepared WHILE the GPU embeds (both the tokenizer and the encoder run in librmu.so with the GIL
+        # released): on the indexing path (1000-document calls, server/RAGHelper.py:423-434, or one big call) the Python
+        # bookkeeping would otherwise sit serially behind every embedding.
+        if len(sel_texts) >= 4096:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                fut = pool.submit(self._embed_docs_for_index, sel_texts)
+                sel_metas = [dict(metadatas[i]) for i in keep]
+                vecs = fut.result()
+        else:
+            vecs = self._embed_docs_for_index(sel_texts)
+            sel_metas = [dict(metadatas[i]) for i in keep]
         with self._lock:
             self._ensure_index(int(vecs.shape[1]))
             n0 = len(self._texts)
             # host records FIRST: a concurrent search may return a new row the moment index.add publishes it
-            for i in keep:
-                self._texts.append(texts[i])
-                self._metas.append(dict(metadatas[i]))
-                self._pks.append(ids[i])
-                self._alive.append(True)
+            self._texts.extend(sel_texts)
+            self._metas.extend(sel_metas)
+            self._pks.extend(sel_ids)
+            self._alive.extend([True] * len(sel_ids))
             try:
                 first = self._index.add(vecs)
             except Exception:
@@ -362,14 +377,13 @@ class MI355XVectorStore(VectorStore):
                     self._texts.append(""); self._metas.append({}); self._pks.append(""); self._alive.append(False)
                 raise RuntimeError(f"index rows ({first}) and host records ({n0}) out of step: the batch was rolled back")
             # the new copies are in: only now retire the rows they replace (a failed add loses nothing)
-            stale = [self._pk_to_row[ids[i]] for i in keep
-                     if ids[i] in self._pk_to_row and self._alive[self._pk_to_row[ids[i]]]]
+            old_rows = self._pk_to_row
+            stale = [old_rows[pk] for pk in sel_ids if pk in old_rows and self._alive[old_rows[pk]]] if old_rows else []
             if stale:
                 self._index.remove_rows(stale)
                 for r in stale:
                     self._alive[r] = False
-            for off, i in enumerate(keep):
-                self._pk_to_row[ids[i]] = n0 + off
+            old_rows.update(zip(sel_ids, range(n0, n0 + len(sel_ids))))
             self._dirty = True
             if self.auto_persist is True:
                 self.persist()

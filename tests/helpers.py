@@ -134,7 +134,7 @@ def _write_tokenizer_files(d, lower=True, model_max_length=512):
     return toks
 
 
-def write_st_checkpoint(d, pooling="mean", normalize=True, max_seq_length=256, layers=6, seed=0, st_files=True, lower=True):
+def write_st_checkpoint(d, pooling="mean", normalize=True, max_seq_length=256, layers=6, seed=0, st_files=True, lower=True, scale=1.0):
     """A sentence-transformers style directory around a seeded random-init BERT-{layers}x384: config.json +
     model.safetensors (BertModel.save_pretrained), vocab.txt, tokenizer_config.json, modules.json,
     sentence_bert_config.json, 1_Pooling/config.json (+ 2_Normalize).  Returns the transformers model (eval, fp32)."""
@@ -153,6 +153,8 @@ def write_st_checkpoint(d, pooling="mean", normalize=True, max_seq_length=256, l
         for n, p in m.named_parameters():
             if "LayerNorm" in n or n.endswith(".bias"):
                 p.add_(0.05 * torch.randn(p.shape, generator=g))
+            elif scale != 1.0 and p.dim() == 2 and "embeddings" not in n:
+                p.mul_(scale)                                   # see make_bert: weights that do not collapse
     m.save_pretrained(d, safe_serialization=True)
     _write_tokenizer_files(d, lower=lower)
     if st_files:

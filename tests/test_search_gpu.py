@@ -333,13 +333,13 @@ def test_rccl_allgather_path_world1(rmu, corpus50k):
             dist.destroy_process_group()
 
 
-# ---- fp16 screening pass + exact fp32 re-score (k <= 24, dim 384; RMU_SCREEN_MIN_NQ=1 in these tests) -------------------------------------
+# ---- fp16 screening pass + exact fp32 re-score (k <= 24, dim 384; RMU_OPT_SCREEN_MIN_NQ = 1 where the batch is small) ----------------------
 @pytest.mark.parametrize("nq,k", [(1, 20), (7, 10), (64, 24), (128, 10), (200, 1), (256, 16), (1024, 10)])
-def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k, monkeypatch):
-    monkeypatch.setenv("RMU_SCREEN_MIN_NQ", "1")     # small batches over a small corpus would take the exact scan (it is faster there)
+def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
     x = O.make_corpus(60_000)
     q, planted = O.make_queries(x, nq)
     idx = rmu.FlatIndex(384)
+    idx.set_screen_min_batch(1)                      # small batches over a small corpus would take the exact scan (it is faster there)
     idx.add(x)
     s, r = idx.search(q, k)
     assert idx.last_screened() != 0, "expected the screening path to answer this batch"   # (< 0: some queries were re-run exactly)
@@ -776,3 +776,66 @@ def test_back_to_back_searches_on_different_caller_streams_do_not_share_scratch(
         assert_topk_parity(outs[1][0].cpu().numpy(), outs[1][1].cpu().numpy(), *O.flat_search(qb, x, 12))
         assert_topk_parity(s0, r0, *O.flat_search(qa[:64], x, 12))
     idx.close()
+
+
+# ---- deep k over a large corpus (BASELINE config 5: dense top-100): the exact 128-deep scan run as a threshold ladder over
+# growing row ranges (>= 262144 rows; below that, and with RMU_DEEP=0, the single cold launch) -----------------------------------
+@pytest.fixture(scope="module")
+def corpus300k():
+    x = O.make_corpus(300_000, seed=77)
+    q, planted = O.make_queries(x, 130, seed=78)
+    return x, q, planted
+
+
+@pytest.mark.parametrize("nq,k", [(64, 100), (5, 33), (33, 112), (130, 100), (1, 64)])
+def test_deep_k_ladder_parity_vs_oracle(rmu, corpus300k, nq, k):
+    x, q, planted = corpus300k
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    s, r = idx.search(q[:nq], k)
+    assert idx.last_geometry()["launches"] >= 2                    # really the ladder (one scan launch per row range)
+    assert_topk_parity(s, r, *O.flat_search(q[:nq], x, k + 4))
+    assert (r[:, 0] == planted[:nq]).all() and (np.diff(s, axis=1) <= 0).all()
+    # device buffers give the same bits
+    import torch
+    sd, rd = idx.search(torch.from_numpy(q[:nq]).cuda(), k)
+    assert np.array_equal(rd.cpu().numpy(), r) and np.array_equal(sd.cpu().numpy(), s)
+    # ... and so does the single cold launch over a prefix that is too small for the ladder (same rows, same arithmetic)
+    small = rmu.FlatIndex(384)
+    small.add(x[:200_000])
+    s1, r1 = small.search(q[:nq], k)
+    assert small.last_geometry()["launches"] == 1
+    assert_topk_parity(s1, r1, *O.flat_search(q[:nq], x[:200_000], k + 4))
+    small.close(); idx.close()
+
+
+def test_deep_k_ladder_with_clustered_duplicates_tombstones_and_l2(rmu, corpus300k):
+    """100 near-duplicates of one row stored in consecutive rows (one corpus part, one ladder range) must all come back; deleted
+    rows never do; the native-L2 index takes the same ladder."""
+    from ragmeup_amd import _native as N
+    x, q, _ = corpus300k
+    rng = np.random.default_rng(5)
+    dup = x[1000][None, :] + 1e-3 * rng.standard_normal((100, 384)).astype(np.float32)
+    dup /= np.linalg.norm(dup, axis=1, keepdims=True)
+    xd = np.concatenate([x[:150_000], dup, x[150_000:]])
+    qq = np.concatenate([x[1000][None, :], dup[:40], q[:8]])
+    idx = rmu.FlatIndex(384)
+    idx.add(xd)
+    s, r = idx.search(qq, 100)
+    assert_topk_parity(s, r, *O.flat_search(qq, xd, 104))
+    assert set(r[0].tolist()) <= set(range(150_000, 150_100)) | {1000}
+    dead = np.arange(0, xd.shape[0], 3)
+    idx.remove_rows(dead)
+    alive = np.ones(xd.shape[0], bool); alive[dead] = False
+    s, r = idx.search(qq[:20], 100)
+    assert_topk_parity(s, r, *O.flat_search(qq[:20], xd, 104, alive=alive))
+    idx.close()
+    xl = (rng.standard_normal((270_000, 384)) * rng.uniform(0.5, 2.0, (270_000, 1))).astype(np.float32)
+    ql = xl[:12] + 0.05 * rng.standard_normal((12, 384)).astype(np.float32)
+    il2 = rmu.FlatIndex(384, metric=N.METRIC_L2SQ)
+    il2.add(xl)
+    d, r = il2.search(ql, 64)
+    os_, or_ = O.flat_search(ql, xl, 68, metric=O.METRIC_L2SQ)
+    scale = float((xl ** 2).sum(1).max())
+    assert_topk_parity(-d, r, os_, or_, score_tol=2e-6 * scale + 1e-4, tie_tol=1e-6 * scale)
+    il2.close()
