@@ -191,6 +191,13 @@ int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, 
                     int batch, int max_len, int mode, float* out_dev, int64_t out_stride,
                     uint64_t hip_stream);
 
+/* The same forward for a HANDFUL of tokens (batch * max_len <= 256: embed_query, a few passages to rerank) from HOST buffers to a
+ * HOST result: the interactive per-request pattern of the reference (one query per /chat call, RAGHelper.py:497-499).  The
+ * library replays one captured hipGraph per input shape (H2D, ~45 launches, D2H: one graph launch, one synchronisation).
+ * ids / type_ids (may be NULL) [batch, max_len], lens [batch]: host int32; out_host as out_dev above, on the host. */
+int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens,
+                         int batch, int max_len, int mode, float* out_host, int64_t out_stride);
+
 /* ---- WordPiece tokenizer (host C++; the step in front of both encoder forwards) --------------------
  * Restates transformers' BertTokenizer (BasicTokenizer + WordPiece) as used by sentence-transformers `tokenize`
  * (HuggingFaceEmbeddings.embed_documents, RAGHelper.py:423-434) and CrossEncoder pair tokenisation

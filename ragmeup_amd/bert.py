@@ -124,6 +124,28 @@ class BertEncoder:
             pass
 
     # ---- forward ------------------------------------------------------------------------------------------
+    SMALL_TOKENS = 256          # rmu_bert_encode_host: batch * max_len it accepts
+
+    def encode_host(self, ids, lens, type_ids=None, mode: int = 0) -> np.ndarray:
+        """The interactive path (embed_query, a few pairs): HOST int32 arrays in, HOST fp32 array out, batch * L <= 256.  One
+        captured hipGraph per input shape is replayed inside librmu.so (rmu_bert_encode_host): one graph launch + one
+        synchronisation instead of ~45 launches and three torch tensor copies."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        B, L = ids.shape
+        tt = None if type_ids is None else np.ascontiguousarray(type_ids, dtype=np.int32)
+        kind = mode & 0xff
+        if kind == MODE_CE:
+            out = np.empty((B,), dtype=np.float32)
+        elif kind == MODE_TOKENS:
+            out = np.empty((int(np.minimum(np.maximum(lens, 0), L).sum()), self.HIDDEN), dtype=np.float32)
+        else:
+            out = np.empty((B, self.HIDDEN), dtype=np.float32)
+        N.check(self._lib.rmu_bert_encode_host(self._h, ids.ctypes.data, tt.ctypes.data if tt is not None else None, lens.ctypes.data,
+                                               int(B), int(L), int(mode), out.ctypes.data, 1 if kind == MODE_CE else self.HIDDEN),
+                "rmu_bert_encode_host")
+        return out
+
     def encode_ids(self, ids, lens, type_ids=None, mode: int = 0, out=None):
         """ids [B, L] int (numpy or torch, padded), lens [B].  mode = MODE_MEAN / MODE_CLS (| NO_NORMALIZE) -> [B, 384] fp32
         (torch CUDA); MODE_CE -> [B] fp32 logits; MODE_TOKENS -> [sum(min(lens, L)), 384] fp32, sequences packed in batch order.

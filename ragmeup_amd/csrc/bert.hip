@@ -16,6 +16,9 @@
 // (D^T = W . A^T) so a lane ends up with 4 consecutive output features of one token: 8-byte bf16 stores.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -1971,7 +1974,15 @@ struct rmu_bert {
     bf16 *h = nullptr, *h1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr;
     int* cu = nullptr;
     hipStream_t stream = nullptr;
+    // small-batch host path (rmu_bert_encode_host): one captured graph per (batch, max_len, mode, token types) shape -- H2D of the
+    // ids, the ~45 launches of a forward, D2H of the result -- replayed with ONE hipGraphLaunch.  All addresses inside are
+    // the fixed staging buffers below, so a replay needs no node updates.
+    struct SmallGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool warm = false; };
+    std::map<uint64_t, SmallGraph> graphs;
+    int32_t *h_in = nullptr, *d_in = nullptr;      // [ids | type ids | lens], pinned host / device
+    float *h_out = nullptr, *d_out = nullptr;
 };
+static constexpr int SMALL_IN_INTS = 2 * 256 + 256, SMALL_OUT_FLOATS = 256 * 384;   // SMALL_M = 256 tokens at most
 
 extern "C" void rmu_set_error_(const char* msg);   // rmu_api.hip: thread-local message behind rmu_last_error()
 static int bfail(int code, const std::string& m) { rmu_set_error_(m.c_str()); return code; }
@@ -2008,6 +2019,14 @@ extern "C" int rmu_bert_free(rmu_bert_t* m) {
     for (void* p : m->owned) (void)hipFree(p);
     for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->cu})
         if (p) (void)hipFree(p);
+    for (auto& kv : m->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    if (m->h_in) (void)hipHostFree(m->h_in);
+    if (m->h_out) (void)hipHostFree(m->h_out);
+    if (m->d_in) (void)hipFree(m->d_in);
+    if (m->d_out) (void)hipFree(m->d_out);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return RMU_OK;
@@ -2092,7 +2111,16 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
     return RMU_OK;
 }
 
+static void drop_graphs(rmu_bert* m) {       // the captured launches hold workspace addresses
+    for (auto& kv : m->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    m->graphs.clear();
+}
+
 static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
+    if (tokens > m->ws_tokens || batch + 1 > m->ws_batch) drop_graphs(m);
     if (tokens > m->ws_tokens) {
         (void)hipDeviceSynchronize();
         for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid})
@@ -2243,22 +2271,24 @@ static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hi
     hipLaunchKernelGGL(k_attention<MAXT>, grid, dim3(256), lds, s, qkv, cu, ctx);
 }
 
-extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
-                               int max_len, int mode, float* out_dev, int64_t out_stride, uint64_t hip_stream) {
-    if (!m || !ids || !lens || !out_dev) return bfail(RMU_E_INVALID, "rmu_bert_encode: null argument");
+static int check_encode_args(rmu_bert_t* m, const void* ids, const void* lens, const void* out, int batch, int max_len, int mode, int64_t out_stride) {
+    if (!m || !ids || !lens || !out) return bfail(RMU_E_INVALID, "rmu_bert_encode: null argument");
     if (batch < 1 || batch > 65535 || max_len < 1 || max_len > m->cfg.max_pos)
         return bfail(RMU_E_INVALID, "rmu_bert_encode: 1 <= batch <= 65535, 1 <= max_len <= max_pos");
     const int kind = mode & 0xff;
-    const bool normalize = !(mode & RMU_BERT_NO_NORMALIZE);
     if ((mode & ~(0xff | RMU_BERT_NO_NORMALIZE)) || kind > RMU_BERT_TOKENS)
         return bfail(RMU_E_INVALID, "rmu_bert_encode: mode must be RMU_BERT_POOL_MEAN / CE_LOGIT / POOL_CLS / TOKENS (| RMU_BERT_NO_NORMALIZE)");
     if (kind == RMU_BERT_CE_LOGIT && !m->cfg.has_head) return bfail(RMU_E_INVALID, "rmu_bert_encode: model has no classification head");
     if (kind != RMU_BERT_CE_LOGIT && out_stride < H) return bfail(RMU_E_INVALID, "rmu_bert_encode: out_stride < hidden");
-    std::lock_guard<std::mutex> lk(m->mu);
+    return RMU_OK;
+}
+
+// every launch of one forward on stream s (device pointers; no allocation, no synchronisation: capturable)
+static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch, int max_len, int mode,
+                            float* out_dev, int64_t out_stride, hipStream_t s) {
+    const int kind = mode & 0xff;
+    const bool normalize = !(mode & RMU_BERT_NO_NORMALIZE);
     const int64_t cap = (int64_t)batch * max_len;
-    int rc = ensure_ws(m, cap, batch);
-    if (rc) return bfail(rc, "rmu_bert_encode: workspace");
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
     const float eps = m->cfg.ln_eps;
 
     hipLaunchKernelGGL(k_cu_seqlens, dim3(1), dim3(1024), 0, s, (const int*)lens, batch, max_len, m->cu);
@@ -2319,7 +2349,88 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
                            out_dev, out_stride);
     else
         hipLaunchKernelGGL(k_cls_head, dim3((unsigned)batch), dim3(128), 0, s, (const bf16*)m->h, (const int*)m->cu, m->wp, m->bp, m->wc, m->bc, out_dev);
+}
+
+extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
+                               int max_len, int mode, float* out_dev, int64_t out_stride, uint64_t hip_stream) {
+    int rc = check_encode_args(m, ids, lens, out_dev, batch, max_len, mode, out_stride);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(m->mu);
+    rc = ensure_ws(m, (int64_t)batch * max_len, batch);
+    if (rc) return bfail(rc, "rmu_bert_encode: workspace");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
+    enqueue_forward(m, ids, type_ids, lens, batch, max_len, mode, out_dev, out_stride, s);
     B_TRY(hipGetLastError());
     if (!hip_stream) B_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}
+
+// The interactive path (embed_query, a handful of passages to rerank: batch * max_len <= 256 tokens) from HOST buffers.  A forward at
+// that size is ~45 launches of 1-3 us of work each: launch-latency-bound.  The first call of a shape runs eagerly, the second
+// captures H2D + launches + D2H into a hipGraph, every later one is ONE hipGraphLaunch + ONE synchronisation.
+extern "C" int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch, int max_len,
+                                    int mode, float* out_host, int64_t out_stride) {
+    int rc = check_encode_args(m, ids, lens, out_host, batch, max_len, mode, out_stride);
+    if (rc) return rc;
+    const int64_t cap = (int64_t)batch * max_len;
+    if (cap > SMALL_M) return bfail(RMU_E_INVALID, "rmu_bert_encode_host: batch * max_len must be <= 256 (use rmu_bert_encode for bulk work)");
+    std::lock_guard<std::mutex> lk(m->mu);
+    rc = ensure_ws(m, cap, batch);
+    if (rc) return bfail(rc, "rmu_bert_encode_host: workspace");
+    if (!m->h_in) {
+        if (hipHostMalloc((void**)&m->h_in, SMALL_IN_INTS * sizeof(int32_t)) != hipSuccess || hipHostMalloc((void**)&m->h_out, SMALL_OUT_FLOATS * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&m->d_in, SMALL_IN_INTS * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&m->d_out, SMALL_OUT_FLOATS * sizeof(float)) != hipSuccess)
+            return bfail(RMU_E_OOM, "rmu_bert_encode_host: staging buffers");
+    }
+    const int kind = mode & 0xff;
+    // staging layout: ids [cap] | type ids [cap] | lens [batch]
+    memcpy(m->h_in, ids, (size_t)cap * 4);
+    if (type_ids) memcpy(m->h_in + cap, type_ids, (size_t)cap * 4);
+    memcpy(m->h_in + 2 * cap, lens, (size_t)batch * 4);
+    int64_t n_tok = 0;
+    for (int b = 0; b < batch; ++b) n_tok += std::min(std::max(lens[b], 0), max_len);
+    const int64_t rows_out = kind == RMU_BERT_TOKENS ? cap : batch;                       // (the graph copies the shape's upper bound)
+    const size_t out_floats = kind == RMU_BERT_CE_LOGIT ? (size_t)batch : (size_t)rows_out * H;
+    const size_t in_bytes = (size_t)(2 * cap + batch) * 4;
+    hipStream_t s = m->stream;
+    auto enqueue_all = [&]() {
+        (void)hipMemcpyAsync(m->d_in, m->h_in, in_bytes, hipMemcpyHostToDevice, s);
+        enqueue_forward(m, m->d_in, type_ids ? m->d_in + cap : nullptr, m->d_in + 2 * cap, batch, max_len, mode, m->d_out, kind == RMU_BERT_CE_LOGIT ? 1 : H, s);
+        (void)hipMemcpyAsync(m->h_out, m->d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost, s);
+    };
+    static const bool use_graph = !(getenv("RMU_GRAPH") && atoi(getenv("RMU_GRAPH")) == 0);
+    const uint64_t key = ((uint64_t)batch << 32) | ((uint64_t)max_len << 16) | ((uint64_t)(mode & 0xfff) << 1) | (type_ids ? 1u : 0u);
+    rmu_bert::SmallGraph& g = m->graphs[key];
+    if (use_graph && g.exec) {
+        B_TRY(hipGraphLaunch(g.exec, s));
+    } else if (use_graph && g.warm) {
+        // second call of this shape: capture (every function attribute / first-use static of the launchers is set by now)
+        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            enqueue_all();
+            ok = hipStreamEndCapture(s, &g.graph) == hipSuccess && g.graph != nullptr;
+            if (ok) ok = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (ok) {
+            B_TRY(hipGraphLaunch(g.exec, s));
+        } else {                                        // no graph for this shape: stay eager (and do not try again)
+            (void)hipGetLastError();
+            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+            g.warm = false;
+            enqueue_all();
+        }
+    } else {
+        enqueue_all();
+        if (use_graph && m->graphs.size() <= 512) g.warm = true;
+    }
+    B_TRY(hipGetLastError());
+    B_TRY(hipStreamSynchronize(s));
+    if (kind == RMU_BERT_CE_LOGIT) {
+        memcpy(out_host, m->h_out, (size_t)batch * sizeof(float));
+    } else {
+        const int64_t rows = kind == RMU_BERT_TOKENS ? n_tok : batch;
+        for (int64_t r = 0; r < rows; ++r) memcpy(out_host + r * out_stride, m->h_out + r * H, H * sizeof(float));
+    }
     return RMU_OK;
 }

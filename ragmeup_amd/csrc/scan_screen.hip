@@ -47,23 +47,32 @@ constexpr int S_NI = S_RT * S_U16 / 256;  // 3 DMA wave-instructions per wave pe
 // need 4 x 1 KiB per 32-cycle MFMA = all 128 B/clk of the LDS before the DMA writes are counted (ablations in
 // DESIGN.md 4.3).  With G = 2 every A fragment feeds two MFMAs (64 queries per wave, 256 per workgroup), halving LDS
 // and L2 bytes per MFMA; the price is 80 KiB of candidate slots, hence the smaller ring slots and CAP.
-template <int G, int NRV = 0>
+// NW = waves per workgroup.  8 (round 3, G = 1): two waves per SIMD, 32 queries each, still 256 queries per workgroup -- a lone
+// wave per SIMD issues roughly one instruction per 6-7 cycles in a wait / MFMA / ds_read / VALU mix (tools/ubench/mfma_issue.hip:
+// the same skeleton runs 46 cycles per MFMA bare and 65 with five VALU fillers), so the 4-wave kernel's ~4.5 fillers per MFMA keep
+// the matrix pipe under half busy; two interleaved instruction streams per SIMD hide each other's issue gaps.  The price is
+// one A-fragment read per MFMA instead of one per two (128 of the LDS's 256 B/clk).
+template <int G, int NRV = 0, int NW = 4>
 struct ScreenCfg {
+    static_assert(NW == 4 || (NW == 8 && G == 1), "8 waves carry one 32-query group each");
     // K' = 32 candidates per (chunk, query).  Appends reserve their position with ds_add_rtn; a position past the slot
     // is retried after the compaction (back to K' entries) that it triggers, and a slot is compacted early once an
     // append lands in its last A entries.
     static constexpr int QW = 32 * G;                       // queries per wave
-    static constexpr int CAP = G == 2 ? 40 : 56, NPL = 1, A = 4;
-    static constexpr int NR = NRV ? NRV : (G == 2 ? 6 : 8);   // ring slots (NRV: ring-depth experiments)
+    static constexpr bool BIG = G == 2 || NW == 8;          // 256 queries per workgroup: 80 KiB of candidate slots
+    static constexpr int CAP = BIG ? 40 : 56, NPL = 1, A = 4;
+    static constexpr int NR = NRV ? NRV : (BIG ? 6 : 8);      // ring slots (NRV: ring-depth experiments)
+    static constexpr int NDW = NW == 8 ? 6 : 4;             // waves that issue the corpus DMA (12 one-KiB pieces per chunk) ...
+    static constexpr int NIW = 12 / NDW;                    // ... and how many pieces each of them issues per chunk
     static constexpr int RING_BYTES = NR * S_SLOT;
-    static constexpr int CAND_BYTES = 4 * QW * CAP * 8;
+    static constexpr int CAND_BYTES = NW * QW * CAP * 8;
     static constexpr int CNT_OFF = RING_BYTES + CAND_BYTES;
-    static constexpr int THR_OFF = CNT_OFF + 4 * QW * 4;
-    static constexpr int TRASH_OFF = THR_OFF + 4 * QW * 4;
-    static constexpr int GT_OFF = TRASH_OFF + 256 * 8;
-    static constexpr int LDS_BYTES = GT_OFF + 4 * 256;
+    static constexpr int THR_OFF = CNT_OFF + NW * QW * 4;
+    static constexpr int TRASH_OFF = THR_OFF + NW * QW * 4;
+    static constexpr int GT_OFF = TRASH_OFF + NW * 64 * 8;
+    static constexpr int LDS_BYTES = GT_OFF + NW * 256;
 };
-static_assert(ScreenCfg<1>::LDS_BYTES <= 160 * 1024 && ScreenCfg<2>::LDS_BYTES <= 160 * 1024, "LDS");
+static_assert(ScreenCfg<1>::LDS_BYTES <= 160 * 1024 && ScreenCfg<2>::LDS_BYTES <= 160 * 1024 && ScreenCfg<1, 0, 8>::LDS_BYTES <= 160 * 1024, "LDS");
 
 extern __shared__ __attribute__((aligned(16))) char ssm[];
 
@@ -96,9 +105,9 @@ __global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, in
 
 // EXP = timing ablations (wrong results): bit 0 no corpus DMA, bit 1 no LDS fragment reads, bit 3 no filter VALU; bit 2 = debug counters
 // S_PRE = A-fragment prefetch depth in steps
-template <int G, int EXP = 0, int S_PRE = 4, int NRV = 0, int NT = 0>
-__global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
-    using C = ScreenCfg<G, NRV>;
+template <int G, int EXP = 0, int S_PRE = 4, int NRV = 0, int NT = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a) {
+    using C = ScreenCfg<G, NRV, NW>;
     constexpr bool DBG = (EXP & 4) != 0;   // cycle / event counters into a.dbg (RMU_SCAN_EXP=7)
     static_assert(S_CS % S_PRE == 0, "fragment register ring must close over a chunk");
     const int lane = threadIdx.x & 63;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     u64* cand_w = (u64*)(ssm + C::RING_BYTES) + (size_t)w * C::QW * C::CAP;
     u32* cnt_w = (u32*)(ssm + C::CNT_OFF) + w * C::QW;
     float* thr_w = (float*)(ssm + C::THR_OFF) + w * C::QW;
-    const int q_base = (qt * 4 + w) * C::QW;             // this wave's first query; group g, lane j owns q_base + 32 g + j
+    const int q_base = (qt * NW + w) * C::QW;            // this wave's first query; group g, lane j owns q_base + 32 g + j
     bool q_ok[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) q_ok[g] = q_base + 32 * g + j < a.nq;
@@ -161,10 +170,10 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     // ---- DMA source map: LDS unit f -> row f/24, physical unit f%24 holds logical unit p ^ ((row >> 1) & 7).  LDS rows are
     // 384 B = 96 banks apart, so rows alternate between two bank halves; the XOR spreads 8 row pairs over the 8 units of an
     // aligned block: any 16 consecutive rows reading one logical unit touch 16 distinct 4-bank groups (conflict free).
-    u32 dma_off[S_NI];
+    u32 dma_off[C::NIW];
 #pragma unroll
-    for (int n = 0; n < S_NI; ++n) {
-        const int f = (n * 4 + w) * 64 + lane;
+    for (int n = 0; n < C::NIW; ++n) {
+        const int f = (n * C::NDW + (w < C::NDW ? w : 0)) * 64 + lane;
         const int i = f / S_U16, p = f % S_U16;
         dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16);
     }
@@ -174,20 +183,21 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
     // and twelve back-to-back 1-KiB DMA instructions per chunk and workgroup cost ~700 cycles per tile that way.
     auto issue_part = [&](int cc, int n) {
         if (EXP & 1) return;   // ablation: no corpus DMA at all
+        if (NW > C::NDW && w >= C::NDW) return;   // (uniform) 8 waves: six of them carry the twelve pieces
         int ce = cc;
         if (ce >= nchunks) ce = nchunks - 1;
         const char* sbase = img + ((t0 + (ce >> 1)) * S_RT) * (int64_t)IMGB + (ce & 1) * S_CKB;
         char* slot = ring + (cc % C::NR) * S_SLOT;
         if (NT)       // literal aux operands only (see scan_topk.hip)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
-                                             (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 2);
+                                             (__attribute__((address_space(3))) void*)(slot + (n * C::NDW + w) * 1024), 16, 0, 2);
         else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
-                                             (__attribute__((address_space(3))) void*)(slot + (n * 4 + w) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(slot + (n * C::NDW + w) * 1024), 16, 0, 0);
     };
     auto issue_chunk = [&](int cc) {
 #pragma unroll
-        for (int n = 0; n < S_NI; ++n) issue_part(cc, n);
+        for (int n = 0; n < C::NIW; ++n) issue_part(cc, n);
     };
     // A fragment of (row j, chunk step t): logical unit 2t + h = 8 (t >> 2) + (2 (t & 3) + h); the XOR touches the low three
     // bits only, so four per-lane bases + an immediate (t >> 2) * 128 address a whole chunk
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
             set_thr();
         }
     };
-    constexpr int GRP = S_NI;                              // corpus VMEM ops per chunk group
+    constexpr int GRP = C::NIW;                            // corpus VMEM ops per chunk group (of a wave that issues any)
     constexpr int WAITN = GRP * (C::NR - 3);               // at a chunk's barrier only chunks >= cc + 2 may be in flight
 
     struct Acc { f32x16 a; };                          // 4096 * s~  (rows and queries are both scaled by 2^6)
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256) void scan_screen_kernel(const ScanLaunch a) {
                 }
                 if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], cur_off, t + S_PRE);
                 else read_frag(fr[gs % S_PRE], nxt_off, t + S_PRE - S_CS);
-                if (t % 4 == 1) issue_part(cc + C::NR - 1, t / 4);      // steps 1, 5, 9: the chunk's three DMA instructions
+                if (t % 4 == 1 && t / 4 < C::NIW) issue_part(cc + C::NR - 1, t / 4);      // steps 1, 5 (, 9): the wave's DMA instructions of the chunk
             }
         }
     };
@@ -509,14 +519,14 @@ int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s)
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
-template <int G, int EXP = 0, int PRE = 4, int NRV = 0, int NT = 0>
+template <int G, int EXP = 0, int PRE = 4, int NRV = 0, int NT = 0, int NW = 4>
 static int screen_launch_cfg(const ScanLaunch* p, hipStream_t s) {
     // function-local static: initialised exactly once, thread-safe (C++11)
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_kernel<G, EXP, PRE, NRV, NT>,
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, ScreenCfg<G, NRV>::LDS_BYTES);
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_kernel<G, EXP, PRE, NRV, NT, NW>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, ScreenCfg<G, NRV, NW>::LDS_BYTES);
     if (attr_rc != hipSuccess) return RMU_E_HIP;
-    constexpr int lds = ScreenCfg<G, NRV>::LDS_BYTES;
-    hipLaunchKernelGGL((scan_screen_kernel<G, EXP, PRE, NRV, NT>), dim3(p->grid), dim3(256), lds, s, *p);
+    constexpr int lds = ScreenCfg<G, NRV, NW>::LDS_BYTES;
+    hipLaunchKernelGGL((scan_screen_kernel<G, EXP, PRE, NRV, NT, NW>), dim3(p->grid), dim3(64 * NW), lds, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
@@ -529,7 +539,10 @@ int rmu_screen_plan(ScanLaunch* p) {
     static const int force_g = getenv("RMU_SCREEN_G") ? atoi(getenv("RMU_SCREEN_G")) : 0;
     p->qg = force_g == 1 || force_g == 2 ? force_g : (p->nq > 128 ? 2 : 1);
     p->wq = 4; p->kv = 0;
-    const int qwg = 128 * p->qg;
+    // full query tiles (> 128 queries): 8 waves x 32 queries (two waves per SIMD) instead of 4 x 64 -- RMU_SCREEN_W8=0 keeps the 4-wave form
+    static const int w8 = getenv("RMU_SCREEN_W8") ? atoi(getenv("RMU_SCREEN_W8")) : 1;
+    if (w8 && p->qg == 2 && !force_g) { p->qg = 1; p->wq = 8; }
+    const int qwg = p->wq == 8 ? 256 : 128 * p->qg;
     p->nqt = (p->nq + qwg - 1) / qwg;
     const int64_t tiles_total = (p->n_rows + S_RT - 1) / S_RT;
     int best_s = 8;
@@ -551,13 +564,14 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->parts = s;
     static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
-    p->lds_bytes = rmu_screen_lds_bytes(p->qg);
+    p->lds_bytes = p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
     return RMU_OK;
 }
 
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;   // timing ablations, wrong results
     static const int pre = getenv("RMU_SCREEN_SPRE") ? atoi(getenv("RMU_SCREEN_SPRE")) : 4;
+    if (p->wq == 8) return p->dbg ? screen_launch_cfg<1, 4, 4, 0, 0, 8>(p, s) : screen_launch_cfg<1, 0, 4, 0, 0, 8>(p, s);
     if (p->dbg) {
         if (p->qg == 2 && ex == 8) return screen_launch_cfg<2, 12>(p, s);
         if (p->qg == 2 && ex == 9) return screen_launch_cfg<2, 13>(p, s);

@@ -12,8 +12,9 @@ Behaviour restated from the pinned dependencies:
 What the checkpoint directory declares is read by `ragmeup_amd.checkpoint`, never assumed; with a bare `encoder=`
 (no directory) the all-MiniLM-L6-v2 settings BASELINE.json names apply: mean pooling, Normalize, max_seq_length 256.
 
-Sequences are length-sorted and batched by a token budget (sentence-transformers sorts by length too); the
-packed-token kernels spend no FLOPs on padding.  Token ids stay in numpy arrays from `rmu_tok_encode` to
+Sequences are length-sorted and batched by a token budget (sentence-transformers sorts by length too; 1M padded tokens per
+forward = ~9 GB of bf16 workspace of the 288 GB: an 8192-text pipeline block is ONE forward, which is where the fused
+kernels are efficient); the packed-token kernels spend no FLOPs on padding.  Token ids stay in numpy arrays from `rmu_tok_encode` to
 `rmu_bert_encode`: no per-text Python lists on the indexing path.
 
 A tokenizer needs a vocabulary, which does not exist offline in the build image: pass `tokenizer=` (any
@@ -48,7 +49,7 @@ class _EncoderBase:
     _default_max_seq_length = 256
 
     def __init__(self, encoder: BertEncoder | None = None, model_dir: str | None = None, tokenizer: Any = None,
-                 max_seq_length: int | None = None, token_budget: int = 262144, device: int = 0):
+                 max_seq_length: int | None = None, token_budget: int = 1 << 20, device: int = 0):
         self.spec = None
         if encoder is None:
             if model_dir is None:
@@ -200,8 +201,25 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
     def embed_documents(self, texts: list[str]) -> list[list[float]]:
         return self.embed_documents_array(texts).tolist()
 
+    def _embed_query_fast(self, text: str):
+        """One query of up to 256 tokens through the graph-replayed host entry point (rmu_bert_encode_host): the reference's
+        per-request pattern (one embed_query per /chat call, server/RAGHelper.py:497-499) is launch-bound.  None when this object
+        is not backed by the native encoder + tokenizer (subclasses that only override embed_documents keep working)."""
+        enc = getattr(self, "encoder", None)
+        if not isinstance(enc, BertEncoder) or getattr(self, "tokenizer", None) is None:
+            return None
+        ids, lens = self._tokenize([text])
+        if ids.shape[1] > enc.SMALL_TOKENS:
+            return self.embed_id_arrays(ids, lens).cpu().numpy()[0]
+        return enc.encode_host(ids, lens, None, self._mode)[0]
+
+    def embed_query_array(self, text: str) -> np.ndarray:
+        v = self._embed_query_fast(text)
+        return v if v is not None else np.asarray(self.embed_documents([text])[0], dtype=np.float32)
+
     def embed_query(self, text: str) -> list[float]:
-        return self.embed_documents([text])[0]
+        v = self._embed_query_fast(text)
+        return v.tolist() if v is not None else self.embed_documents([text])[0]
 
     def token_embeddings_ids(self, ids: np.ndarray, lens: np.ndarray):
         """Final hidden state of every token (sentence-transformers output_value="token_embeddings"): one batch, packed

@@ -303,6 +303,8 @@ class MI355XVectorStore(VectorStore):
         return np.asarray(self._embeddings.embed_documents(texts), dtype=np.float32)
 
     def _embed_query(self, text: str) -> np.ndarray:
+        if hasattr(self._embeddings, "embed_query_array"):         # our Embeddings: no Python float list in between
+            return np.asarray(self._embeddings.embed_query_array(text), dtype=np.float32)
         return np.asarray(self._embeddings.embed_query(text), dtype=np.float32)
 
     def _doc(self, row: int) -> Document:

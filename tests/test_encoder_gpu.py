@@ -244,3 +244,50 @@ def test_every_switchable_kernel_variant_keeps_parity(env):
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["finite"] and res["min_cos"] >= 0.999 and res["norm_err"] < 1e-5, res
     assert res["max_tok_rel"] <= 2e-2 and res["min_centred_cos"] >= 0.99, res
+
+
+def test_host_entry_point_replays_a_graph_and_matches_the_device_path(bi, cross):
+    """rmu_bert_encode_host (the interactive path: embed_query, a few pairs; batch * L <= 256): first call of a shape eager, second
+    captured, later ones replayed -- every one of them must equal rmu_bert_encode on the same ids bit for bit (same kernels), for
+    several shapes, both heads, and again after a bulk encode has re-allocated the workspace the captured launches point into."""
+    enc, w = bi
+    ce, _ = cross
+    rng = np.random.default_rng(4)
+    shapes = [(1, 12), (1, 31), (3, 40), (1, 256), (16, 16)]
+    cases = []
+    for n, L in shapes:
+        lens = rng.integers(2, L + 1, n).astype(np.int32); lens[0] = L
+        ids = rng.integers(1000, 30522, (n, L)).astype(np.int32)
+        ids[:, 0] = 101
+        ids[np.arange(n), lens - 1] = 102
+        cases.append((ids, lens))
+    for rep in range(4):                                                       # eager, capture, replay, replay
+        for ids, lens in cases:
+            for mode in (0, 2, 0x100, 3):
+                want = enc.encode_ids(ids, lens, None, mode=mode).cpu().numpy()
+                got = enc.encode_host(ids, lens, None, mode=mode)
+                assert got.shape == want.shape and np.array_equal(got, want), (rep, ids.shape, mode)
+        if rep == 1:                                                           # workspace growth drops the captured graphs
+            big_ids, _, big_lens = synth_tokens(64, seed=3, lmax=128, mean=100, std=20)
+            enc.encode_ids(big_ids, big_lens, None, mode=0)
+    ids, tt, lens = synth_tokens(2, seed=9, lmin=20, lmax=120, mean=90, std=20, pair=True)
+    for rep in range(3):
+        assert np.array_equal(ce.encode_host(ids, lens, tt, mode=1), ce.encode_ids(ids, lens, tt, mode=1).cpu().numpy())
+    with pytest.raises(Exception):
+        enc.encode_host(np.zeros((2, 200), np.int32), np.array([200, 200], np.int32))          # 400 tokens: not the small path
+
+
+def test_embed_query_takes_the_host_path_and_equals_embed_documents(bi, tmp_path):
+    from ragmeup_amd.embeddings import MI355XEmbeddings
+    from ragmeup_amd.tokenizer import WordPieceTokenizer
+    from tests.helpers import synth_texts, synth_vocab
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(synth_vocab()) + "\n", encoding="utf-8")
+    emb = MI355XEmbeddings(encoder=bi[0], tokenizer=WordPieceTokenizer(str(vp)), max_seq_length=256)
+    texts = synth_texts(6, seed=1, wmin=4, wmax=30)
+    docs = emb.embed_documents_array(texts)
+    for rep in range(3):
+        for i, t in enumerate(texts):
+            qv = np.asarray(emb.embed_query(t), np.float32)
+            assert np.abs(qv - docs[i]).max() < 2e-3 and float((qv * docs[i]).sum()) > 0.9999    # batch of 6 vs batch of 1: bf16 noise only
+            assert np.array_equal(qv, emb.embed_query_array(t))
