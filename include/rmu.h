@@ -186,7 +186,11 @@ int rmu_bert_free(rmu_bert_t* m);
                                 * packed rows, sequence b at rows [sum(len[<b]), +len[b]), len = min(lens, max_len)
                                 *                                              -> out_dev fp32 [sum len, out_stride] */
 #define RMU_BERT_NO_NORMALIZE 0x100 /* OR-ed into POOL_MEAN / POOL_CLS: the checkpoint has no Normalize module */
-/* ids/type_ids: device int32 [batch, max_len] (row padded), lens: device int32 [batch]. */
+/* ids/type_ids: device int32 [batch, max_len] (row padded), lens: device int32 [batch].
+ * Rounding and batch shape: activations are bf16, and which kernels serve a call depends on batch * max_len (<= 256 tokens: the
+ * small-batch GEMMs; <= 16384: the GEMM pair; above: the fused FFN kernel) -- a sequence's result is bit-identical across
+ * calls that take the same kernels and equal up to bf16 rounding noise (|d| < 2e-3 on unit vectors, cosine > 0.9999)
+ * otherwise: a query embedded alone reproduces the vector its text got at indexing time to that noise, not bit for bit. */
 int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens,
                     int batch, int max_len, int mode, float* out_dev, int64_t out_stride,
                     uint64_t hip_stream);

@@ -657,6 +657,9 @@ static const int kScreenKp = 32;     // K': candidates the screening pass keeps 
 
 static u64* g_dbg = nullptr;         // RMU_SCAN_EXP=7: cycle / event counters of the scan kernels (diagnostics only)
 static u64* dbg_buffer() {
+#ifndef RMU_DEBUG_KERNELS
+    return nullptr;          // the counter instantiations exist only in a --debug-kernels build
+#endif
     static std::once_flag once;
     std::call_once(once, [] {
         if (getenv("RMU_SCAN_EXP") && atoi(getenv("RMU_SCAN_EXP")) == 7) (void)hipMalloc((void**)&g_dbg, 128);

@@ -569,9 +569,11 @@ int rmu_screen_plan(ScanLaunch* p) {
 }
 
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
-    static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;   // timing ablations, wrong results
+#ifdef RMU_DEBUG_KERNELS      // timing ablations, ring / prefetch depth experiments, cycle counters (wrong results by design for EXP != 0):
+                              // python -m ragmeup_amd.build --debug-kernels; tools/ablate_screen.sh
+    static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;
     static const int pre = getenv("RMU_SCREEN_SPRE") ? atoi(getenv("RMU_SCREEN_SPRE")) : 4;
-    if (p->wq == 8) return p->dbg ? screen_launch_cfg<1, 4, 4, 0, 0, 8>(p, s) : screen_launch_cfg<1, 0, 4, 0, 0, 8>(p, s);
+    if (p->wq == 8 && p->dbg) return screen_launch_cfg<1, 4, 4, 0, 0, 8>(p, s);
     if (p->dbg) {
         if (p->qg == 2 && ex == 8) return screen_launch_cfg<2, 12>(p, s);
         if (p->qg == 2 && ex == 9) return screen_launch_cfg<2, 13>(p, s);
@@ -592,8 +594,10 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
         if (nrv == 5) return screen_launch_cfg<2, 0, 4, 5>(p, s);
         if (pre == 6) return screen_launch_cfg<2, 0, 6>(p, s);
         if (pre == 3) return screen_launch_cfg<2, 0, 3>(p, s);
-        return screen_launch_cfg<2>(p, s);
     }
+#endif
+    if (p->wq == 8) return screen_launch_cfg<1, 0, 4, 0, 0, 8>(p, s);                 // full query tiles: 8 waves x 32 queries
+    if (p->qg == 2) return screen_launch_cfg<2>(p, s);                                // RMU_SCREEN_W8=0 / RMU_SCREEN_G=2: 4 waves x 64 queries
     return p->nt ? screen_launch_cfg<1, 0, 4, 0, 1>(p, s) : screen_launch_cfg<1>(p, s);
 }
 

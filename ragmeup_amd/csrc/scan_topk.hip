@@ -446,6 +446,7 @@ template <int D>
 int launch_d(const ScanLaunch* p, hipStream_t s) {
     switch (p->wq * 2 + p->kv) {
         case 8: {
+#ifdef RMU_DEBUG_KERNELS      // timing ablations / cycle counters (wrong results by design): python -m ragmeup_amd.build --debug-kernels
             static const int exp = getenv("RMU_SCAN_EXP") ? atoi(getenv("RMU_SCAN_EXP")) : 0;
             if (D == 384 && exp == 1) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 1>>(p, s);
             if (D == 384 && exp == 2) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 2>>(p, s);
@@ -454,6 +455,7 @@ int launch_d(const ScanLaunch* p, hipStream_t s) {
             if (D == 384 && exp == 5) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 5>>(p, s);
             if (D == 384 && exp == 6) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 6>>(p, s);
             if (D == 384 && exp == 7) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 7>>(p, s);
+#endif
             return launch_cfg<C_w4_k0<D>>(p, s);
         }
         case 9: return launch_cfg<C_w4_k1<D>>(p, s);

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Timing ablations of scan_screen_kernel.  Run ON THE GPU BOX:  gpurun -- 'bash tools/ablate_screen.sh'
+# Timing ablations of scan_screen_kernel.  Needs the debug instantiations: build with
+#   python -m ragmeup_amd.build --debug-kernels      (then rebuild the product library: python -m ragmeup_amd.build --force)
+# and force the 4-wave form the table was measured on: RMU_SCREEN_W8=0.  Run ON THE GPU BOX:  gpurun -- 'bash tools/ablate_screen.sh'
 # RMU_SCREEN_EXP bits: 1 = no corpus LDS-DMA, 2 = no LDS fragment reads, 8 = no filter compares (results are wrong by design);
 # RMU_SCREEN_NOFILTER=1 skips the candidate appends; RMU_SCAN_EXP=7 selects the build with cycle counters (clock64 per wave).
 # Prints, for the largest row range of the 10M x 1024 ladder: wall time of the launch (rocprofv3), cycles per wave, clock.

@@ -1,5 +1,5 @@
 """Static resource table of every kernel in librmu.so (no GPU needed): compiles each .hip for gfx950 to assembly and reads
-the code-object metadata -> profiles/r01_kernel_resources.md (arch VGPRs = unified count minus AGPRs, AGPRs, SGPRs, scratch bytes per lane, static LDS).
+the code-object metadata -> profiles/<round>_kernel_resources.md (python tools/kernel_resources.py r03) (arch VGPRs = unified count minus AGPRs, AGPRs, SGPRs, scratch bytes per lane, static LDS).
 Dynamic LDS (the scan kernels' rings and candidate slots) is a launch parameter: see rmu_last_scan_geometry / DESIGN.md."""
 import glob
 import os
@@ -30,7 +30,7 @@ for src in sorted(glob.glob(os.path.join(root, "ragmeup_amd", "csrc", "*.hip")))
         rows.append((os.path.basename(src), dem[:96], tot - ag if tot >= ag else tot, ag, k.get(".sgpr_count", "?"),
                      k.get(".private_segment_fixed_size", "?"), k.get(".group_segment_fixed_size", "?")))
 rows.sort()
-path = os.path.join(root, "profiles", "r01_kernel_resources.md")
+path = os.path.join(root, "profiles", (sys.argv[1] if len(sys.argv) > 1 else "r03") + "_kernel_resources.md")
 with open(path, "w") as o:
     o.write("# Kernel resources (gfx950 code-object metadata; produced by `tools/kernel_resources.py`, no GPU needed)\n\n")
     o.write("`scratch` = private segment bytes per lane (non-zero = register spills); `LDS` = static only (the scan kernels' rings are dynamic).\n\n")

@@ -12,15 +12,15 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02p"
-RP = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03p"
+RP = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src = f"gpurun_out/{tag}"
 STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.py then repeats 10 searches with per-launch events (roofline pass)
 
 
 def short(n):
     m = re.search(r'(scan_topk_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
-                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn_fused|k_gemm<\d, \d, \d+, \d>|k_attention2|k_attention|k_layernorm|k_embed_ln|k_meanpool_l2|k_cls_head)', n)
+                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn2|k_ffn_fused|k_gemm3|k_gemm_small|k_gemm<\d, \d, \d+, \d>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
     s = m.group(1) if m else n[:40]
     if s in ('scan_topk_kernel',):
         c = re.search(r'Cfg<([^>]*)>', n)
@@ -108,7 +108,7 @@ txt = [
     stats('scan_b1', 'HBM-bound regime: batch 1, default path (fp16 image, 768 B per row, screening ladder with ratio 8)'),
     stats('exact_b1', 'batch 1 forced onto the exact fp32 scan (`RMU_SCREEN=0`, WQ=1 geometry)'),
     stats('scan_b32', 'north-star regime: batch 32 over 10M rows, default path (fp16 image, nt stream, ladder ratio 8)'),
-    stats('embed', 'encoder: 8192-chunk calls x ~128 tokens (BERT-6x384, bf16 MFMA; fused FFN kernel)'),
+    stats('embed', 'encoder: 8192-chunk calls x ~128 tokens (BERT-6x384, bf16 MFMA; k_ffn2 / k_attn3 / k_gemm3 / k_gemm)'),
     "## PMC passes (separate runs, `--kernel-trace --pmc ...` only)\n",
     line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK), line('exact_pmc_b1', B1), line('pmc_b32', SK),
     "\n## Derived (FETCH_SIZE is in KiB and under-reports by 2x on gfx950 per MI355X_MICROARCH.md -> bytes = FETCH_SIZE x 1024 x 2)\n",
@@ -124,5 +124,45 @@ txt = [
     f"- batch 1, exact scan: HBM fetch {f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
 ]
 open(f'profiles/{RP}_summary.md', 'w').write("\n".join(txt) + "\n")
+# C5's dense part and the encoder PMC pass (optional outputs of tools/profile.sh)
+if os.path.exists(f'{src}/top100_stats.csv'):
+    shutil.copy(f'{src}/top100_stats.csv', f'profiles/{RP}_top100_stats.csv')
+    if os.path.exists(f'{src}/top100_probe.txt'):
+        shutil.copy(f'{src}/top100_probe.txt', f'profiles/{RP}_top100_probe.txt')
+if os.path.exists(f'{src}/enc_pmc_counters.csv'):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f'{src}/enc_pmc_counters.csv')):
+        n = r['Kernel_Name']
+        kn = next((k for k in ('k_ffn2', 'k_gemm3', 'k_attn3', 'k_gemm_small', 'k_gemm') if k in n), n[:30])
+        acc[kn][r['Counter_Name']].append(float(r['Counter_Value']))
+    cn = ['GRBM_GUI_ACTIVE', 'SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_BUSY_CYCLES']
+    ks = [k for k in ('k_ffn2', 'k_gemm3', 'k_gemm', 'k_attn3') if k in acc]
+    m = {k: {c: sum(v) / len(v) for c, v in acc[k].items()} for k in ks}
+    out = [f"# Encoder kernels: PMC pass (round {int(RP[1:])})\n",
+           "`rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU "
+           "SQ_INSTS_MFMA --kernel-include-regex \"k_ffn2|k_gemm3|k_attn3|k_gemm\" -- python tools/enc_smoke.py 2048` (tools/profile.sh); 2048 chunks (~262 k tokens), "
+           "means over the 6 launches (one per layer) of each kernel; raw sums over the chip (GRBM_GUI_ACTIVE summed over the 8 XCDs; SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / "
+           "SQ_ACTIVE_INST_ANY in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles: MI355X_MICROARCH.md).\n",
+           "| counter | " + " | ".join(f"`{k}`" for k in ks) + " |", "|---|" + "---|" * len(ks)]
+    for c in cn:
+        out.append(f"| {c} | " + " | ".join(f"{m[k].get(c, float('nan')):,.0f}".replace(",", " ") for k in ks) + " |")
+    out += ["\nDerived (1024 SIMDs; kernel cycles = GRBM_GUI_ACTIVE / 8):\n", "| | " + " | ".join(f"`{k}`" for k in ks) + " |", "|---|" + "---|" * len(ks)]
+    cyc = {k: m[k]['GRBM_GUI_ACTIVE'] / 8 for k in ks}
+    out.append("| kernel cycles | " + " | ".join(f"{cyc[k] / 1e6:.3f} M" for k in ks) + " |")
+    out.append("| MFMA pipe busy = MFMA_BUSY / 1024 / cycles | " + " | ".join(f"**{m[k]['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / cyc[k]:.3f}**" for k in ks) + " |")
+    out.append("| VALU instructions per MFMA (INSTS_VALU counts the MFMAs too) | " + " | ".join(f"{m[k]['SQ_INSTS_VALU'] / max(m[k]['SQ_INSTS_MFMA'], 1):.1f}" for k in ks) + " |")
+    out.append("| share of wave time waiting (WAIT_INST_ANY / WAVE_CYCLES) | " + " | ".join(f"{m[k]['SQ_WAIT_INST_ANY'] / m[k]['SQ_WAVE_CYCLES']:.2f}" for k in ks) + " |")
+    out.append("| share of wave time with an instruction active | " + " | ".join(f"{m[k]['SQ_ACTIVE_INST_ANY'] / m[k]['SQ_WAVE_CYCLES']:.2f}" for k in ks) + " |")
+    out.append("| resident waves per SIMD = WAVE_CYCLES x 4 / 1024 / cycles | " + " | ".join(f"{m[k]['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc[k]:.2f}" for k in ks) + " |")
+    open(f'profiles/{RP}_encoder_pmc.md', 'w').write("\n".join(out) + "\n")
+# what bench.py reports as roofline.traffic: HBM bytes per bench step of exactly these configurations, from THIS round's passes
+json.dump({"source": f"tools/profile.sh {tag} -> tools/summarize_profiles.py: sum per bench step over the launches of (2 x FETCH_SIZE [gfx950 correction] "
+                     f"+ WRITE_SIZE where collected) x 1024, profiles/{RP}_pmc_means.csv",
+           "entries": [{"path": "screen", "rows": 10_000_000, "batch": 1024, "bytes_per_step": scr_fetch + scr_write},
+                       {"path": "screen", "rows": 10_000_000, "batch": 32, "bytes_per_step": f('pmc_b32', SK, 'FETCH_SIZE') * 2048},
+                       {"path": "screen", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('pmc_b1', SK, 'FETCH_SIZE') * 2048},
+                       {"path": "exact", "rows": 10_000_000, "batch": 1024, "bytes_per_step": f('exact_pmc_b', EK, 'FETCH_SIZE') * 2048},
+                       {"path": "exact", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('exact_pmc_b1', B1, 'FETCH_SIZE') * 2048}]},
+          open(f'profiles/{RP}_traffic.json', 'w'), indent=1)
 print("\n".join(txt[-4:]))
 print("SCREEN_TRAFFIC =", scr_fetch + scr_write, "B1 screen", f('pmc_b1',SK,'FETCH_SIZE')*2048, "B32 screen", f('pmc_b32',SK,'FETCH_SIZE')*2048, "exact", f('exact_pmc_b',EK,'FETCH_SIZE')*2048, "exact B1", f('exact_pmc_b1',B1,'FETCH_SIZE')*2048)
