@@ -118,6 +118,14 @@ class _EncoderBase:
         if n == 0:
             return out
         lens = np.minimum(np.asarray(lens, dtype=np.int32), min(ids.shape[1], self.max_seq_length))
+        Lmax = max(1, int(lens.max()))
+        if n * Lmax <= self.token_budget and n <= 65535:
+            # the whole block is ONE forward: no length sort (the packed-token kernels spend nothing on padding; sorting only
+            # serves to cut a block into batches), no gather of the id rows, no scatter of the result rows
+            self.encoder.encode_ids(ids if ids.shape[1] == Lmax else np.ascontiguousarray(ids[:, :Lmax]), lens,
+                                    None if types is None else (types if types.shape[1] == Lmax else np.ascontiguousarray(types[:, :Lmax])),
+                                    mode=mode, out=out)
+            return out
         for idx in self._batches(lens):
             L = max(1, int(lens[idx[0]]))                          # length-sorted: the first is the longest
             res = self.encoder.encode_ids(np.ascontiguousarray(ids[idx, :L]), lens[idx],

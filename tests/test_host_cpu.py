@@ -354,19 +354,26 @@ def test_embeddings_pipeline_blocks_equal_single_pass(tmp_path, librmu):
         has_head = False
         calls = 0
 
-        def encode_ids(self, ids, lens, tt=None, mode=0):
+        def encode_ids(self, ids, lens, tt=None, mode=0, out=None):
             FakeEncoder.calls += 1
             ids = torch.as_tensor(np.asarray(ids), dtype=torch.float32)
             feat = torch.stack([ids.sum(1), (ids * torch.arange(1, ids.shape[1] + 1)).sum(1), torch.as_tensor(np.asarray(lens), dtype=torch.float32)], 1)
-            return feat.repeat(1, 128)                   # [n, 384], a deterministic function of the token ids
+            res = feat.repeat(1, 128)                    # [n, 384], a deterministic function of the token ids
+            if out is not None:
+                out.copy_(res)
+                return out
+            return res
 
     rng = np.random.default_rng(0)
     surface = ["alpha", "betas", "gamma", "deltaing", "the", "of", "unknown", "alpha,", "beta."]
     texts = [" ".join(rng.choice(surface, size=rng.integers(1, 30))) for _ in range(2500)]
     emb = MI355XEmbeddings(encoder=FakeEncoder(), tokenizer=WordPieceTokenizer(str(vp)), max_seq_length=32)
     emb.pipeline_block = 10 ** 9
-    one = emb.embed_documents_array(texts)
+    one = emb.embed_documents_array(texts)                 # one block = one forward (no length sort)
     emb.pipeline_block = 300                               # 9 blocks, the last one partial
     many = emb.embed_documents_array(texts)
     assert one.shape == (2500, 384) and np.array_equal(one, many)
+    emb.token_budget = 2000                                # a block no longer fits one forward: length-sorted batches, scattered back
+    assert np.array_equal(emb.embed_documents_array(texts), one)
+    emb.token_budget = 1 << 20
     assert emb.embed_documents(texts[:3]) == one[:3].tolist() and emb.embed_query(texts[7]) == one[7].tolist()

@@ -17,7 +17,10 @@ for n in (10_000, 1_000_000):
     e = timed(lambda: enc.encode_ids(qi, ql, None, 0, out=out), 200, 20)
     s = timed(lambda: idx.search(v, 10), 200, 20)
     b = timed(lambda: idx.search(enc.encode_ids(qi, ql, None, 0, out=out), 10), 200, 20)
-    print(f"rows {n}: encode(batch 1, 16 tokens) {e:.3f} ms   search(top-10) {s:.3f} ms   both {b:.3f} ms")
+    g = timed(lambda: enc.encode_host(qids, qlens, None, 0), 200, 20)                      # host ids -> host vector, one hipGraph replay
+    gb = timed(lambda: idx.search(enc.encode_host(qids, qlens, None, 0), 10), 200, 20)
+    print(f"rows {n}: encode(batch 1, 16 tokens) {e:.3f} ms   search(top-10) {s:.3f} ms   both {b:.3f} ms   |   "
+          f"graph-replayed host encode {g:.3f} ms   + search {gb:.3f} ms")
     idx.close()
 ids, tt, lens = synth_tokens(30, seed=9, lmin=100, lmax=190, mean=147, std=20, pair=True)
 ce = BertEncoder(bert_weights(1, True), layers=6)
