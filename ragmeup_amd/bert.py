@@ -9,6 +9,7 @@ PyTorch is used only to hold the weight / id tensors on the device; every FLOP r
 from __future__ import annotations
 
 import ctypes
+import threading
 import os
 from typing import Mapping
 
@@ -88,6 +89,8 @@ class BertEncoder:
         h = ctypes.c_void_p()
         N.check(self._lib.rmu_bert_create(ctypes.byref(h), ctypes.byref(cfg), ptrs, len(tens)), "rmu_bert_create")
         self._h = h
+        self._lock = threading.Lock()              # one forward at a time per encoder (the library serialises them anyway)
+        self._stage = {}                           # slot -> (pinned host int32, device int32) staging pair
         self.max_pos = int(tens[1].shape[0])
         self.vocab_size = int(tens[0].shape[0])
         del tens                                   # the library keeps its own (bf16 / fp32) copies
@@ -151,16 +154,44 @@ class BertEncoder:
         (torch CUDA); MODE_CE -> [B] fp32 logits; MODE_TOKENS -> [sum(min(lens, L)), 384] fp32, sequences packed in batch order.
         `out` may be a pre-allocated CUDA tensor (e.g. a slice of a corpus matrix)."""
         torch = self._torch
-        ids_t = torch.as_tensor(ids).to(self.device, torch.int32).contiguous()
-        lens_t = torch.as_tensor(lens).to(self.device, torch.int32).contiguous()
-        tt_t = None if type_ids is None else torch.as_tensor(type_ids).to(self.device, torch.int32).contiguous()
+        with self._lock:
+            return self._encode_ids_locked(ids, lens, type_ids, mode, out)
+
+    def _stage_in(self, a, slot: str):
+        """HOST array -> device int32 through this encoder's pinned staging buffer.  A transient pageable buffer handed to the
+        runtime gets registered with the GPU for the copy; freeing it (munmap) then invalidates the registration through the
+        kernel driver, which stalls the device queues for ~90 ms at unpredictable later points (measured: add_documents in
+        1000-text calls, 28k instead of 180k chunks/s).  Pinned staging never registers anything."""
+        torch = self._torch
+        if torch.is_tensor(a):
+            if a.is_cuda:
+                return a.to(self.device, torch.int32).contiguous()
+            a = a.numpy()
+        a = np.asarray(a)
+        n = a.size
+        st = self._stage.get(slot)
+        if st is None or st[0].numel() < n:
+            cap = max(n + n // 4, 1 << 16)
+            st = (torch.empty(cap, dtype=torch.int32).pin_memory(), torch.empty(cap, dtype=torch.int32, device=self.device))
+            self._stage[slot] = st
+        if n:
+            np.copyto(st[0][:n].numpy().reshape(a.shape), a, casting="unsafe")     # strided views and int64 copy straight in
+            st[1][:n].copy_(st[0][:n], non_blocking=True)       # complete before this call returns: encode_ids synchronises
+        return st[1][:n].view(a.shape)
+
+    def _encode_ids_locked(self, ids, lens, type_ids, mode, out):
+        torch = self._torch
+        lens_host = None if torch.is_tensor(lens) else np.asarray(lens)
+        ids_t = self._stage_in(ids, "ids")
+        lens_t = self._stage_in(lens, "lens")
+        tt_t = None if type_ids is None else self._stage_in(type_ids, "types")
         B, L = ids_t.shape
         kind = mode & 0xff
         if out is None:
             if kind == MODE_CE:
                 shape = (B,)
             elif kind == MODE_TOKENS:
-                n_tok = int(np.minimum(np.maximum(np.asarray(lens.cpu() if torch.is_tensor(lens) else lens, dtype=np.int64), 0), L).sum())
+                n_tok = int(np.minimum(np.maximum(np.asarray(lens.cpu() if lens_host is None else lens_host, dtype=np.int64), 0), L).sum())
                 shape = (n_tok, self.HIDDEN)
             else:
                 shape = (B, self.HIDDEN)

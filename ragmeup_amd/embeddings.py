@@ -99,6 +99,9 @@ class _EncoderBase:
         tt = _pad(enc["token_type_ids"], max_len=self.max_seq_length)[0] if want_types else None
         return ids, tt, lens
 
+    #: a block that fits the token budget runs as one forward in input order (no length sort)
+    one_forward = True
+
     def _batches(self, lens: np.ndarray):
         """Length-sorted batches under a token budget: yields index arrays (into the original order)."""
         order = np.argsort(-lens, kind="stable")
@@ -119,17 +122,14 @@ class _EncoderBase:
             return out
         lens = np.minimum(np.asarray(lens, dtype=np.int32), min(ids.shape[1], self.max_seq_length))
         Lmax = max(1, int(lens.max()))
-        if n * Lmax <= self.token_budget and n <= 65535:
+        if self.one_forward and n * Lmax <= self.token_budget and n <= 65535:
             # the whole block is ONE forward: no length sort (the packed-token kernels spend nothing on padding; sorting only
             # serves to cut a block into batches), no gather of the id rows, no scatter of the result rows
-            self.encoder.encode_ids(ids if ids.shape[1] == Lmax else np.ascontiguousarray(ids[:, :Lmax]), lens,
-                                    None if types is None else (types if types.shape[1] == Lmax else np.ascontiguousarray(types[:, :Lmax])),
-                                    mode=mode, out=out)
+            self.encoder.encode_ids(ids[:, :Lmax], lens, None if types is None else types[:, :Lmax], mode=mode, out=out)
             return out
         for idx in self._batches(lens):
             L = max(1, int(lens[idx[0]]))                          # length-sorted: the first is the longest
-            res = self.encoder.encode_ids(np.ascontiguousarray(ids[idx, :L]), lens[idx],
-                                          None if types is None else np.ascontiguousarray(types[idx, :L]), mode=mode)
+            res = self.encoder.encode_ids(ids[idx, :L], lens[idx], None if types is None else types[idx, :L], mode=mode)
             out[torch.as_tensor(idx, device=out.device, dtype=torch.long)] = res
         return out
 

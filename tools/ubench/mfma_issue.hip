@@ -98,6 +98,38 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters, con
 static char* g_w = nullptr;
 static const unsigned int WBYTES = 2359296;       // the FFN weights of one layer (bf16)
 
+#define REP6(X) X(0) X(1) X(2) X(3) X(4) X(5)
+// the FFN skeleton (+ five v_fma_f32 per MFMA when VALU) with 6 accumulators: <= 128 registers, so NW = 4 (one wave per SIMD) and
+// NW = 8 (two per SIMD) run the same instruction stream per wave; DMA pieces per wave scale so that a workgroup moves 3 KiB per
+// 6 MFMA steps of every wave either way
+template <int NW, int VALU>
+__global__ __launch_bounds__(64 * NW) void k2(unsigned long long* out, int iters, const char* w, unsigned int wbytes) {
+    unsigned long long t0 = 0, t1 = 0;
+    const unsigned int lds_base = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) char*)lds_ + (threadIdx.x >> 6) * 1024u;
+    unsigned int voff = (threadIdx.x & 63) * 16u + (threadIdx.x >> 6) * 1024u;
+    unsigned int slot = 0;
+    asm volatile("v_mov_b32 v0, 0\n v_mov_b32 v1, 0\n v_mov_b32 v2, 0\n v_mov_b32 v3, 0\n v_mov_b32 v4, 0\n v_mov_b32 v5, 0\n v_mov_b32 v6, 0\n v_mov_b32 v7, 0\n"
+                 "v_mov_b32 v8, 0\n v_mov_b32 v9, 0\n v_mov_b32 v10, 0\n v_mov_b32 v11, 0\n v_mov_b32 v12, 0"
+                 ::: "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12");
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0));
+    for (int i = 0; i < iters; ++i) {
+#define STEP(j) asm volatile("s_waitcnt lgkmcnt(3)\n v_mfma_f32_32x32x16_bf16 a[%c0:%c1], v[0:3], v[4:7], a[%c0:%c1]\n ds_read_b128 v[16:19], v12" ::"i"(16 * j), "i"(16 * j + 15)); \
+        if (VALU) asm volatile("v_fma_f32 v8, v8, v8, v8\n v_fma_f32 v9, v9, v9, v9\n v_fma_f32 v10, v10, v10, v10\n v_fma_f32 v11, v11, v11, v11\n v_fma_f32 v8, v8, v8, v8"); \
+        if ((j % (NW == 8 ? 6 : 3)) == 0) { \
+            asm volatile("s_mov_b32 m0, %1\n s_nop 0\n global_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(__builtin_amdgcn_readfirstlane((int)(lds_base + slot * 24576u))), "s"(w) : "memory"); \
+            voff += 1024u * NW; if (voff >= wbytes) voff -= wbytes; \
+        }
+        REP6(STEP)
+        REP6(STEP)
+#undef STEP
+        slot = slot == 4 ? 0 : slot + 1;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n s_nop 15\n s_nop 15\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1));
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * NW + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 template <int V>
 static void run(const char* name, unsigned long long* d, int iters) {
     const int grid = 256;
@@ -122,9 +154,32 @@ static void run(const char* name, unsigned long long* d, int iters) {
     printf("%-64s %7.1f memtime ticks / MFMA   %7.3f ms   %7.1f TFLOP/s  (=> %.1f ns / MFMA / SIMD)\n", name, per, ms, tf, ms * 1e6 / ((double)iters * 12));
 }
 
+template <int NW, int VALU>
+static void run2(const char* name, unsigned long long* d, int iters) {
+    const int grid = 256, lds = 5 * 24576;
+    hipFuncSetAttribute((const void*)k2<NW, VALU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((k2<NW, VALU>), dim3(grid), dim3(64 * NW), lds, 0, d, 8, g_w, WBYTES);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k2<NW, VALU>), dim3(grid), dim3(64 * NW), lds, 0, d, iters, g_w, WBYTES);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(grid * NW);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    double s = 0;
+    for (auto v : h) s += (double)v;
+    const double per_wave = s / h.size() / ((double)iters * 12);
+    const double tf = (double)grid * NW * iters * 12 * 32768.0 / (ms * 1e-3) / 1e12;
+    printf("%-64s %7.1f ticks / MFMA / wave = %5.1f per SIMD   %7.3f ms   %7.1f TFLOP/s\n", name, per_wave, per_wave / (NW / 4), ms, tf);
+}
+
 int main() {
     unsigned long long* d;
-    hipMalloc(&d, 1024 * 4 * 8);
+    hipMalloc(&d, 1024 * 8 * 8);
     hipMalloc((void**)&g_w, WBYTES + 8192);
     hipMemset(g_w, 0x3c, WBYTES + 8192);
     const int iters = 20000;
@@ -143,5 +198,9 @@ int main() {
     run<12>("FFN skeleton without the barrier", d, iters);
     run<13>("plain 12-acc stream, NON-ZERO operands", d, iters);
     run<14>("FFN skeleton + 5 v_fma_f32, NON-ZERO operands", d, iters);
+    run2<4, 0>("6-acc skeleton, 4 waves (1 per SIMD)", d, iters);
+    run2<8, 0>("6-acc skeleton, 8 waves (2 per SIMD)", d, iters);
+    run2<4, 1>("6-acc skeleton + 5 v_fma_f32, 4 waves (1 per SIMD)", d, iters);
+    run2<8, 1>("6-acc skeleton + 5 v_fma_f32, 8 waves (2 per SIMD)", d, iters);
     return 0;
 }
