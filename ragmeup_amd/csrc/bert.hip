@@ -118,6 +118,31 @@ __global__ void k_permute_w2(const bf16* __restrict__ src, bf16* __restrict__ ds
     dst[i] = src[blk + (e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4))];
 }
 
+// Weight streams for k_ffn3: the very slab images its LDS slots hold, in stream order, so that a DMA wave instruction reads 1 KiB of
+// contiguous bytes and the 2-3 instructions a wave issues per slab differ only by the instruction's immediate offset.
+//   W1 stream: [chunk c][slab i] 16 KiB = [64 rows][16 units]; physical unit pu of row r holds logical lu = pu ^ (r & 15);
+//              lu < 8: k [64 i + 8 lu, +8), lu >= 8: k [192 + 64 i + 8 (lu - 8), +8) of W1 row 64 c + r
+//   W2 stream: [chunk c][tile t] 24 KiB = [384 rows][4 units]; pu of row r holds lu = pu ^ ((r >> 2) & 3): k [64 c + 32 t + 8 lu, +8) of
+//              the k_permute_w2 copy's row r
+#ifdef RMU_DEBUG_KERNELS
+__global__ void k_pack_ffn3(const bf16* __restrict__ w1, const bf16* __restrict__ w2p, bf16* __restrict__ w1s, bf16* __restrict__ w2s) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n1 = (int64_t)FF * H / 8;
+    if (d < n1) {
+        const int slab = (int)(d >> 10), within = (int)(d & 1023), c = slab / 3, i = slab % 3;
+        const int r = within >> 4, pu = within & 15, lu = pu ^ (r & 15);
+        const int k0 = lu < 8 ? 64 * i + 8 * lu : 192 + 64 * i + 8 * (lu - 8);
+        *(bf16x8*)(w1s + d * 8) = *(const bf16x8*)(w1 + (int64_t)(64 * c + r) * H + k0);
+    } else if (d < 2 * n1) {
+        const int64_t e = d - n1;
+        const int slab = (int)(e / 1536), within = (int)(e % 1536), c = slab >> 1, t = slab & 1;
+        const int r = within >> 2, pu = within & 3, lu = pu ^ ((r >> 2) & 3);
+        *(bf16x8*)(w2s + e * 8) = *(const bf16x8*)(w2p + (int64_t)r * FF + 64 * c + 32 * t + 8 * lu);
+    }
+}
+
+#endif
+
 // Weight copy for k_gemm3's LDS-DMA: block (nb, kb) = rows [16 nb, +16) x k [32 kb, +32) stored as the very 1 KiB its ring
 // slot holds (row r of the block at byte 64 r, logical 16-byte unit u at physical unit u ^ ((r >> 2) & 3)), blocks in [nb][kb]
 // order: one DMA wave instruction then reads 1 KiB of CONTIGUOUS bytes (8 cache lines) instead of 16 rows x 64 B (16 lines) --
@@ -1207,6 +1232,446 @@ __global__ __launch_bounds__(256) void k_ffn2(const bf16* __restrict__ x, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_ffn3 -- the fused FFN block with TWO waves per SIMD (round 3).  tools/ubench/mfma_issue.hip: the loop skeleton of k_ffn2
+// (wait + MFMA + fragment read, LDS-DMA, vmcnt + barrier) plus five VALU instructions per MFMA runs at 66.9 cycles per MFMA
+// with one wave per SIMD and at 44.3 per SIMD with two -- the second wave issues while the first sits in a wait or a dependent
+// VALU chain.  k_ffn2's wave needs ~370 registers, so the second wave has to come from splitting its work, not from occupancy:
+//   * a workgroup is still 128 tokens, now 8 waves: waves p and p + 4 (p = 0..3) share tokens [32 p, +32);
+//   * FFN1 is split over K: wave half s keeps the token fragments of k in [192 s, +192) only (48 registers instead of 96) and
+//     produces, for both 32-feature tiles of a chunk, the partial sum over its half.  It owns tile s: the partner's partial for
+//     that tile arrives through LDS (fp32, 4 KiB per wave and chunk) and is added before the activation;
+//   * the activation is split over the feature tiles: each wave activates its own tile (16 values per lane) and publishes the
+//     bf16 B fragments (2 KiB) for both waves of the pair;
+//   * FFN2 is split over the OUTPUT features: wave half s accumulates outputs [192 s, +192) (96 registers instead of 192) over
+//     all 64 features of the chunk; the residual of exactly those outputs sits in its own token fragments.
+// Per wave and chunk: 24 + 24 MFMAs (as many per SIMD as k_ffn2), 48 fragment reads, 12 LDS-DMA instructions, 16 activations,
+// 6 + 10 exchange LDS instructions; both exchanges ride on barriers the slab stream has anyway.  The W1 slab i now holds, for
+// the chunk's 64 rows, k in [64 i, +64) and [192 + 64 i, +64) side by side (both halves work on every slab).  W1 slots are
+// 16 KiB and W2 slots 24 KiB (slot = slab index, as in k_ffn2), which leaves room for the exchange buffers: 150 KiB.
+// ------------------------------------------------------------------------------------------------------------
+namespace ffn3 {
+constexpr int TOK = 128, CH = 64, NCH = FF / CH;
+constexpr int S1 = 16 * 1024, S2 = 24 * 1024;
+constexpr int W2_OFF = 3 * S1, RING = 3 * S1 + 2 * S2;
+constexpr int B1_OFF = RING;
+constexpr int XP_OFF = B1_OFF + FF * 4;             // 8 waves x 4 KiB: the fp32 partial of the partner's tile
+constexpr int PX_OFF = XP_OFF + 8 * 4096;           // 4 pairs x 2 tiles x 2 KiB: activated B fragments
+constexpr int LDS_BYTES = PX_OFF + 8 * 2048;
+constexpr int TSTR = H * 2 + 16;
+static_assert(LDS_BYTES <= 160 * 1024 && TOK * TSTR <= LDS_BYTES, "LDS");
+// DMA instructions per wave that may still be in flight when slab i must have landed (W1 slab = 2 per wave, W2 slab = 3; issue
+// order per iteration as in k_ffn2: S4 during slab 0; S0', S1', S2' during slab 3; S3' during slab 4)
+__host__ __device__ constexpr int wait_n(int i) { return i == 0 ? 7 : i == 1 ? 8 : i == 2 ? 6 : i == 3 ? 3 : 6; }
+}  // namespace ffn3
+
+template <bool LN_IN, int PF, bool DBG, int VAR>   // VAR bit 0: activation as packed-f32 instructions (else hipcc's vector code), bit 1: k_pack_ffn3 weight streams (else W1 / W2p rows); DBG: ablation flags (RMU_FFN3_DBG, debug build): 1 no activation, 2 no fragment reads, 4 no DMA, 8 no exchange, 16 no barriers
+__global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const bf16* __restrict__ W1, const float* __restrict__ b1,
+                                              const bf16* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ g,
+                                              const float* __restrict__ bta, float eps, bf16* __restrict__ out,
+                                              const int* __restrict__ cu, int batch, const float* __restrict__ g1,
+                                              const float* __restrict__ bta1, int dflags) {
+    using namespace ffn3;
+    using ffn::static_for; using ffn::ds_read16;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const int M = cu[batch];
+    const int m0 = blockIdx.x * TOK;
+    if (m0 >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = w & 3, s = w >> 2;
+    const int r31 = lane & 31, hh = lane >> 5;
+    char* ring = gsm;
+    float* b1s = (float*)(gsm + B1_OFF);
+
+    // ---- this half's k range of the token rows as B fragments; b1 into LDS ---------------------------------------------------
+    bf16x8 hf[12];
+    {
+        const int tok = min(m0 + 32 * p + r31, M - 1);
+        const bf16* row = x + (int64_t)tok * H + s * 192 + hh * 8;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) hf[j] = *(const bf16x8*)(row + j * 16);
+    }
+    for (int i = threadIdx.x; i < FF; i += 512) b1s[i] = b1[i];
+    if (LN_IN) {
+        // h1 = bf16(LN1(y)): statistics over all 384 values of the token = this lane's 96, lane ^ 32's, and the partner wave's
+        // two lanes' (through LDS).  Same arithmetic as k_ffn2 (fp32, two passes) up to the order of the partial sums.
+        float* sc = (float*)(gsm + XP_OFF);
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm += bf2f(hf[j][e]);
+        sm += __shfl_xor(sm, 32);
+        if (hh == 0) sc[w * 32 + r31] = sm;
+        __syncthreads();
+        sm += sc[(w ^ 4) * 32 + r31];
+        const float mu = sm * (1.0f / H);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = bf2f(hf[j][e]) - mu; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 32);
+        if (hh == 0) sc[256 + w * 32 + r31] = q;
+        __syncthreads();
+        q += sc[256 + (w ^ 4) * 32 + r31];
+        const float rs = rsqrtf(q * (1.0f / H) + eps);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int f0 = s * 192 + j * 16 + hh * 8;
+            const f32x4 ga = *(const f32x4*)(g1 + f0), gb = *(const f32x4*)(g1 + f0 + 4);
+            const f32x4 ba = *(const f32x4*)(bta1 + f0), bb = *(const f32x4*)(bta1 + f0 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (bf16)((bf2f(hf[j][e]) - mu) * rs * ga[e] + ba[e]);
+                o[4 + e] = (bf16)((bf2f(hf[j][4 + e]) - mu) * rs * gb[e] + bb[e]);
+            }
+            hf[j] = o;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- slab stream: W1 / W2 are the k_pack_ffn3 streams (slab images, contiguous); wave w moves bytes [2048 w, +2048) of a W1 slab and
+    // [3072 w, +3072) of a W2 slab, 1 KiB per instruction: one LDS base (M0) and one address per slab, the pieces are immediate offsets
+    // (applied to the global and the LDS address alike) -------------------------------------------------------------------------
+    const u32 v1 = (u32)lane * 16 + (u32)w * 2048, v2 = (u32)lane * 16 + (u32)w * 3072;
+    // (VAR bit 1 clear: W1 / W2 are the row-major matrices; DMA instruction q = it * 8 + w of a slab covers LDS units [64 q, +64), the
+    // swizzle lives in the per-lane source offset -- 4 rows x 256 B resp. 16 rows x 64 B per instruction, one address + M0 per instruction)
+    u32 w1off0 = 0, w2off0 = 0;
+    if constexpr (!(VAR & 2)) {
+        const int row1 = w * 4 + (lane >> 4), lu = (lane & 15) ^ (row1 & 15);
+        w1off0 = (u32)((row1 * H + (lu & 7) * 8 + (lu >> 3) * 192) * 2);
+        const int row2 = w * 16 + (lane >> 2), p2 = lane & 3;
+        w2off0 = (u32)((row2 * FF + ((p2 ^ ((row2 >> 2) & 3)) * 8)) * 2);
+    }
+    auto issue_part = [&](int ci, auto ic, auto itc) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int it = decltype(itc)::value;
+        if (DBG && (dflags & 4)) return;
+        if constexpr (i < 3) {
+            const u32 cc = (u32)(ci < NCH ? ci : NCH - 1);
+            if constexpr (VAR & 2) {
+                const u32 o = v1 + (cc * (u32)(3 * S1) + (u32)(i * S1));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W1 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + i * S1 + w * 2048), 16, it * 1024, 0);
+            } else {
+                const u32 o = w1off0 + (cc * (u32)(CH * H * 2) + (u32)(i * 128 + it * (32 * H * 2)));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W1 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + i * S1 + (it * 8 + w) * 1024), 16, 0, 0);
+            }
+        } else {
+            const u32 cc = (u32)(ci < 1 ? 0 : (ci > NCH ? NCH - 1 : ci - 1));
+            if constexpr (VAR & 2) {
+                const u32 o = v2 + (cc * (u32)(2 * S2) + (u32)((i - 3) * S2));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W2 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + W2_OFF + (i - 3) * S2 + w * 3072), 16, it * 1024, 0);
+            } else {
+                const u32 o = w2off0 + (cc * (u32)(CH * 2) + (u32)((i - 3) * 64 + it * (128 * FF * 2)));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W2 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + W2_OFF + (i - 3) * S2 + (it * 8 + w) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc2[6];                                 // outputs [192 s + 32 j, +32)
+#pragma unroll
+    for (int o = 0; o < 6; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[o][r] = 0.f;
+
+    const u32 lds0 = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)gsm;
+    u32 a1A[4], a1B[4], a2[2];                      // fragment addresses: own tile (rows 32 s + r31), partner's tile, W2 rows 192 s + r31
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const u32 unit = (u32)(((8 * s + 2 * ks + hh) ^ (r31 & 15)) * 16);
+        a1A[ks] = lds0 + (u32)((32 * s + r31) * 256) + unit;
+        a1B[ks] = lds0 + (u32)((32 * (1 - s) + r31) * 256) + unit;
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) a2[k2] = lds0 + (u32)W2_OFF + (u32)((192 * s + r31) * 64 + (((2 * k2 + hh) ^ ((r31 >> 2) & 3)) * 16));
+    const u32 xp_w = lds0 + (u32)XP_OFF + (u32)(w * 4096) + (u32)lane * 16;             // + j * 1024: registers 4 j .. 4 j + 3
+    const u32 xp_r = lds0 + (u32)XP_OFF + (u32)((w ^ 4) * 4096) + (u32)lane * 16;
+    const u32 px_w = lds0 + (u32)PX_OFF + (u32)((p * 2 + s) * 2048) + (u32)lane * 16;   // + k-step * 1024
+    const u32 px_r = lds0 + (u32)PX_OFF + (u32)(p * 2 * 2048) + (u32)lane * 16;         // + tile * 2048 + k-step * 1024
+    bf16x8 fq[PF];
+#pragma unroll
+    for (int m = 0; m < PF; ++m) fq[m] = bf16x8{};
+
+    f32x16 accA, accB;                              // FFN1 partial sums over this half's k: own tile (bias included), partner's tile
+    f32x16 prv;                                     // own tile of the chunk before: full pre-activation (GELU source)
+    u32x4 pf[2];                                    // slabs 0-2: the own tile's activated fragments being built; slabs 3-4: the B fragments of the tile in use
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { prv[r] = 0.f; accB[r] = 0.f; }
+    pf[0] = u32x4{}; pf[1] = u32x4{};
+
+    auto load_bias = [&](int cc) {                  // register 4 q + e of lane half hh <-> feature 32 s + 8 q + 4 hh + e of the chunk
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(b1s + cc * CH + s * 32 + q * 8 + hh * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accA[4 * q + e] = bv[e];
+        }
+    };
+    // The activation in PACKED fp32 (v_pk_*_f32, two values per instruction), written as instructions because hipcc scalarises most of
+    // the vector form once registers are tight (88 v_fma_f32 + 20 v_pk_fma_f32 per chunk).  gelu(v) = v (0.5 + Q0 vc P(u)), vc =
+    // clamp(v), u = vc^2, P = Q / Q0 MONIC (its first Horner step is an add, and every step takes ONE constant: an SGPR pair --
+    // gfx950 packed-f32 operands are 64-bit, one scalar source per instruction).  Same polynomial as k_ffn2's up to fp32 rounding.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto c2 = [](float c) { return f32x2{c, c}; };
+    auto pk_fma_s = [](f32x2& d, f32x2 a, f32x2 k) { asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d) : "v"(a), "s"(k)); };   // d = d a + k
+    f32x2 gcl = {}, gch = {}, gul = {}, guh = {}, gpl = {}, gph = {};
+    // one stage (of six) of the activation of group q of the own tile: values prv[4 q ..] -> pf
+    f32x4 gc = {}, gu = {}, gp = {};
+    auto sp = [](float c) { return f32x4{c, c, c, c}; };
+    auto gelu_stage_vec = [&](int q, int st) {        // VAR bit 0 clear: k_ffn2's stages, left to hipcc
+        switch (st) {
+            case 0:
+                asm volatile("" : "+v"(gc));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gc[e] = __builtin_amdgcn_fmed3f(prv[4 * q + e], -RMU_GCLAMP, RMU_GCLAMP);
+                asm volatile("" : "+v"(gc));
+                break;
+            case 1:
+                asm volatile("" : "+v"(gc));
+                gu = gc * gc;
+                gp = __builtin_elementwise_fma(sp(RMU_GQ0), gu, sp(RMU_GQ1));
+                asm volatile("" : "+v"(gu), "+v"(gp));
+                break;
+            case 2: case 3: case 4: {
+                const float ca = st == 2 ? RMU_GQ2 : st == 3 ? RMU_GQ4 : RMU_GQ6, cb = st == 2 ? RMU_GQ3 : st == 3 ? RMU_GQ5 : RMU_GQ7;
+                asm volatile("" : "+v"(gp));
+                gp = __builtin_elementwise_fma(gp, gu, sp(ca));
+                gp = __builtin_elementwise_fma(gp, gu, sp(cb));
+                asm volatile("" : "+v"(gp));
+                break;
+            }
+            default: {
+                asm volatile("" : "+v"(gp));
+                gp = __builtin_elementwise_fma(gc, gp, sp(0.5f));
+                const f32x4 pv = {prv[4 * q], prv[4 * q + 1], prv[4 * q + 2], prv[4 * q + 3]};
+                gp = pv * gp;
+                bf16x2 lo, hi;
+                lo[0] = (bf16)gp[0]; lo[1] = (bf16)gp[1]; hi[0] = (bf16)gp[2]; hi[1] = (bf16)gp[3];
+                u32 d0 = __builtin_bit_cast(u32, lo), d1 = __builtin_bit_cast(u32, hi);
+                asm volatile("" : "+v"(d0), "+v"(d1));
+                pf[q >> 1][(q & 1) * 2] = d0;
+                pf[q >> 1][(q & 1) * 2 + 1] = d1;
+            }
+        }
+    };
+    auto gelu_stage = [&](int q, int st) {
+        if (DBG && (dflags & 1)) return;
+        if constexpr (!(VAR & 1)) { gelu_stage_vec(q, st); return; }
+        switch (st) {
+            case 0:
+                asm volatile("v_med3_f32 %0, %1, -%2, %2" : "=v"(gcl[0]) : "v"(prv[4 * q]), "s"(RMU_GCLAMP));   // one scalar source, negated in place
+                asm volatile("v_med3_f32 %0, %1, -%2, %2" : "=v"(gcl[1]) : "v"(prv[4 * q + 1]), "s"(RMU_GCLAMP));   // one scalar source, negated in place
+                asm volatile("v_med3_f32 %0, %1, -%2, %2" : "=v"(gch[0]) : "v"(prv[4 * q + 2]), "s"(RMU_GCLAMP));   // one scalar source, negated in place
+                asm volatile("v_med3_f32 %0, %1, -%2, %2" : "=v"(gch[1]) : "v"(prv[4 * q + 3]), "s"(RMU_GCLAMP));   // one scalar source, negated in place
+                break;
+            case 1:
+                asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(gul) : "v"(gcl));
+                asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(guh) : "v"(gch));
+                asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(gpl) : "v"(gul), "s"(c2(RMU_GQ1 / RMU_GQ0)));
+                asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(gph) : "v"(guh), "s"(c2(RMU_GQ1 / RMU_GQ0)));
+                break;
+            case 2:
+                pk_fma_s(gpl, gul, c2(RMU_GQ2 / RMU_GQ0)); pk_fma_s(gph, guh, c2(RMU_GQ2 / RMU_GQ0));
+                pk_fma_s(gpl, gul, c2(RMU_GQ3 / RMU_GQ0)); pk_fma_s(gph, guh, c2(RMU_GQ3 / RMU_GQ0));
+                break;
+            case 3:
+                pk_fma_s(gpl, gul, c2(RMU_GQ4 / RMU_GQ0)); pk_fma_s(gph, guh, c2(RMU_GQ4 / RMU_GQ0));
+                pk_fma_s(gpl, gul, c2(RMU_GQ5 / RMU_GQ0)); pk_fma_s(gph, guh, c2(RMU_GQ5 / RMU_GQ0));
+                break;
+            case 4:
+                pk_fma_s(gpl, gul, c2(RMU_GQ6 / RMU_GQ0)); pk_fma_s(gph, guh, c2(RMU_GQ6 / RMU_GQ0));
+                pk_fma_s(gpl, gul, c2(RMU_GQ7 / RMU_GQ0)); pk_fma_s(gph, guh, c2(RMU_GQ7 / RMU_GQ0));
+                break;
+            default: {
+                // gp = vc P;  gp = Q0 gp + 0.5;  gp = v gp;  -> bf16 pairs
+                f32x2 pvl = {prv[4 * q], prv[4 * q + 1]}, pvh = {prv[4 * q + 2], prv[4 * q + 3]};
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(gpl) : "v"(gcl));
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(gph) : "v"(gch));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, 0.5 op_sel_hi:[1,1,0]" : "+v"(gpl) : "s"(c2(RMU_GQ0)));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, 0.5 op_sel_hi:[1,1,0]" : "+v"(gph) : "s"(c2(RMU_GQ0)));
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(gpl) : "v"(pvl));
+                asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(gph) : "v"(pvh));
+                u32 d0, d1;
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d0) : "v"(gpl[0]), "v"(gpl[1]));
+                asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d1) : "v"(gph[0]), "v"(gph[1]));
+                pf[q >> 1][(q & 1) * 2] = d0;
+                pf[q >> 1][(q & 1) * 2 + 1] = d1;
+            }
+        }
+    };
+
+    // prologue of the stream: slabs 0 .. 3 of iteration 0
+    static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        issue_part(0, ic, std::integral_constant<int, 0>{});
+        issue_part(0, ic, std::integral_constant<int, 1>{});
+        if constexpr (i == 3) issue_part(0, ic, std::integral_constant<int, 2>{});
+    });
+    load_bias(0);
+
+    // Iteration c (ONE body, as k_ffn2): FFN1 partials of chunk min(c, NCH - 1); activation of the own tile of chunk c - 1;
+    // FFN2 of chunk c - 1 over this half's outputs.
+    for (int c = 0; c <= NCH; ++c) {
+        static_for<5>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(wait_n(i)) : "memory");
+            if (!DBG || !(dflags & 16)) __builtin_amdgcn_s_barrier();
+            if constexpr (i == 0) asm volatile("" : "+v"(accA));      // the bias reads have landed (the wait above)
+            if constexpr (i < 3) {
+                // ---- FFN1 slab i: 4 k-steps x 2 tiles, n = 2 ks + (0: own tile, 1: partner's); behind MFMA n: activation stage 8 i + n
+                static_for<PF>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    if (!DBG || !(dflags & 2)) ds_read16<i * S1>(fq[n], (n & 1) ? a1B[n >> 1] : a1A[n >> 1]);
+                });
+                static_for<8>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    if constexpr (n % 2 == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"(n + PF <= 8 ? PF - 2 : 8 - 2 - n));
+                    if constexpr (n & 1) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], hf[i * 4 + (n >> 1)], accB, 0, 0, 0);
+                    else accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], hf[i * 4 + (n >> 1)], accA, 0, 0, 0);
+                    if constexpr (n + PF < 8) { if (!DBG || !(dflags & 2)) ds_read16<i * S1>(fq[n % PF], ((n + PF) & 1) ? a1B[(n + PF) >> 1] : a1A[(n + PF) >> 1]); }
+                    else asm volatile("" : "+v"(fq[n % PF]));
+                    if constexpr (i == 0 && n % 2 == 1 && n / 2 < 3) issue_part(c, std::integral_constant<int, 4>{}, std::integral_constant<int, n / 2>{});
+                    gelu_stage((8 * i + n) / 6, (8 * i + n) % 6);
+                });
+                if constexpr (i == 2) if (!DBG || !(dflags & 8)) {
+                    // both exchanges (completed by the wait + barrier that open slab 3): the partner's tile partial, the own activated tile
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(px_w), "v"(pf[0]) : "memory");
+                    asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(px_w), "v"(pf[1]) : "memory");
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = {accB[4 * j], accB[4 * j + 1], accB[4 * j + 2], accB[4 * j + 3]};
+                        if (j == 0) asm volatile("ds_write_b128 %0, %1" ::"v"(xp_w), "v"(v) : "memory");
+                        if (j == 1) asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(xp_w), "v"(v) : "memory");
+                        if (j == 2) asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(xp_w), "v"(v) : "memory");
+                        if (j == 3) asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(xp_w), "v"(v) : "memory");
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accB[r] = 0.f;
+                }
+            } else {
+                // ---- FFN2 over feature tile t of chunk c - 1: 2 k-steps x 6 output tiles, n = 6 k2 + j -------------------------------
+                constexpr int t = i - 3;
+                // exchange reads first (older than every fragment read: the first counted wait below covers them)
+                f32x4 pp[4];
+                if (DBG && (dflags & 8)) { pp[0] = pp[1] = pp[2] = pp[3] = f32x4{}; asm volatile("" : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(pp[3])); }
+                if (!DBG || !(dflags & 8)) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pf[0]) : "v"(px_r), "n"(t * 2048));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pf[1]) : "v"(px_r), "n"(t * 2048 + 1024));
+                }
+                if constexpr (t == 0) if (!DBG || !(dflags & 8)) {
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(pp[0]) : "v"(xp_r));
+                    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(pp[1]) : "v"(xp_r));
+                    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(pp[2]) : "v"(xp_r));
+                    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(pp[3]) : "v"(xp_r));
+                }
+                static_for<PF>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    if (!DBG || !(dflags & 2)) ds_read16<t * S2 + (n % 6) * 2048>(fq[n], a2[n / 6]);
+                });
+                static_for<12>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    if constexpr (n % 2 == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"(n + PF <= 12 ? PF - 2 : 12 - 2 - n));
+                    if constexpr (n == 0) asm volatile("" : "+v"(pf[0]), "+v"(pf[1]));
+                    acc2[n % 6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], __builtin_bit_cast(bf16x8, pf[n / 6]), acc2[n % 6], 0, 0, 0);
+                    if constexpr (n + PF < 12) { if (!DBG || !(dflags & 2)) ds_read16<t * S2 + ((n + PF) % 6) * 2048>(fq[n % PF], a2[(n + PF) / 6]); }
+                    else asm volatile("" : "+v"(fq[n % PF]));
+                    if constexpr (t == 0) {
+                        if constexpr (n % 2 == 0) {          // S0', S1', S2' of iteration c + 1: 6 instructions over 12 steps
+                            constexpr int k = n / 2;
+                            issue_part(c + 1, std::integral_constant<int, k / 2>{}, std::integral_constant<int, k % 2>{});
+                        }
+                        if constexpr (n >= 2 && n < 10) {    // own tile: full pre-activation = own partial + the partner's (two values per step)
+                            constexpr int e0 = 2 * (n - 2);
+                            if constexpr (e0 % 4 == 0) asm volatile("" : "+v"(pp[e0 / 4]));
+                            float m0v = accA[e0] + pp[e0 / 4][e0 % 4], m1v = accA[e0 + 1] + pp[(e0 + 1) / 4][(e0 + 1) % 4];
+                            asm volatile("" : "+v"(m0v), "+v"(m1v));
+                            prv[e0] = m0v;
+                            prv[e0 + 1] = m1v;
+                        }
+                    } else {
+                        if constexpr (n % 4 == 0) issue_part(c + 1, std::integral_constant<int, 3>{}, std::integral_constant<int, n / 4>{});
+                    }
+                });
+                if constexpr (t == 1) load_bias(c + 1 < NCH ? c + 1 : NCH - 1);
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the tail reloads: the LDS becomes the pre-LN tile
+    __syncthreads();
+    char* tile = gsm;
+    {
+        // acc2[j][4 q + e] = output feature n = 192 s + 32 j + 8 q + 4 hh + e of token 32 p + r31; the residual h1[token][n] sits in
+        // hf[2 j + (q >> 1)] of this lane ((q & 1) == hh) or of lane ^ 32 (as k_ffn2).  y = bf16(bf16(acc + b2) + resid).
+        const int tr = 32 * p + r31;
+        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const u32x4 hv = __builtin_bit_cast(u32x4, hf[2 * j + qq]);
+                const u32x2 own = hh ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]};
+                const u32x2 oth = hh ? u32x2{hv[0], hv[1]} : u32x2{hv[2], hv[3]};
+                u32x2 rcv;
+                rcv[0] = (u32)__shfl_xor((int)oth[0], 32);
+                rcv[1] = (u32)__shfl_xor((int)oth[1], 32);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int q = 2 * qq + qb;
+                    const u32x2 rs2 = (qb == hh) ? own : rcv;
+                    const bf16x4 res = __builtin_bit_cast(bf16x4, rs2);
+                    const int n = s * 192 + j * 32 + q * 8 + hh * 4;
+                    const f32x4 bv = *(const f32x4*)(b2 + n);
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16)(bf2f((bf16)(acc2[j][4 * q + e] + bv[e])) + bf2f(res[e]));
+                    *(bf16x4*)(tile + tr * TSTR + n * 2) = v;
+                }
+            }
+    }
+    __syncthreads();
+    {
+        const bool act = lane < 48;
+        const int c0 = (act ? lane : 0) * 8;
+        float gg[8], bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gg[i] = g[c0 + i]; bb[i] = bta[c0 + i]; }
+        for (int r = 0; r < 16; ++r) {
+            const int tr = w * 16 + r;
+            const int m = m0 + tr;
+            if (m >= M) break;
+            const bf16x8 yv = *(const bf16x8*)(tile + tr * TSTR + c0 * 2);
+            float v[8];
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[i] = act ? bf2f(yv[i]) : 0.f; sm += v[i]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            const float mu = sm * (1.0f / H);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = act ? v[i] - mu : 0.f; q = fmaf(d, d, q); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rs = rsqrtf(q * (1.0f / H) + eps);
+            bf16x8 ov;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] = (bf16)((v[i] - mu) * rs * gg[i] + bb[i]);
+            if (act) *(bf16x8*)(out + (int64_t)m * H + c0) = ov;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_gemm3 -- persistent big-tile GEMM for the encoder's shapes: out[m, n] = epi( sum_k A[m, k] W[n, k] + bias[n] ).
 //
 // What the cycle counters of k_gemm / k_ffn_fused and tools/ubench/fill.hip say about a CU's memory pipeline (all 256 CUs busy,
@@ -1959,6 +2424,7 @@ struct BertLayer {
     bf16 *wqkv, *wo, *w1, *w2;
     bf16* w2p;      // W2 with the columns of every 32-block permuted to the fused FFN kernel's k-slot order
     bf16 *wqkv_t, *wo_t, *w1_t, *w2_t;   // k_tile_w copies for k_gemm3
+    bf16 *w1s, *w2s;                     // k_pack_ffn3 streams for k_ffn3's VAR bit 1 (debug builds only; nullptr otherwise)
     float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
 struct rmu_bert {
@@ -2085,6 +2551,11 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
             conv_bf16(L.w2, wptr[wi], (size_t)H * FF, 1.f, s);
             hipLaunchKernelGGL(k_permute_w2, dim3((unsigned)(((size_t)H * FF + 255) / 256)), dim3(256), 0, s, (const bf16*)L.w2, L.w2p, (int64_t)H * FF);
         }
+#ifdef RMU_DEBUG_KERNELS
+        rc |= dev_alloc(m, &L.w1s, (size_t)FF * H);
+        rc |= dev_alloc(m, &L.w2s, (size_t)H * FF);
+        if (!rc) hipLaunchKernelGGL(k_pack_ffn3, dim3((unsigned)((2 * (size_t)FF * H / 8 + 255) / 256)), dim3(256), 0, s, (const bf16*)L.w1, (const bf16*)L.w2p, L.w1s, L.w2s);
+#endif
         wi++;
         rc |= copy_f32(m, &L.b2, wptr[wi++], H, 1.f, s);
         rc |= copy_f32(m, &L.ln2g, wptr[wi++], H, 1.f, s);
@@ -2226,6 +2697,39 @@ static void launch_ffn2(const bf16* x, bool ln_in, const BertLayer& L, float eps
     else { if (gv) launch_ffn2_t<false, 1, 4>(x, L, eps, out, cu, batch, m_cap, s); else launch_ffn2_t<false, 0, 4>(x, L, eps, out, cu, batch, m_cap, s); }
 }
 
+template <bool LN_IN, int PF, int VAR>
+static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
+    const dim3 grid((unsigned)((m_cap + ffn3::TOK - 1) / ffn3::TOK));
+    const bf16* w1 = (VAR & 2) ? L.w1s : L.w1;
+    const bf16* w2 = (VAR & 2) ? L.w2s : L.w2p;
+#ifdef RMU_DEBUG_KERNELS
+    static const int dflags = getenv("RMU_FFN3_DBG") ? atoi(getenv("RMU_FFN3_DBG")) : 0;
+    if (dflags) {
+        static const hipError_t attr_d = hipFuncSetAttribute((const void*)k_ffn3<LN_IN, PF, true, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
+        (void)attr_d;
+        hipLaunchKernelGGL((k_ffn3<LN_IN, PF, true, VAR>), grid, dim3(512), ffn3::LDS_BYTES, s, x, w1, L.b1, w2, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
+                           L.ln1g, L.ln1b, dflags);
+        return;
+    }
+#endif
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_ffn3<LN_IN, PF, false, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
+    (void)attr_rc;
+    hipLaunchKernelGGL((k_ffn3<LN_IN, PF, false, VAR>), grid, dim3(512), ffn3::LDS_BYTES, s, x, w1, L.b1, w2, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
+                       L.ln1g, L.ln1b, 0);
+}
+static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
+#ifdef RMU_DEBUG_KERNELS
+    // A/B forms (measured, 8192 chunks, per launch: VAR 0 3227 us, 1 3404, 2 3245, 3 3370 -- the packed-f32 activation is SLOWER than
+    // hipcc's mostly scalar one although the loop shrinks from 431 to 357 instructions, and the stream form of the weights changes nothing)
+    static const int var = getenv("RMU_FFN3_VAR") ? atoi(getenv("RMU_FFN3_VAR")) : 0;
+#define RMU_FFN3_CASE(V) case V: if (ln_in) launch_ffn3_t<true, 4, V>(x, L, eps, out, cu, batch, m_cap, s); else launch_ffn3_t<false, 4, V>(x, L, eps, out, cu, batch, m_cap, s); return;
+    switch (var & 3) { RMU_FFN3_CASE(1) RMU_FFN3_CASE(2) RMU_FFN3_CASE(3) default: break; }
+#undef RMU_FFN3_CASE
+#endif
+    if (ln_in) launch_ffn3_t<true, 4, 0>(x, L, eps, out, cu, batch, m_cap, s);
+    else launch_ffn3_t<false, 4, 0>(x, L, eps, out, cu, batch, m_cap, s);
+}
+
 template <int EPI>
 static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu, int batch,
                          int N, int K, hipStream_t s) {
@@ -2317,12 +2821,14 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // 32k tokens 1.70 vs 1.45).  RMU_FUSED_FFN=0 / 1 forces either path.
         static const int fused_env = getenv("RMU_FUSED_FFN") ? atoi(getenv("RMU_FUSED_FFN")) : -1;
         const bool fused_ffn = !(g3_mask & 4) && (fused_env < 0 ? cap > 16384 : fused_env != 0);
-        // k_ffn2 (default) also takes LayerNorm 1 into its prologue: the out-proj sum y goes straight in (RMU_FFN_LNIN=0: separate
-        // k_layernorm launch; RMU_FFN_V=1: the round-2 kernel k_ffn_fused, kept this round for the A/B numbers in DESIGN.md)
-        static const int ffn_v = getenv("RMU_FFN_V") ? atoi(getenv("RMU_FFN_V")) : 2;
+        // k_ffn3 (default; two waves per SIMD) and k_ffn2 (RMU_FFN_V=2; one) also take LayerNorm 1 into their prologue: the out-proj sum y
+        // goes straight in (RMU_FFN_LNIN=0: separate k_layernorm launch; RMU_FFN_V=1: the round-2 kernel k_ffn_fused -- both kept
+        // this round for the A/B numbers in DESIGN.md)
+        static const int ffn_v = getenv("RMU_FFN_V") ? atoi(getenv("RMU_FFN_V")) : 3;
         static const bool ln_in = !(getenv("RMU_FFN_LNIN") && atoi(getenv("RMU_FFN_LNIN")) == 0);
-        if (fused_ffn && ffn_v == 2 && ln_in) {
-            launch_ffn2(m->y, true, L, eps, m->h, m->cu, batch, cap, s);
+        if (fused_ffn && ffn_v >= 2 && ln_in) {
+            if (ffn_v == 3) launch_ffn3(m->y, true, L, eps, m->h, m->cu, batch, cap, s);
+            else launch_ffn2(m->y, true, L, eps, m->h, m->cu, batch, cap, s);
             continue;
         }
         hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
@@ -2333,7 +2839,8 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
             continue;
         }
         if (fused_ffn) {          // FFN1 + GELU + FFN2 + residual + LayerNorm in one kernel: the 1536-wide intermediate stays on chip
-            if (ffn_v == 2) launch_ffn2(m->h1, false, L, eps, m->h, m->cu, batch, cap, s);
+            if (ffn_v == 3) launch_ffn3(m->h1, false, L, eps, m->h, m->cu, batch, cap, s);
+            else if (ffn_v == 2) launch_ffn2(m->h1, false, L, eps, m->h, m->cu, batch, cap, s);
             else launch_ffn_fused(m->h1, L, eps, m->h, m->cu, batch, cap, s);
             continue;
         }

@@ -175,7 +175,8 @@ def test_delete_by_source_expression_and_upsert(store):
         store.delete(expr="source LIKE 'x'")
 
 
-def test_from_documents_reattaches_unless_drop_old():
+def test_from_documents_reattaches_unless_drop_old(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)                               # the relative uri "u" persists beside the working directory
     MI355XVectorStore._index_factory = FakeIndex
     try:
         MI355XVectorStore._collections.clear()

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check"
 keep() {  # keep only our kernels' rows of a CSV
   f=$(find $OUT/$1 -name "*$2" | head -1)
-  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|merge_select|merge_wg|k_gather_flagged|k_ffn2|k_ffn_fused|k_gemm3|k_gemm|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
+  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|merge_select|merge_wg|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
 }
 # 1) headline bench (10M x 384, B=1024) on the default path (fp16 hi/lo screening + exact re-score): stats + PMC passes
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan -o scan -- $B > $OUT/scan_bench.json 2> $OUT/scan.err
@@ -59,7 +59,7 @@ keep embed kernel_stats.csv stats
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/top100 -o t -- python $R/tools/topk_probe.py 1000000:64:100 > $OUT/top100_probe.txt 2>> $OUT/scan.err
 keep top100 kernel_stats.csv stats
 # 6) encoder PMC (the four dominant kernels only; a pass over every kernel hung rocprofv3 in round 1)
-timeout -k 5 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-include-regex "k_ffn2|k_gemm3|k_attn3|k_gemm" --output-format csv -d $OUT/enc_pmc -o a -- python $R/tools/enc_smoke.py 2048 > /dev/null 2>> $OUT/scan.err
+timeout -k 5 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-include-regex "k_ffn3|k_gemm3|k_attn3|k_gemm" --output-format csv -d $OUT/enc_pmc -o a -- python $R/tools/enc_smoke.py 2048 > /dev/null 2>> $OUT/scan.err
 keep enc_pmc counter_collection.csv counters
 for d in top100 enc_pmc scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
 ls -la $OUT

@@ -20,7 +20,7 @@ STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.
 
 def short(n):
     m = re.search(r'(scan_topk_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
-                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn2|k_ffn_fused|k_gemm3|k_gemm_small|k_gemm<\d, \d, \d+, \d>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
+                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm_small|k_gemm<\d, \d, \d+, \d>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
     s = m.group(1) if m else n[:40]
     if s in ('scan_topk_kernel',):
         c = re.search(r'Cfg<([^>]*)>', n)
@@ -108,7 +108,7 @@ txt = [
     stats('scan_b1', 'HBM-bound regime: batch 1, default path (fp16 image, 768 B per row, screening ladder with ratio 8)'),
     stats('exact_b1', 'batch 1 forced onto the exact fp32 scan (`RMU_SCREEN=0`, WQ=1 geometry)'),
     stats('scan_b32', 'north-star regime: batch 32 over 10M rows, default path (fp16 image, nt stream, ladder ratio 8)'),
-    stats('embed', 'encoder: 8192-chunk calls x ~128 tokens (BERT-6x384, bf16 MFMA; k_ffn2 / k_attn3 / k_gemm3 / k_gemm)'),
+    stats('embed', 'encoder: 8192-chunk calls x ~128 tokens (BERT-6x384, bf16 MFMA; k_ffn3 / k_attn3 / k_gemm3 / k_gemm)'),
     "## PMC passes (separate runs, `--kernel-trace --pmc ...` only)\n",
     line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK), line('exact_pmc_b1', B1), line('pmc_b32', SK),
     "\n## Derived (FETCH_SIZE is in KiB and under-reports by 2x on gfx950 per MI355X_MICROARCH.md -> bytes = FETCH_SIZE x 1024 x 2)\n",
@@ -133,14 +133,14 @@ if os.path.exists(f'{src}/enc_pmc_counters.csv'):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f'{src}/enc_pmc_counters.csv')):
         n = r['Kernel_Name']
-        kn = next((k for k in ('k_ffn2', 'k_gemm3', 'k_attn3', 'k_gemm_small', 'k_gemm') if k in n), n[:30])
+        kn = next((k for k in ('k_ffn3', 'k_ffn2', 'k_gemm3', 'k_attn3', 'k_gemm_small', 'k_gemm') if k in n), n[:30])
         acc[kn][r['Counter_Name']].append(float(r['Counter_Value']))
     cn = ['GRBM_GUI_ACTIVE', 'SQ_INSTS_MFMA', 'SQ_INSTS_VALU', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_BUSY_CYCLES']
-    ks = [k for k in ('k_ffn2', 'k_gemm3', 'k_gemm', 'k_attn3') if k in acc]
+    ks = [k for k in ('k_ffn3', 'k_ffn2', 'k_gemm3', 'k_gemm', 'k_attn3') if k in acc]
     m = {k: {c: sum(v) / len(v) for c, v in acc[k].items()} for k in ks}
     out = [f"# Encoder kernels: PMC pass (round {int(RP[1:])})\n",
            "`rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU "
-           "SQ_INSTS_MFMA --kernel-include-regex \"k_ffn2|k_gemm3|k_attn3|k_gemm\" -- python tools/enc_smoke.py 2048` (tools/profile.sh); 2048 chunks (~262 k tokens), "
+           "SQ_INSTS_MFMA --kernel-include-regex \"k_ffn3|k_gemm3|k_attn3|k_gemm\" -- python tools/enc_smoke.py 2048` (tools/profile.sh); 2048 chunks (~262 k tokens), "
            "means over the 6 launches (one per layer) of each kernel; raw sums over the chip (GRBM_GUI_ACTIVE summed over the 8 XCDs; SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / "
            "SQ_ACTIVE_INST_ANY in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles: MI355X_MICROARCH.md).\n",
            "| counter | " + " | ".join(f"`{k}`" for k in ks) + " |", "|---|" + "---|" * len(ks)]
