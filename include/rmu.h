@@ -215,6 +215,11 @@ int rmu_tok_vocab_size(rmu_tok_t* tk);
  * their first max_len-2 tokens; pairs use "longest_first" truncation. */
 int rmu_tok_encode(rmu_tok_t* tk, const char* const* texts_a, const char* const* texts_b, int n, int max_len,
                    int32_t* ids, int32_t* type_ids, int32_t* lens);
+/* The same over NUL-separated blobs: blob_a holds n strings back to back, each terminated by '\0' (bytes_a = total size including
+ * the terminators); blob_b likewise or NULL.  One host buffer per call instead of n pointers: what a Python caller builds with a
+ * single join + encode.  RMU_E_INVALID when a blob does not hold exactly n terminated strings. */
+int rmu_tok_encode_blob(rmu_tok_t* tk, const char* blob_a, int64_t bytes_a, const char* blob_b, int64_t bytes_b, int n, int max_len,
+                        int32_t* ids, int32_t* type_ids, int32_t* lens);
 
 #ifdef __cplusplus
 }

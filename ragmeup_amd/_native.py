@@ -26,7 +26,7 @@ SYMBOLS = [
     "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing", "rmu_last_screened",
     "rmu_comm_unique_id", "rmu_comm_init", "rmu_comm_free", "rmu_comm_world", "rmu_shard_allgather_topk", "rmu_index_screen_candidates",
     "rmu_bert_create", "rmu_bert_free", "rmu_bert_encode", "rmu_bert_encode_host",
-    "rmu_tok_create", "rmu_tok_free", "rmu_tok_vocab_size", "rmu_tok_encode",
+    "rmu_tok_create", "rmu_tok_free", "rmu_tok_vocab_size", "rmu_tok_encode", "rmu_tok_encode_blob",
 ]
 
 
@@ -74,6 +74,7 @@ def _declare(lib):
     lib.rmu_tok_free.argtypes = [vp]
     lib.rmu_tok_vocab_size.argtypes = [vp]
     lib.rmu_tok_encode.argtypes = [vp, c.POINTER(c.c_char_p), c.POINTER(c.c_char_p), i32, i32, vp, vp, vp]
+    lib.rmu_tok_encode_blob.argtypes = [vp, c.c_char_p, i64, c.c_char_p, i64, i32, i32, vp, vp, vp]
     if hasattr(lib, "rmu_bert_create"):
         lib.rmu_bert_create.argtypes = [c.POINTER(vp), vp, c.POINTER(vp), i32]
         lib.rmu_bert_free.argtypes = [vp]

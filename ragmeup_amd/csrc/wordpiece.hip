@@ -436,3 +436,28 @@ extern "C" int rmu_tok_encode(rmu_tok_t* tk, const char* const* texts_a, const c
     if (failed.load()) { rmu_set_error_("rmu_tok_encode: out of memory while tokenising"); return RMU_E_OOM; }
     return RMU_OK;
 }
+
+extern "C" int rmu_tok_encode_blob(rmu_tok_t* tk, const char* blob_a, int64_t bytes_a, const char* blob_b, int64_t bytes_b, int n, int max_len,
+                                   int32_t* ids, int32_t* type_ids, int32_t* lens) {
+    if (!tk || !blob_a || n < 0 || bytes_a < n || (blob_b && bytes_b < n)) { rmu_set_error_("rmu_tok_encode_blob: bad argument"); return RMU_E_INVALID; }
+    std::vector<const char*> pa, pb;
+    try {
+        auto split = [&](const char* blob, int64_t bytes, std::vector<const char*>& out) {
+            out.reserve((size_t)n);
+            const char* p = blob;
+            const char* e = blob + bytes;
+            while (p < e && (int)out.size() < n) {
+                const char* z = (const char*)memchr(p, 0, (size_t)(e - p));
+                if (!z) return false;
+                out.push_back(p);
+                p = z + 1;
+            }
+            return (int)out.size() == n && p == e;
+        };
+        if (!split(blob_a, bytes_a, pa) || (blob_b && !split(blob_b, bytes_b, pb))) {
+            rmu_set_error_("rmu_tok_encode_blob: the blob does not hold exactly n NUL-terminated strings");
+            return RMU_E_INVALID;
+        }
+    } catch (...) { rmu_set_error_("rmu_tok_encode_blob: out of memory"); return RMU_E_OOM; }
+    return rmu_tok_encode(tk, pa.data(), blob_b ? pb.data() : nullptr, n, max_len, ids, type_ids, lens);
+}

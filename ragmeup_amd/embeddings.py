@@ -164,7 +164,10 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         return C.read_sentence_transformer(model_dir)
 
     def _prep(self, texts: list[str]) -> list[str]:
-        out = [t.replace("\n", " ") for t in texts]                 # langchain-huggingface embed_documents
+        from .tokenizer import WordPieceTokenizer
+        # langchain-huggingface embed_documents replaces "\n" by " " before sentence-transformers sees the text; the native
+        # tokenizer treats both as whitespace (BERT's BasicTokenizer), so the copy of every text is skipped there
+        out = texts if isinstance(self.tokenizer, WordPieceTokenizer) else [t.replace("\n", " ") for t in texts]
         if self._text_lower:
             out = [t.lower() for t in out]                           # sentence_bert_config.json do_lower_case
         return out
@@ -194,13 +197,22 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         if out is None:
             out = torch.empty((len(texts), 384), dtype=torch.float32, device=self.encoder.device)
         starts = list(range(0, len(texts), blk))
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(self._tokenize, texts[starts[0]:starts[0] + blk])
-            for i, lo in enumerate(starts):
-                ids, lens = fut.result()
-                if i + 1 < len(starts):
-                    fut = pool.submit(self._tokenize, texts[starts[i + 1]:starts[i + 1] + blk])
-                self.embed_id_arrays(ids, lens, out=out[lo:lo + ids.shape[0]])
+        # Both stages spend their time in librmu.so with the GIL released, but each needs it back for a few lines of Python per
+        # block; with CPython's default 5 ms switch interval the encoding thread waited up to that long behind the tokenising
+        # thread's string handling, every block (~30 ms per 65536 texts measured).  A short interval for the duration of the call.
+        import sys
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_switch, 2e-4))
+        try:
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                fut = pool.submit(self._tokenize, texts[starts[0]:starts[0] + blk])
+                for i, lo in enumerate(starts):
+                    ids, lens = fut.result()
+                    if i + 1 < len(starts):
+                        fut = pool.submit(self._tokenize, texts[starts[i + 1]:starts[i + 1] + blk])
+                    self.embed_id_arrays(ids, lens, out=out[lo:lo + ids.shape[0]])
+        finally:
+            sys.setswitchinterval(old_switch)
         return out
 
     def embed_documents_array(self, texts: list[str]) -> np.ndarray:

@@ -460,6 +460,11 @@ class MI355XVectorStore(VectorStore):
         rows = [int(x) for x in r[0] if x >= 0]
         if not rows:
             return []
+        if r.shape[1] <= 64 and hasattr(self._index, "mmr"):
+            # the greedy selection on the device (rmu_index_mmr: fp64, same rule and tie order; tests/test_search_gpu.py holds it to
+            # the oracle): no re-fetch of the candidate vectors, no per-pick numpy calls (0.32 ms of a 0.58 ms query on the host)
+            pos = self._index.mmr(q[None], r, k, lambda_mult)[0]
+            return [self._doc(int(r[0, p])) for p in pos if p >= 0]
         cand = self._index.get_rows(rows)      # the `pk in [...]` vector re-fetch of the replaced store
         picked = maximal_marginal_relevance(q, cand, k=k, lambda_mult=lambda_mult)
         return [self._doc(rows[i]) for i in picked]

@@ -181,3 +181,30 @@ def test_literal_special_tokens_match_transformers(pair):
     e = hf("what is [MASK] ?", "it is the [SEP] token", truncation="longest_first", max_length=32, return_token_type_ids=True)
     ids, tt, lens = mine.encode(["what is [MASK] ?"], ["it is the [SEP] token"], max_len=32)
     assert ids[0, :lens[0]].tolist() == e["input_ids"] and tt[0, :lens[0]].tolist() == e["token_type_ids"]
+
+
+def test_blob_entry_matches_the_pointer_entry_and_rejects_miscounted_blobs(pair, librmu):
+    """rmu_tok_encode_blob (one NUL-separated buffer per side) is the same tokenizer as rmu_tok_encode (n pointers); a text that
+    itself contains NUL goes through the pointer form, where C strings end at the NUL on both paths of the reference too."""
+    import ctypes
+    from ragmeup_amd import _native as N
+    mine, hf = pair
+    rng = random.Random(7)
+    a = [_rand_text(rng, rng.randint(0, 30)) for _ in range(300)] + ["", "x"]
+    b = [_rand_text(rng, rng.randint(0, 30)) for _ in range(300)] + ["y", ""]
+    n = len(a)
+    ids, tt, lens = mine.encode(a, b, max_len=40)                       # blob path
+    arr_a = (ctypes.c_char_p * n)(*[t.encode() for t in a]); arr_b = (ctypes.c_char_p * n)(*[t.encode() for t in b])
+    ids2 = np.empty_like(ids); tt2 = np.empty_like(tt); lens2 = np.empty_like(lens)
+    N.check(librmu.rmu_tok_encode(mine._h, arr_a, arr_b, n, 40, ids2.ctypes.data, tt2.ctypes.data, lens2.ctypes.data), "tok")
+    assert (ids == ids2).all() and (tt == tt2).all() and (lens == lens2).all()
+    with_nul = ["the quick\0brown fox", "lazy dog"]
+    i3, _, l3 = mine.encode(with_nul, max_len=16)                        # falls back: the C string ends at the NUL
+    assert i3[0, :l3[0]].tolist() == hf("the quick", truncation=True, max_length=16)["input_ids"]
+    assert i3[1, :l3[1]].tolist() == hf("lazy dog", truncation=True, max_length=16)["input_ids"]
+    RMU_E_INVALID = -1                                                   # include/rmu.h
+    blob = b"one\0two\0"
+    out = np.empty((3, 8), np.int32); ln = np.empty(3, np.int32)
+    assert librmu.rmu_tok_encode_blob(mine._h, blob, len(blob), None, 0, 3, 8, out.ctypes.data, None, ln.ctypes.data) == RMU_E_INVALID
+    assert librmu.rmu_tok_encode_blob(mine._h, blob, len(blob) - 1, None, 0, 2, 8, out.ctypes.data, None, ln.ctypes.data) == RMU_E_INVALID
+    assert librmu.rmu_tok_encode_blob(mine._h, blob, len(blob), None, 0, 2, 8, out.ctypes.data, None, ln.ctypes.data) == 0
