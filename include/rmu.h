@@ -96,6 +96,14 @@ int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, float* 
 int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const int64_t* rows, int fetch_k, int k,
                   double lambda_mult, unsigned flags, int32_t* out_pos);
 
+/* The reference's per-request retrieval in ONE call (VectorStoreRetriever.invoke with search_type="mmr", RAGHelper.py:497-499:
+ * dense top-fetch_k, then maximal_marginal_relevance over those candidates): rmu_index_search followed by rmu_index_mmr on
+ * the device-resident candidate list, one host round trip.  HOST q [nq, dim]; HOST outputs out_rows [nq, k] int64 (row ids +
+ * row_base in pick order, -1 past the number of candidates) and out_scores [nq, k] fp32 (the search score of each pick; may
+ * be NULL).  fetch_k <= 64, k <= fetch_k.  Results equal rmu_index_search + rmu_index_mmr called one after the other. */
+int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
+                         int64_t* out_rows, float* out_scores);
+
 /* Persist / restore the corpus matrix (flat file: 64-byte header, liveness bytes, fp32 rows; restart = one H2D copy).
  * Serves: the Milvus-Lite `data.db` the reference re-opens when vector_store_initial_load is False
  * (RAGHelper.py:391, :417; .env.template:33,36).  Tombstones survive (poisoned rows are stored as they are). */

@@ -22,7 +22,7 @@ MAX_DIM = 768
 SYMBOLS = [
     "rmu_init", "rmu_last_error", "rmu_version",
     "rmu_index_create", "rmu_index_free", "rmu_index_size", "rmu_index_dim", "rmu_index_metric", "rmu_index_set_option", "rmu_index_add",
-    "rmu_index_remove_rows", "rmu_index_get_rows", "rmu_index_save", "rmu_index_load", "rmu_index_mmr", "rmu_index_search", "rmu_topk_merge",
+    "rmu_index_remove_rows", "rmu_index_get_rows", "rmu_index_save", "rmu_index_load", "rmu_index_mmr", "rmu_index_search_mmr", "rmu_index_search", "rmu_topk_merge",
     "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing", "rmu_last_screened",
     "rmu_comm_unique_id", "rmu_comm_init", "rmu_comm_free", "rmu_comm_world", "rmu_shard_allgather_topk", "rmu_index_screen_candidates",
     "rmu_bert_create", "rmu_bert_free", "rmu_bert_encode", "rmu_bert_encode_host",
@@ -62,6 +62,7 @@ def _declare(lib):
     lib.rmu_index_remove_rows.argtypes = [vp, vp, i64, c.POINTER(i64)]
     lib.rmu_index_get_rows.argtypes = [vp, vp, i64, vp]
     lib.rmu_index_mmr.argtypes = [vp, vp, i64, vp, i32, i32, c.c_double, u32, vp]
+    lib.rmu_index_search_mmr.argtypes = [vp, vp, i64, i32, i32, c.c_double, i64, vp, vp]
     lib.rmu_index_save.argtypes = [vp, c.c_char_p]
     lib.rmu_index_load.argtypes = [c.POINTER(vp), c.c_char_p]
     lib.rmu_index_search.argtypes = [vp, vp, i64, i32, u32, i64, vp, vp, u64]

@@ -80,7 +80,7 @@ struct Buf {
 struct Tls {
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm, fbq, fb_s, fb_r, fb_i;
+    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm, fbq, fb_s, fb_r, fb_i, mm_q, mm_s, mm_r, mm_p;
     std::vector<hipEvent_t> lev;   // per-launch events of the screening ladder
     int ensure_events(int n) {
         while ((int)lev.size() < n) {
@@ -130,7 +130,7 @@ struct Tls {
         if (pend_ev) (void)hipEventDestroy(pend_ev);
         if (stream) (void)hipStreamSynchronize(stream);
         for (Buf* b : {&q, &partial, &out_s, &out_r, &in_s, &in_r, &qn, &gthr, &mscratch, &qsplit, &ckeys, &flag, &nrm, &fbq, &fb_s,
-                       &fb_r, &fb_i})
+                       &fb_r, &fb_i, &mm_q, &mm_s, &mm_r, &mm_p})
             b->release();
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -290,6 +290,82 @@ __global__ __launch_bounds__(256) void k_mmr(const float* __restrict__ x, int dp
         sel = argmax(lambda * sim_q - (1.0 - lambda) * red, valid && !picked);
     }
     for (int t = want + lane; t < k; t += 64) out_pos[qi * k + t] = -1;
+}
+
+// The same selection for ONE query per workgroup with the candidates staged in LDS: k_mmr's lane walks its own row in global memory
+// one float at a time (a dependent load per fp64 fma: 0.32 ms for the reference's per-request call, 20 candidates, 10 picks); here
+// all 256 threads first copy the <= 64 rows (coalesced) into LDS rows of dim + 1 floats (odd stride: lane i's column c sits in bank
+// (i + c) % 64), then wave 0 runs k_mmr's arithmetic unchanged -- the same fp64 fma chain in the same order, so the picks are
+// bit-identical to k_mmr's.  dim <= 384 (98.6 KiB).
+__global__ __launch_bounds__(256) void k_mmr_lds(const float* __restrict__ x, int dpad, int dim, int64_t n_rows,
+                                                 const float* __restrict__ q, const int64_t* __restrict__ rows, int64_t nq,
+                                                 int fetch_k, int k, double lambda, int* __restrict__ out_pos) {
+    extern __shared__ __attribute__((aligned(16))) float mm[];
+    const int ld = dim + 1;
+    float* qs = mm + 64 * ld;
+    const int64_t qi = blockIdx.x;
+    for (int i = threadIdx.x; i < fetch_k * dim; i += 256) {
+        const int r = i / dim, c = i - r * dim;
+        const int64_t row = rows[qi * fetch_k + r];
+        mm[r * ld + c] = (row >= 0 && row < n_rows) ? x[row * (int64_t)dpad + c] : 0.f;
+    }
+    for (int c = threadIdx.x; c < dim; c += 256) qs[c] = q[qi * dim + c];
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const int64_t row = lane < fetch_k ? rows[qi * fetch_k + lane] : -1;
+    const bool valid = row >= 0 && row < n_rows;
+    const float* xr = mm + (lane < fetch_k ? lane : 0) * ld;
+    double dq = 0.0, nx = 0.0, nqq = 0.0;
+#pragma unroll 16
+    for (int c = 0; c < dim; ++c) {                            // (unrolled: the LDS reads of 16 steps go out ahead of the fma chain)
+        const double a = (double)xr[c], b = (double)qs[c];
+        dq = fma(a, b, dq);
+        nx = fma(a, a, nx);
+        nqq = fma(b, b, nqq);
+    }
+    nx = sqrt(nx); nqq = sqrt(nqq);
+    double sim_q = dq / (nx * nqq);
+    if (!(sim_q == sim_q) || isinf(sim_q)) sim_q = 0.0;
+    const int n_valid = __builtin_popcountll(__ballot(valid));
+    const int want = k < n_valid ? k : n_valid;
+    auto argmax = [&](double v, bool ok) -> int {
+        double m = ok ? v : -INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        const unsigned long long eq = __ballot(ok && v == m);
+        return eq ? __builtin_ctzll(eq) : -1;
+    };
+    bool picked = false;
+    double red = -INFINITY;
+    int sel = argmax(sim_q, valid);
+    for (int t = 0; t < want && sel >= 0; ++t) {
+        if (lane == 0) out_pos[qi * k + t] = sel;
+        if (lane == sel) picked = true;
+        if (t + 1 == want) break;
+        const double ns = __shfl(nx, sel);
+        const float* xs = mm + sel * ld;                       // uniform address: an LDS broadcast
+        double d = 0.0;
+#pragma unroll 16
+        for (int c = 0; c < dim; ++c) d = fma((double)xr[c], (double)xs[c], d);
+        double cs = d / (nx * ns);
+        if (!(cs == cs) || isinf(cs)) cs = 0.0;
+        red = fmax(red, cs);
+        sel = argmax(lambda * sim_q - (1.0 - lambda) * red, valid && !picked);
+    }
+    for (int t = want + lane; t < k; t += 64) out_pos[qi * k + t] = -1;
+}
+
+// picks -> result rows / scores of rmu_index_search_mmr: out[qi, t] = candidate list entry pos[qi, t] (+ row_base), -1 where pos is -1
+__global__ void k_take_picks(const int* __restrict__ pos, const int64_t* __restrict__ rows, const float* __restrict__ scores, int64_t nq,
+                             int fetch_k, int k, int64_t row_base, int64_t* __restrict__ out_rows, float* __restrict__ out_scores) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * k) return;
+    const int64_t qi = i / k;
+    const int p = pos[i];
+    const int64_t r = p >= 0 ? rows[qi * fetch_k + p] : -1;
+    out_rows[i] = r >= 0 ? r + row_base : -1;
+    out_scores[i] = p >= 0 ? scores[qi * fetch_k + p] : -INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -542,6 +618,20 @@ extern "C" int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t
     return RMU_OK;
 }
 
+static void launch_mmr(const rmu_index* idx, const float* dq, const int64_t* dr, int64_t nq, int fetch_k, int k, double lambda_mult, int* dout,
+                       hipStream_t s) {
+    static const bool lds_off = getenv("RMU_MMR_LDS") && atoi(getenv("RMU_MMR_LDS")) == 0;
+    if (idx->dim <= 384 && nq <= 65535 && !lds_off) {          // one workgroup per query, candidates staged in LDS (bit-identical picks)
+        const size_t lds = (size_t)(64 * (idx->dim + 1) + idx->dim) * sizeof(float);
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_mmr_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (64 * 385 + 384) * 4);
+        (void)attr_rc;
+        hipLaunchKernelGGL(k_mmr_lds, dim3((unsigned)nq), dim3(256), lds, s, idx->x, idx->dpad, idx->dim, idx->n, dq, dr, nq, fetch_k, k, lambda_mult, dout);
+    } else {
+        hipLaunchKernelGGL(k_mmr, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, idx->x, idx->dpad, idx->dim, idx->n, dq, dr, nq, fetch_k,
+                           k, lambda_mult, dout);
+    }
+}
+
 extern "C" int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const int64_t* rows, int fetch_k, int k,
                              double lambda_mult, unsigned flags, int32_t* out_pos) {
     if (!idx || !q || !rows || !out_pos) return fail(RMU_E_INVALID, "rmu_index_mmr: null pointer");
@@ -567,11 +657,43 @@ extern "C" int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const
         dr = (const int64_t*)t.in_r.p;
         dout = (int*)t.out_r.p;
     }
-    hipLaunchKernelGGL(k_mmr, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, idx->x, idx->dpad, idx->dim, idx->n, dq, dr, nq, fetch_k,
-                       k, lambda_mult, dout);
+    launch_mmr(idx, dq, dr, nq, fetch_k, k, lambda_mult, dout, s);
     HIP_TRY(hipGetLastError());
     if (!io_dev) HIP_TRY(hipMemcpyAsync(out_pos, dout, (size_t)nq * k * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}
+
+extern "C" int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
+                                    int64_t* out_rows, float* out_scores) {
+    if (!idx || !q || !out_rows) return fail(RMU_E_INVALID, "rmu_index_search_mmr: null pointer");
+    if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1 || k > fetch_k)
+        return fail(RMU_E_INVALID, "rmu_index_search_mmr: nq >= 1, fetch_k in [1, 64], k in [1, fetch_k]");
+    Tls& t = g_tls;
+    int rc = t.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_search_mmr: stream");
+    hipStream_t s = t.stream;
+    const size_t nf = (size_t)nq * fetch_k, nk = (size_t)nq * k;
+    // candidate scores / rows, the raw queries (the search normalises its own copy for COSINE), picks, and the results (rows | scores)
+    if (t.mm_s.ensure(nf * sizeof(float)) || t.mm_r.ensure(nf * sizeof(int64_t)) || t.mm_q.ensure((size_t)nq * idx->dim * sizeof(float)) ||
+        t.mm_p.ensure(nk * (sizeof(int) + sizeof(int64_t) + sizeof(float))))
+        return fail(RMU_E_OOM, "rmu_index_search_mmr: workspace");
+    // the search on this thread's own stream, results left on the device (no synchronisation inside)
+    rc = rmu_index_search(idx, q, nq, fetch_k, RMU_F_OUT_DEVICE, 0, (float*)t.mm_s.p, (int64_t*)t.mm_r.p, (uint64_t)(uintptr_t)s);
+    if (rc) return rc;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    HIP_TRY(hipMemcpyAsync(t.mm_q.p, q, (size_t)nq * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    int64_t* d_rows = (int64_t*)t.mm_p.p;
+    float* d_sc = (float*)(d_rows + nk);
+    int* d_pos = (int*)(d_sc + nk);
+    launch_mmr(idx, (const float*)t.mm_q.p, (const int64_t*)t.mm_r.p, nq, fetch_k, k, lambda_mult, d_pos, s);
+    hipLaunchKernelGGL(k_take_picks, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (const int*)d_pos, (const int64_t*)t.mm_r.p,
+                       (const float*)t.mm_s.p, nq, fetch_k, k, row_base, d_rows, d_sc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_rows, d_rows, nk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (out_scores) HIP_TRY(hipMemcpyAsync(out_scores, d_sc, nk * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    t.finished(s, true);
     return RMU_OK;
 }
 

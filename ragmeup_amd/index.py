@@ -115,6 +115,21 @@ class FlatIndex:
                                         float(lambda_mult), 0, out.ctypes.data), "rmu_index_mmr")
         return out
 
+    def search_mmr(self, q, fetch_k: int, k: int, lambda_mult: float = 0.5, row_base: int = 0):
+        """`search(q, fetch_k)` + `mmr(...)` in one call with one host round trip (rmu_index_search_mmr; the reference's per-request
+        retriever call): q [nq, dim] host fp32 -> (rows [nq, k] int64 in pick order, -1 padded; scores [nq, k] fp32)."""
+        qq = np.ascontiguousarray(q, dtype=np.float32)
+        if qq.ndim == 1:
+            qq = qq[None]
+        if qq.shape[1] != self.dim:
+            raise ValueError(f"expected [nq, {self.dim}] got {qq.shape}")
+        nq = qq.shape[0]
+        rows = np.empty((nq, int(k)), dtype=np.int64)
+        scores = np.empty((nq, int(k)), dtype=np.float32)
+        N.check(self._lib.rmu_index_search_mmr(self._h, qq.ctypes.data, nq, int(fetch_k), int(k), float(lambda_mult), int(row_base),
+                                               rows.ctypes.data, scores.ctypes.data), "rmu_index_search_mmr")
+        return rows, scores
+
     # -- search ------------------------------------------------------------------------------------
     def search(self, q, k: int, row_base: int = 0):
         """Exact top-k.  numpy in -> numpy out; torch CUDA in -> torch CUDA out (same device)."""

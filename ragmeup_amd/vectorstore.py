@@ -456,6 +456,11 @@ class MI355XVectorStore(VectorStore):
     def max_marginal_relevance_search_by_vector(self, embedding, k: int = 4, fetch_k: int = 20,
                                                 lambda_mult: float = 0.5, **kw) -> list[Document]:
         q = np.asarray(embedding, dtype=np.float32)
+        if (self._index is not None and hasattr(self._index, "search_mmr") and len(self._index) > 0
+                and 1 <= k <= min(int(fetch_k), 64)):
+            # dense top-fetch_k and the greedy selection in one library call (rmu_index_search_mmr): one host round trip
+            rows, _ = self._index.search_mmr(q[None], min(int(fetch_k), N.MAX_K, 64), k, lambda_mult)
+            return [self._doc(int(x)) for x in rows[0] if x >= 0]
         s, r = self._search_vecs(q[None], fetch_k)
         rows = [int(x) for x in r[0] if x >= 0]
         if not rows:

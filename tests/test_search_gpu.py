@@ -512,6 +512,53 @@ def test_device_mmr_edges(rmu):
     idx.close()
 
 
+@pytest.mark.parametrize("metric", ["ip", "cosine", "l2"])
+def test_search_mmr_in_one_call_equals_the_two_calls(rmu, metric):
+    """rmu_index_search_mmr == rmu_index_search + rmu_index_mmr (rows in pick order, their search scores), incl. a row_base, fewer
+    live rows than fetch_k, and the error cases."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((5000, 384)).astype(np.float32)
+    q = (x[:33] + 0.6 * rng.standard_normal((33, 384))).astype(np.float32)
+    from ragmeup_amd import _native as NN
+    metric = {"ip": NN.METRIC_IP, "cosine": NN.METRIC_COSINE, "l2": NN.METRIC_L2SQ}[metric]
+    idx = rmu.FlatIndex(384, metric=metric)
+    idx.add(x)
+    s, r = idx.search(q, 20)
+    pos = idx.mmr(q, r, 10, 0.35)
+    rows, sc = idx.search_mmr(q, 20, 10, 0.35, row_base=1000)
+    assert (rows == np.take_along_axis(r, pos.astype(np.int64), axis=1) + 1000).all()
+    assert (sc == np.take_along_axis(s, pos.astype(np.int64), axis=1)).all()
+    one_r, _ = idx.search_mmr(q[5], 20, 10, 0.35)                                  # the per-request shape: one query
+    assert (one_r[0] == np.take_along_axis(r, pos.astype(np.int64), axis=1)[5]).all()
+    idx.close()
+    tiny = rmu.FlatIndex(384, metric=metric)
+    tiny.add(x[:6])
+    rows, sc = tiny.search_mmr(q[:2], 20, 10)
+    assert ((rows[:, :6] >= 0).all() and (rows[:, 6:] == -1).all() and np.isneginf(sc[:, 6:]).all()
+            and sorted(rows[0, :6].tolist()) == list(range(6)))
+    from ragmeup_amd._native import RmuError
+    with pytest.raises(RmuError):
+        tiny.search_mmr(q[:2], 65, 4)
+    with pytest.raises(RmuError):
+        tiny.search_mmr(q[:2], 8, 9)
+    tiny.close()
+
+
+@pytest.mark.parametrize("dim", [100, 768])
+def test_device_mmr_other_dims(rmu, dim):
+    """dim <= 384 takes the LDS-staged kernel (one workgroup per query), wider rows the one-wave-per-query kernel: same picks."""
+    rng = np.random.default_rng(dim)
+    x = rng.standard_normal((3000, dim)).astype(np.float32)
+    q = (x[:40] + 0.5 * rng.standard_normal((40, dim))).astype(np.float32)
+    idx = rmu.FlatIndex(dim)
+    idx.add(x)
+    s, r = idx.search(q, 32)
+    pos = idx.mmr(q, r, 12, 0.4)
+    for i in range(40):
+        assert list(pos[i]) == O.mmr(q[i], x[r[i]], k=12, lambda_mult=0.4)
+    idx.close()
+
+
 def test_vectorstore_batch_mmr_uses_device_and_matches_single(rmu):
     from ragmeup_amd.vectorstore import MI355XVectorStore
     from ragmeup_amd.documents import Document
@@ -531,8 +578,14 @@ def test_vectorstore_batch_mmr_uses_device_and_matches_single(rmu):
     qs = [f"question {i}" for i in range(9)]
     batch = st.max_marginal_relevance_search_batch(qs, k=5, fetch_k=20)
     for qtext, got in zip(qs, batch):
-        single = st.max_marginal_relevance_search(qtext, k=5, fetch_k=20)    # host fp64 path of the drop-in
+        single = st.max_marginal_relevance_search(qtext, k=5, fetch_k=20)    # the reference's per-request call: device selection too
         assert [d.page_content for d in got] == [d.page_content for d in single]
+        # ... and both equal the host fp64 expression (langchain's) on the re-fetched candidate vectors
+        from ragmeup_amd.vectorstore import maximal_marginal_relevance
+        qv = np.asarray(Emb().embed_query(qtext), dtype=np.float32)
+        _, r = st._index.search(qv[None], 20)
+        want = [st._doc(int(r[0][i])).page_content for i in maximal_marginal_relevance(qv, st._index.get_rows(r[0]), 5, 0.5)]
+        assert [d.page_content for d in got] == want
 
 
 # ---- round 2: parity pinned at the headline configuration and on the hardware ------------------------------------------------
