@@ -91,6 +91,7 @@ class BertEncoder:
         self._h = h
         self._lock = threading.Lock()              # one forward at a time per encoder (the library serialises them anyway)
         self._stage = {}                           # slot -> (pinned host int32, device int32) staging pair
+        self._side = None                          # side stream of `upload`
         self.max_pos = int(tens[1].shape[0])
         self.vocab_size = int(tens[0].shape[0])
         del tens                                   # the library keeps its own (bf16 / fp32) copies
@@ -157,7 +158,7 @@ class BertEncoder:
         with self._lock:
             return self._encode_ids_locked(ids, lens, type_ids, mode, out)
 
-    def _stage_in(self, a, slot: str):
+    def _stage_in(self, a, slot: str, min_cap: int = 1 << 16):
         """HOST array -> device int32 through this encoder's pinned staging buffer.  A transient pageable buffer handed to the
         runtime gets registered with the GPU for the copy; freeing it (munmap) then invalidates the registration through the
         kernel driver, which stalls the device queues for ~90 ms at unpredictable later points (measured: add_documents in
@@ -171,13 +172,25 @@ class BertEncoder:
         n = a.size
         st = self._stage.get(slot)
         if st is None or st[0].numel() < n:
-            cap = max(n + n // 4, 1 << 16)
+            cap = max(n + n // 4, min_cap)
             st = (torch.empty(cap, dtype=torch.int32).pin_memory(), torch.empty(cap, dtype=torch.int32, device=self.device))
             self._stage[slot] = st
         if n:
             np.copyto(st[0][:n].numpy().reshape(a.shape), a, casting="unsafe")     # strided views and int64 copy straight in
             st[1][:n].copy_(st[0][:n], non_blocking=True)       # complete before this call returns: encode_ids synchronises
         return st[1][:n].view(a.shape)
+
+    def upload(self, arrays, slot: str, min_cap: int = 1 << 16):
+        """HOST int arrays -> device int32 tensors through the staging pair named `slot`, on a side stream, complete on return.
+        For a caller that prepares the NEXT block while `encode_ids` runs the current one (MI355XEmbeddings' pipeline: the staging
+        copy + H2D of a block's ids then no longer sit between two forwards); the tensors stay valid until `slot` is used again."""
+        torch = self._torch
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self._side):
+            outs = [self._stage_in(a, f"{slot}.{i}", min_cap if i == 0 else 1 << 16) for i, a in enumerate(arrays)]   # sized once: pinning is slow
+        self._side.synchronize()
+        return outs
 
     def _encode_ids_locked(self, ids, lens, type_ids, mode, out):
         torch = self._torch

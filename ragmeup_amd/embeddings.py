@@ -196,7 +196,22 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         from concurrent.futures import ThreadPoolExecutor
         if out is None:
             out = torch.empty((len(texts), 384), dtype=torch.float32, device=self.encoder.device)
-        starts = list(range(0, len(texts), blk))
+        # blocks: a short first one (its tokenisation has nothing to hide behind), then `blk` texts each
+        first = min(blk, max(1024, blk // 4))
+        starts = [0] + list(range(first, len(texts), blk))
+        ends = starts[1:] + [len(texts)]
+        can_upload = isinstance(self.encoder, BertEncoder)
+
+        def prepare(i):
+            """tokenise block i and (native encoder) put its ids on the device: everything the forward needs, off its critical path"""
+            ids, lens = self._tokenize(texts[starts[i]:ends[i]])
+            lens = np.minimum(np.asarray(lens, dtype=np.int32), min(ids.shape[1], self.max_seq_length))
+            Lmax = max(1, int(lens.max(initial=1)))
+            if can_upload and self.one_forward and ids.shape[0] * Lmax <= self.token_budget:
+                ids_d, lens_d = self.encoder.upload([ids[:, :Lmax], lens], slot=f"blk{i & 1}", min_cap=self.token_budget)
+                return ids_d, lens_d, True
+            return ids, lens, False
+
         # Both stages spend their time in librmu.so with the GIL released, but each needs it back for a few lines of Python per
         # block; with CPython's default 5 ms switch interval the encoding thread waited up to that long behind the tokenising
         # thread's string handling, every block (~30 ms per 65536 texts measured).  A short interval for the duration of the call.
@@ -205,12 +220,16 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         sys.setswitchinterval(min(old_switch, 2e-4))
         try:
             with ThreadPoolExecutor(max_workers=1) as pool:
-                fut = pool.submit(self._tokenize, texts[starts[0]:starts[0] + blk])
+                fut = pool.submit(prepare, 0)
                 for i, lo in enumerate(starts):
-                    ids, lens = fut.result()
+                    ids, lens, on_device = fut.result()
                     if i + 1 < len(starts):
-                        fut = pool.submit(self._tokenize, texts[starts[i + 1]:starts[i + 1] + blk])
-                    self.embed_id_arrays(ids, lens, out=out[lo:lo + ids.shape[0]])
+                        fut = pool.submit(prepare, i + 1)
+                    dst = out[lo:lo + ids.shape[0]]
+                    if on_device:
+                        self.encoder.encode_ids(ids, lens, None, mode=self._mode, out=dst)
+                    else:
+                        self.embed_id_arrays(ids, lens, out=dst)
         finally:
             sys.setswitchinterval(old_switch)
         return out
