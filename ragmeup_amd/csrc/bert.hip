@@ -316,7 +316,10 @@ extern __shared__ __attribute__((aligned(16))) char gsm[];
 // Tile = (64*WM tokens) x 128 features, 2*WM waves (each 64 x 64), BK = K-slab per stage, ST = ring stages.
 // The kernel is bound by the L2->LDS operand fill rate (measured ~6-7 TB/s chip-wide), not by MFMA issue:
 // flop per staged byte is what matters (128x128: 64, 256x128: 87), and more resident workgroups beat deeper rings.
-template <int EPI, int WM, int BK, int ST>
+// TA: A and W are TILED copies -- 1-KiB blocks of 16 rows x 32 k in exactly the swizzled image a ring slot holds, blocks in
+// [row block][k block] order (W: k_tile_w; A: the attention kernel writes ctx that way) -- so a DMA wave instruction reads one
+// contiguous KiB (8 cache lines) instead of 16 rows x 64 B (16 lines): the CU's in-order memory queue is paid per line touched.
+template <int EPI, int WM, int BK, int ST, bool TA = false>
 __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                    const float* __restrict__ bias, const bf16* __restrict__ resid,
                                                    bf16* __restrict__ out, const int* __restrict__ cu, int batch, int N, int K, int dbg) {
@@ -358,9 +361,22 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
         wrow[it] = n0 + row;
     }
     const int nk = K / BK;
+    static_assert(!TA || BK == 32, "tiled operands are 32-k blocks");
     auto stage = [&](int kt) {                     // kt may run past nk: harmless reloads keep vmcnt uniform
         const int buf = kt % ST;
         const int k0 = (kt < nk ? kt : nk - 1) * BK;
+        if constexpr (TA) {
+            const int kb = k0 / 32, nkb = K / 32;
+#pragma unroll
+            for (int it = 0; it < NITA; ++it)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)A + ((int64_t)((m0 >> 4) + it * NWV + w) * nkb + kb) * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(As + buf * SLABA + (it * NWV + w) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int it = 0; it < NITW; ++it)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W + ((int64_t)((n0 >> 4) + it * NWV + w) * nkb + kb) * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(Ws + buf * SLABW + (it * NWV + w) * 1024), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NITA; ++it)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (int64_t)arow[it] * K + k0 + acol[it]),
@@ -2156,7 +2172,7 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
 // other's loads in series.
 // ------------------------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch, bf16* __restrict__ ctx) {
+__global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch, bf16* __restrict__ ctx, int ctx_tiled) {
     constexpr int LP = KT * 32;
     constexpr int VSTR = LP * 2 + 16;              // bytes per V^T row (dim): +16 spreads the 32 dims over the banks
     constexpr int KBYTES = LP * 64;
@@ -2311,9 +2327,18 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
                     o1[e] = hh ? rcv[1].v[e] : pc[1].v[e];
                     o1[4 + e] = hh ? pc[3].v[e] : rcv[1].v[e];
                 }
-                bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 16;
-                *(bf16x8*)dst = o0;
-                *(bf16x8*)(dst + 8) = o1;
+                if (ctx_tiled) {
+                    // ctx as the out-proj GEMM's 1-KiB blocks: (16-token block, head) -> [16 rows][4 units of 8 dims], unit u of row r at u ^ ((r >> 2) & 3)
+                    const int64_t m = t0 + q;
+                    const int r = (int)(m & 15), sw = (r >> 2) & 3;
+                    bf16* blk = ctx + ((m >> 4) * NH + head) * 512 + r * 32;
+                    *(bf16x8*)(blk + ((2 * hh) ^ sw) * 8) = o0;
+                    *(bf16x8*)(blk + ((2 * hh + 1) ^ sw) * 8) = o1;
+                } else {
+                    bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 16;
+                    *(bf16x8*)dst = o0;
+                    *(bf16x8*)(dst + 8) = o1;
+                }
             }
         }
         qf[0] = qn[0];
@@ -2598,7 +2623,7 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
             if (p) (void)hipFree(p);
         m->h = m->h1 = m->y = m->qkv = m->ctx = m->mid = nullptr;
         m->ws_tokens = 0;
-        const int64_t t = tokens + tokens / 8 + 128;
+        const int64_t t = tokens + tokens / 8 + 512;       // (+ a whole 256-token tile: the tiled out-proj operand is read in full blocks)
         if (hipMalloc((void**)&m->h, t * H * 2) != hipSuccess || hipMalloc((void**)&m->h1, t * H * 2) != hipSuccess ||
             hipMalloc((void**)&m->y, t * H * 2) != hipSuccess || hipMalloc((void**)&m->qkv, t * 3 * H * 2) != hipSuccess ||
             hipMalloc((void**)&m->ctx, t * H * 2) != hipSuccess || hipMalloc((void**)&m->mid, t * FF * 2) != hipSuccess)
@@ -2616,13 +2641,13 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
     return RMU_OK;
 }
 
-template <int EPI, int WM, int BK, int ST>
+template <int EPI, int WM, int BK, int ST, bool TA = false>
 static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
                             int batch, int64_t m_cap, int N, int K, hipStream_t s) {
     constexpr int BM = 64 * WM;
     constexpr int ring = ST * (BM * BK * 2 + BN * BK * 2), stagebuf = 2 * WM * 64 * 144;
     constexpr int lds = ring > stagebuf ? ring : stagebuf;
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm<EPI, WM, BK, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm<EPI, WM, BK, ST, TA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)attr_rc;
     const int64_t mt = ((m_cap + BM - 1) / BM + 7) / 8 * 8;     // token tiles, padded to a multiple of 8 (XCD map)
     const dim3 grid((unsigned)(mt * (N / BN)));
@@ -2631,7 +2656,7 @@ static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, con
 #else
     constexpr int dbg = 0;
 #endif
-    hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg);
+    hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST, TA>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg);
 }
 template <int EPI>
 static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
@@ -2759,12 +2784,12 @@ static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const 
 }
 
 template <int KT>
-static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
+static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, bool ctx_tiled, hipStream_t s) {
     constexpr int lds = KT * 32 * 64 + 32 * (KT * 32 * 2 + 16);
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_attn3<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)attr_rc;
     const dim3 grid((unsigned)((batch + 7) / 8 * 8 * NH));
-    hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx);
+    hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx, ctx_tiled ? 1 : 0);
 }
 
 template <int MAXT>
@@ -2806,14 +2831,18 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         static const int attn_v = getenv("RMU_ATTN_V") ? atoi(getenv("RMU_ATTN_V")) : 3;   // 1: the round-1/2 kernel k_attention (A/B)
+        // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
+        static const bool tiled_env = !(getenv("RMU_CTX_TILED") && atoi(getenv("RMU_CTX_TILED")) == 0);
+        const bool ctx_tiled = tiled_env && attn_v == 3 && !(g3_mask & 2) && cap > 32768;
         if (attn_v == 3) {
-            if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, s);
-            else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, s);
-            else launch_attn3<16>(batch, m->qkv, m->cu, m->ctx, s);
+            if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
+            else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
+            else launch_attn3<16>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
         } else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
         if (g3_mask & 2) launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
+        else if (ctx_tiled) launch_gemm_cfg<EPI_RESID, 4, 32, 2, true>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
         else launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
         // The fused kernels give each 128-token tile to ONE workgroup, which then streams all 2.36 MB of FFN weights through one
         // CU (~100 us per layer whatever the batch): below ~128 tiles most CUs would idle and the GEMM pair, whose feature tiles
