@@ -461,7 +461,12 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
             bf16x8 o = *(const bf16x8*)(tile + row * TSTR + u * 16);
             const int64_t off = (int64_t)m * N + n0 + wn * 64 + u * 8;
             if (EPI == EPI_RESID) {
-                const bf16x8 rv = *(const bf16x8*)(resid + off);
+                int64_t roff = off;
+                if (dbg & 256) {                   // the residual is a TILED activation (1-KiB blocks of 16 tokens x 32 features, see k_ffn3's store)
+                    const int col = n0 + wn * 64 + u * 8, r = m & 15;
+                    roff = ((int64_t)(m >> 4) * (N / 32) + (col >> 5)) * 512 + r * 32 + ((((col >> 3) & 3) ^ ((r >> 2) & 3)) * 8);
+                }
+                const bf16x8 rv = *(const bf16x8*)(resid + roff);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)(bf2f(o[e]) + bf2f(rv[e]));
             }
@@ -1682,7 +1687,14 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
             bf16x8 ov;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ov[i] = (bf16)((v[i] - mu) * rs * gg[i] + bb[i]);
-            if (act) *(bf16x8*)(out + (int64_t)m * H + c0) = ov;
+            if (act) {
+                // dflags bit 8: the TILED activation form -- 1-KiB blocks of 16 tokens x 32 features, [token block][feature block] order, unit u
+                // (8 features) of row r at u ^ ((r >> 2) & 3): exactly what a ring slot of the next layer's QKV GEMM / the out-proj's
+                // residual piece holds, so their DMA instructions read whole contiguous KiB
+                int64_t off = (int64_t)m * H + c0;
+                if (dflags & 256) { const int r = m & 15; off = ((int64_t)(m >> 4) * (H / 32) + (c0 >> 5)) * 512 + r * 32 + ((((c0 >> 3) & 3) ^ ((r >> 2) & 3)) * 8); }
+                *(bf16x8*)(out + off) = ov;
+            }
         }
     }
 }
@@ -1761,24 +1773,27 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
     int ij = 0, it = 0, islot = 0;
     const char *ia, *iw;
     u32 xoff[2];
+    const bool a_tiled = (dflags & 256) != 0;          // A is a tiled activation (k_ffn3's store form)
+    const size_t astep = a_tiled ? 1024 : 64;          // bytes from one 32-k stage to the next
     const u32 woff = (u32)lane * 16;                   // W is the k_tile_w copy: a DMA instruction reads one contiguous 1-KiB block
     auto set_issue_tile = [&](int j) {
         int m0, n0;
         tile_of(j, m0, n0);
         const int rows_here = M - m0;
-        ia = (const char*)(A + (size_t)m0 * K);
+        ia = a_tiled ? (const char*)A + (size_t)(m0 >> 4) * (K / 32) * 1024 : (const char*)(A + (size_t)m0 * K);
         iw = (const char*)W + (size_t)(n0 / 16) * (K / 32) * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (w + 8 * i) * 16 + (lane >> 2);
             const int rc = row < rows_here ? row : rows_here - 1;
-            xoff[i] = (u32)(((size_t)rc * K + (((lane & 3) ^ (lane >> 4)) * 8)) * 2);
+            // tiled A (1-KiB blocks of 16 tokens x 32 k, already in slot order): piece xi of stage `it` = block (m0 / 16 + xi, it), read whole
+            xoff[i] = a_tiled ? (u32)((w + 8 * i) * (K / 32) * 1024 + lane * 16) : (u32)(((size_t)rc * K + (((lane & 3) ^ (lane >> 4)) * 8)) * 2);
         }
     };
     auto issue_x = [&](int i) {
         u32 o = xoff[i];
         asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(ia + (size_t)it * 64) + o),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(ia + (size_t)it * astep) + o),
                                          (__attribute__((address_space(3))) void*)(ring + islot * SLOT + (w + 8 * i) * 1024), 16, 0, 0);
     };
     auto issue_w = [&](int i) {
@@ -2643,7 +2658,7 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
 
 template <int EPI, int WM, int BK, int ST, bool TA = false>
 static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
-                            int batch, int64_t m_cap, int N, int K, hipStream_t s) {
+                            int batch, int64_t m_cap, int N, int K, hipStream_t s, bool resid_tiled = false) {
     constexpr int BM = 64 * WM;
     constexpr int ring = ST * (BM * BK * 2 + BN * BK * 2), stagebuf = 2 * WM * 64 * 144;
     constexpr int lds = ring > stagebuf ? ring : stagebuf;
@@ -2654,9 +2669,9 @@ static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, con
 #ifdef RMU_DEBUG_KERNELS
     static const int dbg = getenv("RMU_GEMM_DBG") ? atoi(getenv("RMU_GEMM_DBG")) : 0;   // timing ablations: 1 no stores, 2 no main loop
 #else
-    constexpr int dbg = 0;
+    const int dbg = 0;
 #endif
-    hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST, TA>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg);
+    hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST, TA>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg | (resid_tiled ? 256 : 0));
 }
 template <int EPI>
 static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
@@ -2723,7 +2738,7 @@ static void launch_ffn2(const bf16* x, bool ln_in, const BertLayer& L, float eps
 }
 
 template <bool LN_IN, int PF, int VAR>
-static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
+static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s, bool out_tiled) {
     const dim3 grid((unsigned)((m_cap + ffn3::TOK - 1) / ffn3::TOK));
     const bf16* w1 = (VAR & 2) ? L.w1s : L.w1;
     const bf16* w2 = (VAR & 2) ? L.w2s : L.w2p;
@@ -2733,31 +2748,31 @@ static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* ou
         static const hipError_t attr_d = hipFuncSetAttribute((const void*)k_ffn3<LN_IN, PF, true, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
         (void)attr_d;
         hipLaunchKernelGGL((k_ffn3<LN_IN, PF, true, VAR>), grid, dim3(512), ffn3::LDS_BYTES, s, x, w1, L.b1, w2, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
-                           L.ln1g, L.ln1b, dflags);
+                           L.ln1g, L.ln1b, dflags | (out_tiled ? 256 : 0));
         return;
     }
 #endif
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_ffn3<LN_IN, PF, false, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
     (void)attr_rc;
     hipLaunchKernelGGL((k_ffn3<LN_IN, PF, false, VAR>), grid, dim3(512), ffn3::LDS_BYTES, s, x, w1, L.b1, w2, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
-                       L.ln1g, L.ln1b, 0);
+                       L.ln1g, L.ln1b, out_tiled ? 256 : 0);
 }
-static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
+static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s, bool out_tiled = false) {
 #ifdef RMU_DEBUG_KERNELS
     // A/B forms (measured, 8192 chunks, per launch: VAR 0 3227 us, 1 3404, 2 3245, 3 3370 -- the packed-f32 activation is SLOWER than
     // hipcc's mostly scalar one although the loop shrinks from 431 to 357 instructions, and the stream form of the weights changes nothing)
     static const int var = getenv("RMU_FFN3_VAR") ? atoi(getenv("RMU_FFN3_VAR")) : 0;
-#define RMU_FFN3_CASE(V) case V: if (ln_in) launch_ffn3_t<true, 4, V>(x, L, eps, out, cu, batch, m_cap, s); else launch_ffn3_t<false, 4, V>(x, L, eps, out, cu, batch, m_cap, s); return;
+#define RMU_FFN3_CASE(V) case V: if (ln_in) launch_ffn3_t<true, 4, V>(x, L, eps, out, cu, batch, m_cap, s, out_tiled); else launch_ffn3_t<false, 4, V>(x, L, eps, out, cu, batch, m_cap, s, out_tiled); return;
     switch (var & 3) { RMU_FFN3_CASE(1) RMU_FFN3_CASE(2) RMU_FFN3_CASE(3) default: break; }
 #undef RMU_FFN3_CASE
 #endif
-    if (ln_in) launch_ffn3_t<true, 4, 0>(x, L, eps, out, cu, batch, m_cap, s);
-    else launch_ffn3_t<false, 4, 0>(x, L, eps, out, cu, batch, m_cap, s);
+    if (ln_in) launch_ffn3_t<true, 4, 0>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
+    else launch_ffn3_t<false, 4, 0>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
 }
 
 template <int EPI>
 static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu, int batch,
-                         int N, int K, hipStream_t s) {
+                         int N, int K, hipStream_t s, bool a_tiled = false) {
     static const int n_wg = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus / 8 * 8; }();
 #ifdef RMU_DEBUG_KERNELS
     static const bool want_dbg = getenv("RMU_G3_DBG") != nullptr;
@@ -2780,7 +2795,7 @@ static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const 
 #endif
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm3<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
     (void)attr_rc;
-    hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, a_tiled ? 256 : 0);
 }
 
 template <int KT>
@@ -2826,9 +2841,12 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
                        m->cfg.type_vocab, m->h);
     const dim3 ln_grid((unsigned)((cap + 4 * LN_ROWS - 1) / (4 * LN_ROWS)));
     const dim3 at_grid(NH, (unsigned)batch);   // k_attention: one workgroup per (head, sequence); k_attn3: one per sequence
+    size_t li = 0;
+    bool h_in_tiled = false;                   // m->h as this layer reads it: row-major from k_embed_ln, tiled from a k_ffn3 that was told so
     for (const BertLayer& L : m->layers) {
+        ++li;
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
-        if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s);
+        if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         static const int attn_v = getenv("RMU_ATTN_V") ? atoi(getenv("RMU_ATTN_V")) : 3;   // 1: the round-1/2 kernel k_attention (A/B)
         // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
@@ -2842,7 +2860,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
         if (g3_mask & 2) launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
-        else if (ctx_tiled) launch_gemm_cfg<EPI_RESID, 4, 32, 2, true>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
+        else if (ctx_tiled) launch_gemm_cfg<EPI_RESID, 4, 32, 2, true>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s, h_in_tiled);
         else launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
         // The fused kernels give each 128-token tile to ONE workgroup, which then streams all 2.36 MB of FFN weights through one
         // CU (~100 us per layer whatever the batch): below ~128 tiles most CUs would idle and the GEMM pair, whose feature tiles
@@ -2856,10 +2874,16 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         static const int ffn_v = getenv("RMU_FFN_V") ? atoi(getenv("RMU_FFN_V")) : 3;
         static const bool ln_in = !(getenv("RMU_FFN_LNIN") && atoi(getenv("RMU_FFN_LNIN")) == 0);
         if (fused_ffn && ffn_v >= 2 && ln_in) {
-            if (ffn_v == 3) launch_ffn3(m->y, true, L, eps, m->h, m->cu, batch, cap, s);
+            // Between layers h travels TILED (1-KiB blocks of 16 tokens x 32 features: the next QKV GEMM's A pieces and the next out-proj's
+            // residual pieces become whole contiguous KiB); the last layer writes row-major for the pooling heads.  RMU_H_TILED=0: never.
+            static const bool h_env = !(getenv("RMU_H_TILED") && atoi(getenv("RMU_H_TILED")) == 0);
+            const bool h_out_tiled = h_env && ffn_v == 3 && ctx_tiled && (g3_mask & 1) && li < m->layers.size();
+            if (ffn_v == 3) launch_ffn3(m->y, true, L, eps, m->h, m->cu, batch, cap, s, h_out_tiled);
             else launch_ffn2(m->y, true, L, eps, m->h, m->cu, batch, cap, s);
+            h_in_tiled = h_out_tiled;
             continue;
         }
+        h_in_tiled = false;
         hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln1g, L.ln1b, eps, m->h1);
         if (g3_mask & 4) {
             launch_gemm3<EPI_GELU>(m->h1, L.w1_t, L.b1, nullptr, m->mid, m->cu, batch, FF, H, s);
