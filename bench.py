@@ -188,7 +188,7 @@ def encoder_flops(lens) -> float:
 
 
 def encoder_roofline(tf: float) -> dict:
-    return {"kernel": "whole forward: k_ffn3 (bf16 MFMA 32x32x16, two waves per SIMD: LayerNorm1 + FFN1 + GELU + FFN2 + residual + LayerNorm2), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj + residual), k_attn3 (32x32x16, two-pass softmax off the MFMA accumulator), k_embed_ln, k_pool", "bound": "mfma", "achieved": round(tf, 2),
+    return {"kernel": "whole forward: k_ffn3 (bf16 MFMA 32x32x16, two waves per SIMD: LayerNorm1 + FFN1 + GELU + FFN2 + residual + LayerNorm2), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj + residual, both operands as 1-KiB tiled blocks), k_attn3 (32x32x16, two-pass softmax off the MFMA accumulator), k_embed_ln, k_pool", "bound": "mfma", "achieved": round(tf, 2),
             "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
             "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches)"}
 

@@ -20,7 +20,7 @@ STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.
 
 def short(n):
     m = re.search(r'(scan_topk_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
-                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm_small|k_gemm<\d, \d, \d+, \d>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
+                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm_small|k_gemm<\d, \d, \d+, \d(?:, \w+)?>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
     s = m.group(1) if m else n[:40]
     if s in ('scan_topk_kernel',):
         c = re.search(r'Cfg<([^>]*)>', n)
