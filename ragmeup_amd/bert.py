@@ -92,6 +92,7 @@ class BertEncoder:
         self._lock = threading.Lock()              # one forward at a time per encoder (the library serialises them anyway)
         self._stage = {}                           # slot -> (pinned host int32, device int32) staging pair
         self._side = None                          # side stream of `upload`
+        self.pipeline_lock = threading.Lock()      # one user of the `upload` slots at a time (MI355XEmbeddings' block pipeline)
         self.max_pos = int(tens[1].shape[0])
         self.vocab_size = int(tens[0].shape[0])
         del tens                                   # the library keeps its own (bf16 / fp32) copies

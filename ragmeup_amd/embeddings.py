@@ -215,11 +215,15 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         # Both stages spend their time in librmu.so with the GIL released, but each needs it back for a few lines of Python per
         # block; with CPython's default 5 ms switch interval the encoding thread waited up to that long behind the tokenising
         # thread's string handling, every block (~30 ms per 65536 texts measured).  A short interval for the duration of the call.
+        import contextlib
         import sys
         old_switch = sys.getswitchinterval()
         sys.setswitchinterval(min(old_switch, 2e-4))
+        # the upload slots belong to ONE pipeline at a time: a second thread embedding a large batch on the same encoder waits here
+        # (the GPU is the shared resource either way)
+        guard = self.encoder.pipeline_lock if can_upload else contextlib.nullcontext()
         try:
-            with ThreadPoolExecutor(max_workers=1) as pool:
+            with guard, ThreadPoolExecutor(max_workers=1) as pool:
                 fut = pool.submit(prepare, 0)
                 for i, lo in enumerate(starts):
                     ids, lens, on_device = fut.result()
