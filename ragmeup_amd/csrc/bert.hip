@@ -2689,6 +2689,7 @@ static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const b
     return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
 }
 
+#ifdef RMU_DEBUG_KERNELS
 // The cycle-counter / ablation instantiations (k_ffn_fused<true>, k_gemm3<*, true>: RMU_FFN_DBG, RMU_G3_DBG) exist only in a
 // build with -DRMU_DEBUG_KERNELS (python -m ragmeup_amd.build --debug-kernels): the product library carries one instantiation
 // of every kernel it can actually take.
@@ -2719,6 +2720,8 @@ static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16
     hipLaunchKernelGGL(k_ffn_fused<false>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
                        (unsigned long long*)nullptr);
 }
+
+#endif
 
 template <bool LN_IN, int GV, int PF>
 static void launch_ffn2_t(const bf16* x, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
@@ -2807,6 +2810,7 @@ static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, b
     hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx, ctx_tiled ? 1 : 0);
 }
 
+#ifdef RMU_DEBUG_KERNELS
 template <int MAXT>
 static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
     constexpr int lds = MAXT * 16 * 80 + DH * (MAXT * 16 * 2 + 8);
@@ -2814,6 +2818,7 @@ static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hi
     (void)attr_rc;
     hipLaunchKernelGGL(k_attention<MAXT>, grid, dim3(256), lds, s, qkv, cu, ctx);
 }
+#endif
 
 static int check_encode_args(rmu_bert_t* m, const void* ids, const void* lens, const void* out, int batch, int max_len, int mode, int64_t out_stride) {
     if (!m || !ids || !lens || !out) return bfail(RMU_E_INVALID, "rmu_bert_encode: null argument");
@@ -2848,7 +2853,13 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
         if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
-        static const int attn_v = getenv("RMU_ATTN_V") ? atoi(getenv("RMU_ATTN_V")) : 3;   // 1: the round-1/2 kernel k_attention (A/B)
+        // The round-1/2 kernels k_attention and k_ffn_fused are instantiated in debug builds only (RMU_ATTN_V=1, RMU_FFN_V=1: the A/B
+        // numbers of DESIGN.md); the product library carries the kernels it takes by default plus k_ffn2 (RMU_FFN_V=2).
+#ifdef RMU_DEBUG_KERNELS
+        static const int attn_v = getenv("RMU_ATTN_V") ? atoi(getenv("RMU_ATTN_V")) : 3;
+#else
+        constexpr int attn_v = 3;
+#endif
         // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
         static const bool tiled_env = !(getenv("RMU_CTX_TILED") && atoi(getenv("RMU_CTX_TILED")) == 0);
         const bool ctx_tiled = tiled_env && attn_v == 3 && !(g3_mask & 2) && cap > 32768;
@@ -2856,9 +2867,12 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
             if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
             else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
             else launch_attn3<16>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
-        } else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
+        }
+#ifdef RMU_DEBUG_KERNELS
+        else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
+#endif
         if (g3_mask & 2) launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
         else if (ctx_tiled) launch_gemm_cfg<EPI_RESID, 4, 32, 2, true>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s, h_in_tiled);
         else launch_gemm<EPI_RESID>(m->ctx, L.wo, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s);
@@ -2871,7 +2885,11 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // k_ffn3 (default; two waves per SIMD) and k_ffn2 (RMU_FFN_V=2; one) also take LayerNorm 1 into their prologue: the out-proj sum y
         // goes straight in (RMU_FFN_LNIN=0: separate k_layernorm launch; RMU_FFN_V=1: the round-2 kernel k_ffn_fused -- both kept
         // this round for the A/B numbers in DESIGN.md)
+#ifdef RMU_DEBUG_KERNELS
         static const int ffn_v = getenv("RMU_FFN_V") ? atoi(getenv("RMU_FFN_V")) : 3;
+#else
+        static const int ffn_v = getenv("RMU_FFN_V") && atoi(getenv("RMU_FFN_V")) == 2 ? 2 : 3;
+#endif
         static const bool ln_in = !(getenv("RMU_FFN_LNIN") && atoi(getenv("RMU_FFN_LNIN")) == 0);
         if (fused_ffn && ffn_v >= 2 && ln_in) {
             // Between layers h travels TILED (1-KiB blocks of 16 tokens x 32 features: the next QKV GEMM's A pieces and the next out-proj's
@@ -2894,7 +2912,9 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         if (fused_ffn) {          // FFN1 + GELU + FFN2 + residual + LayerNorm in one kernel: the 1536-wide intermediate stays on chip
             if (ffn_v == 3) launch_ffn3(m->h1, false, L, eps, m->h, m->cu, batch, cap, s);
             else if (ffn_v == 2) launch_ffn2(m->h1, false, L, eps, m->h, m->cu, batch, cap, s);
+#ifdef RMU_DEBUG_KERNELS
             else launch_ffn_fused(m->h1, L, eps, m->h, m->cu, batch, cap, s);
+#endif
             continue;
         }
         launch_gemm<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, cap, FF, H, s);

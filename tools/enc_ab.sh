@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of encoder kernel variants ON THE GPU BOX: per-kernel durations (rocprofv3 --kernel-trace --stats) and the encode rate of
-# tools/enc_smoke.py for each "name:VAR=val,VAR=val" spec.   bash tools/enc_ab.sh default: old:RMU_FFN_V=1 scalar:RMU_FFN_GELU=1
+# tools/enc_smoke.py for each "name:VAR=val,VAR=val" spec.   bash tools/enc_ab.sh default: ffn2:RMU_FFN_V=2 rowmajor:RMU_H_TILED=0,RMU_CTX_TILED=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for spec in "$@"; do
