@@ -1285,12 +1285,13 @@ static_assert(LDS_BYTES <= 160 * 1024 && TOK * TSTR <= LDS_BYTES, "LDS");
 __host__ __device__ constexpr int wait_n(int i) { return i == 0 ? 7 : i == 1 ? 8 : i == 2 ? 6 : i == 3 ? 3 : 6; }
 }  // namespace ffn3
 
-template <bool LN_IN, int PF, bool DBG, int VAR>   // VAR bit 0: activation as packed-f32 instructions (else hipcc's vector code), bit 1: k_pack_ffn3 weight streams (else W1 / W2p rows); DBG: ablation flags (RMU_FFN3_DBG, debug build): 1 no activation, 2 no fragment reads, 4 no DMA, 8 no exchange, 16 no barriers
+template <bool LN_IN, int PF, bool DBG, int VAR, bool OP = false>   // OP: x is the attention output ctx -- the out-proj GEMM + bias + residual runs in the prologue (see below); VAR bit 0: activation as packed-f32 instructions (else hipcc's vector code), bit 1: k_pack_ffn3 weight streams (else W1 / W2p rows); DBG: ablation flags (RMU_FFN3_DBG, debug build): 1 no activation, 2 no fragment reads, 4 no DMA, 8 no exchange, 16 no barriers
 __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const bf16* __restrict__ W1, const float* __restrict__ b1,
                                               const bf16* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ g,
                                               const float* __restrict__ bta, float eps, bf16* __restrict__ out,
                                               const int* __restrict__ cu, int batch, const float* __restrict__ g1,
-                                              const float* __restrict__ bta1, int dflags) {
+                                              const float* __restrict__ bta1, int dflags, const bf16* __restrict__ wo = nullptr,
+                                              const float* __restrict__ bo = nullptr, const bf16* __restrict__ resid = nullptr) {
     using namespace ffn3;
     using ffn::static_for; using ffn::ds_read16;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -1307,14 +1308,134 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
 
     // ---- this half's k range of the token rows as B fragments; b1 into LDS ---------------------------------------------------
     bf16x8 hf[12];
-    {
+    if constexpr (!OP) {
         const int tok = min(m0 + 32 * p + r31, M - 1);
         const bf16* row = x + (int64_t)tok * H + s * 192 + hh * 8;
 #pragma unroll
         for (int j = 0; j < 12; ++j) hf[j] = *(const bf16x8*)(row + j * 16);
     }
     for (int i = threadIdx.x; i < FF; i += 512) b1s[i] = b1[i];
-    if (LN_IN) {
+    if constexpr (OP) {
+        // ---- the attention block's output projection, here instead of in a launch of its own: y = ctx . Wo^T + bo + h for this wave's
+        // 32 tokens x ITS 192 features (the half s it needs as token fragments), then LayerNorm 1 -- the pre-LN sum never exists in memory,
+        // the out-proj launch (0.56 ms per layer, 2.4 GB of traffic) and the statistics re-read are gone; the price is 144 MFMAs per wave in
+        // front of the 1200 of the FFN and 288 KiB of Wo through the ring.  Same operand roles as FFN2: A = Wo rows out of W2-shaped slabs
+        // ([384 rows][32 k], 12 of them through FOUR 24-KiB slots = the whole ring), B = the ctx rows of the tokens (all 24 k-steps in registers
+        // for the duration, 96; the FFN's accumulators are not live yet), D = features x tokens.  D's register layout (register 4 q + e of
+        // lane half hh = feature 8 q + 4 hh + e of the tile) IS a k-permuted B fragment -- as for FFN2's activations -- so LayerNorm's output goes
+        // straight into the token fragments and W1 is read from its k-permuted copy (k_permute_w2 on W1: L.w1p); the residual of FFN2's
+        // outputs is then the same register of the same lane (no lane exchange in the epilogue).
+        const int tok = min(m0 + 32 * p + r31, M - 1);
+        bf16x8 cf[24];
+        if (dflags & 512) {                      // tiled ctx (k_attn3's store): block (token / 16, head = k / 32), unit ^ ((r >> 2) & 3)
+            const int r = tok & 15, sw = (r >> 2) & 3;
+            const bf16* blk = x + (int64_t)(tok >> 4) * (NH * 512) + r * 32;
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks) cf[ks] = *(const bf16x8*)(blk + (ks >> 1) * 512 + ((((ks & 1) * 2 + hh) ^ sw) * 8));
+        } else {
+            const bf16* row = x + (int64_t)tok * H + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks) cf[ks] = *(const bf16x8*)(row + ks * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // ordinary loads done before the first LDS-DMA (hipcc drains the DMA queue for them otherwise)
+        f32x16 co[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) co[j][r] = 0.f;
+        u32 wooff0;
+        {
+            const int row2 = w * 16 + (lane >> 2), p2 = lane & 3;
+            wooff0 = (u32)((row2 * H + ((p2 ^ ((row2 >> 2) & 3)) * 8)) * 2);
+        }
+        auto issue_wo = [&](int kb) {            // slab kb (clamped: harmless re-loads keep the counted wait uniform) into slot kb & 3
+            const u32 kc = (u32)(kb < 12 ? kb : 11);
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const u32 o = wooff0 + (kc * 64u + (u32)(it * (128 * H * 2)));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)wo + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + (kb & 3) * S2 + (it * 8 + w) * 1024), 16, 0, 0);
+            }
+        };
+        const u32 lds0p = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)gsm;
+        u32 ao[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) ao[k2] = lds0p + (u32)((192 * s + r31) * 64 + (((2 * k2 + hh) ^ ((r31 >> 2) & 3)) * 16));
+        issue_wo(0); issue_wo(1); issue_wo(2);
+        bf16x8 fo[4];
+#pragma unroll
+        for (int kb = 0; kb < 12; ++kb) {                     // (unrolled: the ctx fragments are indexed by kb)
+            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");     // slab kb landed (own pieces); the two younger slabs may be in flight
+            __builtin_amdgcn_s_barrier();                                     // ... everybody's pieces; and slot (kb + 3) & 3 = slab kb - 1's is free
+            issue_wo(kb + 3);
+            const u32 base0 = ao[0] + (u32)((kb & 3) * S2), base1 = ao[1] + (u32)((kb & 3) * S2);
+            // 2 k-steps x 6 tiles, fragments four ahead, one counted wait per two MFMAs (as the FFN2 slabs below)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) asm volatile("ds_read_b128 %0, %1" : "=v"(fo[n]) : "v"(base0 + (u32)(n * 2048)));
+            const bf16x8 cf0 = cf[2 * kb], cf1 = cf[2 * kb + 1];
+            static_for<12>([&, base0, base1, cf0, cf1](auto nc) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n % 2 == 0)
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fo[n % 4]), "+v"(fo[(n + 1) % 4]) : "n"(n + 4 <= 12 ? 2 : 12 - 2 - n));
+                co[n % 6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[n % 4], n / 6 ? cf1 : cf0, co[n % 6], 0, 0, 0);
+                if constexpr (n + 4 < 12) asm volatile("ds_read_b128 %0, %1" : "=v"(fo[n % 4]) : "v"(((n + 4) / 6 ? base1 : base0) + (u32)(((n + 4) % 6) * 2048)));
+                else asm volatile("" : "+v"(fo[n % 4]));
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // tail re-loads drained before the residual's ordinary loads
+        // y = bf16(bf16(acc + bo) + h) (the out-proj kernel's rounding points), kept as fp32 of those bf16 values
+        float sm = 0.f;
+        {
+            const int r = tok & 15, sw = (r >> 2) & 3;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = s * 192 + j * 32 + q * 8 + hh * 4;
+                    const bf16* rp = (dflags & 1024) ? resid + ((int64_t)(tok >> 4) * (H / 32) + (f0 >> 5)) * 512 + r * 32 + ((((f0 >> 3) & 3) ^ sw) * 8) + (f0 & 7)
+                                                     : resid + (int64_t)tok * H + f0;
+                    const bf16x4 rv = *(const bf16x4*)rp;
+                    const f32x4 bv = *(const f32x4*)(bo + f0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = bf2f((bf16)(bf2f((bf16)(co[j][4 * q + e] + bv[e])) + bf2f(rv[e])));
+                        co[j][4 * q + e] = yv;
+                        sm += yv;
+                    }
+                }
+        }
+        float* sc = (float*)(gsm + XP_OFF);
+        sm += __shfl_xor(sm, 32);
+        if (hh == 0) sc[w * 32 + r31] = sm;
+        __syncthreads();
+        sm += sc[(w ^ 4) * 32 + r31];
+        const float mu = sm * (1.0f / H);
+        float qv = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = co[j][r] - mu; qv = fmaf(d, d, qv); }
+        qv += __shfl_xor(qv, 32);
+        if (hh == 0) sc[256 + w * 32 + r31] = qv;
+        __syncthreads();
+        qv += sc[256 + (w ^ 4) * 32 + r31];
+        const float rs = rsqrtf(qv * (1.0f / H) + eps);
+        // token fragment of k-step 2 j + qh = registers of tile j, q in {2 qh, 2 qh + 1}: elements [0, 4) <- q even, [4, 8) <- q odd
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                bf16x8 o;
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int q = 2 * qh + qb, f0 = s * 192 + j * 32 + q * 8 + hh * 4;
+                    const f32x4 ga = *(const f32x4*)(g1 + f0), ba = *(const f32x4*)(bta1 + f0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[4 * qb + e] = (bf16)((co[j][4 * q + e] - mu) * rs * ga[e] + ba[e]);
+                }
+                hf[2 * j + qh] = o;
+            }
+    } else if (LN_IN) {
         // h1 = bf16(LN1(y)): statistics over all 384 values of the token = this lane's 96, lane ^ 32's, and the partner wave's
         // two lanes' (through LDS).  Same arithmetic as k_ffn2 (fp32, two passes) up to the order of the partial sums.
         float* sc = (float*)(gsm + XP_OFF);
@@ -1642,13 +1763,16 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
                 const u32x4 hv = __builtin_bit_cast(u32x4, hf[2 * j + qq]);
                 const u32x2 own = hh ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]};
                 const u32x2 oth = hh ? u32x2{hv[0], hv[1]} : u32x2{hv[2], hv[3]};
-                u32x2 rcv;
-                rcv[0] = (u32)__shfl_xor((int)oth[0], 32);
-                rcv[1] = (u32)__shfl_xor((int)oth[1], 32);
+                u32x2 rcv = {0u, 0u};
+                if constexpr (!OP) {
+                    rcv[0] = (u32)__shfl_xor((int)oth[0], 32);
+                    rcv[1] = (u32)__shfl_xor((int)oth[1], 32);
+                }
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     const int q = 2 * qq + qb;
-                    const u32x2 rs2 = (qb == hh) ? own : rcv;
+                    // OP: the fragments are in accumulator order -- elements [4 qb, +4) of this lane's k-step 2 j + qq ARE features 8 q + 4 hh + e
+                    const u32x2 rs2 = OP ? (qb ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]}) : ((qb == hh) ? own : rcv);
                     const bf16x4 res = __builtin_bit_cast(bf16x4, rs2);
                     const int n = s * 192 + j * 32 + q * 8 + hh * 4;
                     const f32x4 bv = *(const f32x4*)(b2 + n);
@@ -2463,6 +2587,7 @@ __global__ __launch_bounds__(128) void k_cls_head(const bf16* __restrict__ h, co
 struct BertLayer {
     bf16 *wqkv, *wo, *w1, *w2;
     bf16* w2p;      // W2 with the columns of every 32-block permuted to the fused FFN kernel's k-slot order
+    bf16* w1p;      // (debug builds) W1 with the same permutation of ITS columns: k_ffn3's fused out-proj prologue builds the token fragments in accumulator order
     bf16 *wqkv_t, *wo_t, *w1_t, *w2_t;   // k_tile_w copies for k_gemm3
     bf16 *w1s, *w2s;                     // k_pack_ffn3 streams for k_ffn3's VAR bit 1 (debug builds only; nullptr otherwise)
     float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
@@ -2583,6 +2708,10 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
         rc |= copy_f32(m, &L.ln1b, wptr[wi++], H, 1.f, s);
         rc |= dev_alloc(m, &L.w1, (size_t)FF * H);
         if (!rc) conv_bf16(L.w1, wptr[wi], (size_t)FF * H, 1.f, s);
+#ifdef RMU_DEBUG_KERNELS
+        rc |= dev_alloc(m, &L.w1p, (size_t)FF * H);
+        if (!rc) hipLaunchKernelGGL(k_permute_w2, dim3((unsigned)(((size_t)FF * H + 255) / 256)), dim3(256), 0, s, (const bf16*)L.w1, L.w1p, (int64_t)FF * H);
+#endif
         wi++;
         rc |= copy_f32(m, &L.b1, wptr[wi++], FF, 1.f, s);
         rc |= dev_alloc(m, &L.w2, (size_t)H * FF);
@@ -2760,6 +2889,20 @@ static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* ou
     hipLaunchKernelGGL((k_ffn3<LN_IN, PF, false, VAR>), grid, dim3(512), ffn3::LDS_BYTES, s, x, w1, L.b1, w2, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
                        L.ln1g, L.ln1b, out_tiled ? 256 : 0);
 }
+#ifdef RMU_DEBUG_KERNELS
+// the attention output in, the layer output out: out-proj + residual + LayerNorm 1 + FFN + LayerNorm 2 in one launch.  MEASURED (8192
+// chunks, same box): 3830 us per launch against 3314 (k_ffn3) + 569 (out-proj k_gemm) = 3883 -- the prologue's 12 barrier-separated slabs
+// of 12 MFMAs per wave run at a third of the main loop's rate and eat what the saved launch and the 2.4 GB of traffic gave: -1.4 % per
+// layer, not worth a second k_ffn3 instantiation, a third copy of W1 and 40 bytes of scratch.  Debug builds: RMU_FFN_OUTPROJ=1.
+static void launch_ffn3_outproj(const bf16* ctx, bool ctx_tiled, const bf16* resid, bool resid_tiled, const BertLayer& L, float eps, bf16* out,
+                                const int* cu, int batch, int64_t m_cap, hipStream_t s, bool out_tiled) {
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_ffn3<true, 4, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
+    (void)attr_rc;
+    const dim3 grid((unsigned)((m_cap + ffn3::TOK - 1) / ffn3::TOK));
+    hipLaunchKernelGGL((k_ffn3<true, 4, false, 0, true>), grid, dim3(512), ffn3::LDS_BYTES, s, ctx, L.w1p, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
+                       L.ln1g, L.ln1b, (out_tiled ? 256 : 0) | (ctx_tiled ? 512 : 0) | (resid_tiled ? 1024 : 0), L.wo, L.bo, resid);
+}
+#endif
 static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s, bool out_tiled = false) {
 #ifdef RMU_DEBUG_KERNELS
     // A/B forms (measured, 8192 chunks, per launch: VAR 0 3227 us, 1 3404, 2 3245, 3 3370 -- the packed-f32 activation is SLOWER than
@@ -2872,6 +3015,21 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);
         else if (max_len <= 256) launch_attn<16>(at_grid, m->qkv, m->cu, m->ctx, s);
         else launch_attn<32>(at_grid, m->qkv, m->cu, m->ctx, s);
+#endif
+#ifdef RMU_DEBUG_KERNELS
+        // RMU_FFN_OUTPROJ=1: the out-proj GEMM runs inside k_ffn3's prologue (no launch, no pre-LN sum in memory)
+        static const bool op_env = getenv("RMU_FFN_OUTPROJ") && atoi(getenv("RMU_FFN_OUTPROJ")) != 0;
+        static const int fused_env0 = getenv("RMU_FUSED_FFN") ? atoi(getenv("RMU_FUSED_FFN")) : -1;
+        static const bool lnin0 = !(getenv("RMU_FFN_LNIN") && atoi(getenv("RMU_FFN_LNIN")) == 0);
+        static const bool v3 = !(getenv("RMU_FFN_V") && atoi(getenv("RMU_FFN_V")) != 3);
+        if (op_env && v3 && lnin0 && !(g3_mask & 6) && attn_v == 3 && (fused_env0 < 0 ? cap > 16384 : fused_env0 != 0)) {
+            static const bool h_env0 = !(getenv("RMU_H_TILED") && atoi(getenv("RMU_H_TILED")) == 0);
+            const bool h_out_tiled = h_env0 && ctx_tiled && (g3_mask & 1) && li < m->layers.size();
+            launch_ffn3_outproj(m->ctx, ctx_tiled, m->h, h_in_tiled, L, eps, m->h1, m->cu, batch, cap, s, h_out_tiled);
+            std::swap(m->h, m->h1);                // the kernel reads the residual h while other workgroups write the layer output: two buffers
+            h_in_tiled = h_out_tiled;
+            continue;
+        }
 #endif
         if (g3_mask & 2) launch_gemm3<EPI_RESID>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, H, H, s);
         else if (ctx_tiled) launch_gemm_cfg<EPI_RESID, 4, 32, 2, true>(m->ctx, L.wo_t, L.bo, m->h, m->y, m->cu, batch, cap, H, H, s, h_in_tiled);
