@@ -1863,7 +1863,9 @@ constexpr int LDS_BYTES = RING + 8 * STRIP;
 template <int EPI, bool DBG>
 __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
                                                const bf16* __restrict__ resid, bf16* __restrict__ out, const int* __restrict__ cu,
-                                               int batch, int N, int K, unsigned long long* dbg, int dflags) {
+                                               int batch, int N, int K, unsigned long long* dbg, int dflags, long hm_stride) {
+    // hm_stride > 0: the output is written HEAD-MAJOR -- [feature / 32][hm_stride token rows][32] -- the layout k_attn3 reads its (sequence,
+    // head) blocks from as contiguous bytes (a store instruction's 16 rows x 64 B are then one contiguous KiB too)
     using namespace g3;
     using ffn::static_for; using ffn::ds_read16; using ffn::frag_wait; using ffn::sgpr_ptr;
     const int M = cu[batch];
@@ -2007,12 +2009,13 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
     int spend = 12;                                    // next piece to store (12 = nothing parked)
     int srows = 0;                                     // rows of the parked tile below this lane's first row that exist (m < M)
     const bf16* sbase = out;
+    const int64_t srow = hm_stride > 0 ? 32 : N, sft = hm_stride > 0 ? (int64_t)hm_stride * 32 : 32;   // element strides of a piece's rows / of the 32-feature tiles
     auto store_piece = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int ft = k >> 2, tt = (k >> 1) & 1, i = k & 1;
         if (tt * 32 + i * 16 < srows) {
             if (DBG && (dflags & 8)) asm volatile("" ::"v"(so[k]));
-            else *(bf16x8*)(sbase + (int64_t)(tt * 32 + i * 16) * N + ft * 32) = so[k];
+            else *(bf16x8*)(sbase + (int64_t)(tt * 32 + i * 16) * srow + ft * sft) = so[k];
         }
     };
     auto store_next = [&]() {                          // wave-uniform dispatch: the pieces live in fixed registers
@@ -2066,7 +2069,7 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
             const int row0 = m0c + wm * 64 + (lane >> 2);
             srows = M - row0;
             const int64_t lane_off = (int64_t)row0 * N + n0c + wn * 96 + (lane & 3) * 8;
-            sbase = out + lane_off;
+            sbase = hm_stride > 0 ? out + ((int64_t)((n0c + wn * 96) / 32) * hm_stride + row0) * 32 + (lane & 3) * 8 : out + lane_off;
             if (EPI == EPI_RESID) {                    // the residual arrives in store layout, all twelve loads in flight at once
 #pragma unroll
                 for (int k = 0; k < 12; ++k) {
@@ -2311,7 +2314,7 @@ __global__ __launch_bounds__(256) void k_attention(const bf16* __restrict__ qkv,
 // other's loads in series.
 // ------------------------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch, bf16* __restrict__ ctx, int ctx_tiled) {
+__global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch, bf16* __restrict__ ctx, int ctx_tiled, long hm_stride) {
     constexpr int LP = KT * 32;
     constexpr int VSTR = LP * 2 + 16;              // bytes per V^T row (dim): +16 spreads the 32 dims over the banks
     constexpr int KBYTES = LP * 64;
@@ -2334,7 +2337,9 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c31 = lane & 31, hh = lane >> 5;
     const int nkt = (L + 31) >> 5;                 // key tiles (= query tiles) in use
-    const int64_t rs = 3 * H;                      // qkv row stride (elements)
+    // qkv row-major [token][q | k | v of 12 heads x 32]: row stride 1152, a (token, head) piece is 64 B of a 2304-B row; or HEAD-MAJOR
+    // (hm_stride > 0, written so by k_gemm3): [3 x 12 (part, head)][hm_stride tokens][32] -- the sequence's Q / K / V of one head are contiguous
+    const int64_t rs = hm_stride > 0 ? DH : 3 * H;
     // accumulator init of the LAST key tile: 0 for real keys, -inf for the padding (register r <-> key 32 (nkt-1) + 8 (r>>2) + 4 hh + (r&3))
     f32x16 maskc;
 #pragma unroll
@@ -2342,7 +2347,8 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    const bf16* base = qkv + (int64_t)t0 * rs + head * DH;
+    const bf16* base = hm_stride > 0 ? qkv + ((int64_t)head * hm_stride + t0) * DH : qkv + (int64_t)t0 * rs + head * DH;
+    const int64_t koff = hm_stride > 0 ? (int64_t)NH * hm_stride * DH : H, voff = 2 * koff;      // from a Q piece to the same token's K / V piece
 
     // Q fragments of this wave's first tile (B operand: query c31, dims 16 s + 8 hh ..): in flight across the staging
     bf16x8 qf[2] = {bf16x8{}, bf16x8{}};
@@ -2360,8 +2366,8 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
             kv[u2] = uint4{0u, 0u, 0u, 0u};
             vv[u2] = uint4{0u, 0u, 0u, 0u};
             if (r < L) {
-                kv[u2] = *(const uint4*)(base + (int64_t)r * rs + H + u * 8);
-                vv[u2] = *(const uint4*)(base + (int64_t)r * rs + 2 * H + u * 8);
+                kv[u2] = *(const uint4*)(base + (int64_t)r * rs + koff + u * 8);
+                vv[u2] = *(const uint4*)(base + (int64_t)r * rs + voff + u * 8);
             }
         }
 #pragma unroll
@@ -2918,7 +2924,7 @@ static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps
 
 template <int EPI>
 static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu, int batch,
-                         int N, int K, hipStream_t s, bool a_tiled = false) {
+                         int N, int K, hipStream_t s, bool a_tiled = false, int64_t hm_stride = 0) {
     static const int n_wg = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus / 8 * 8; }();
 #ifdef RMU_DEBUG_KERNELS
     static const bool want_dbg = getenv("RMU_G3_DBG") != nullptr;
@@ -2928,7 +2934,7 @@ static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const 
         static unsigned long long* dbg = nullptr;
         if (!dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
         static const int dflags = getenv("RMU_G3_FLAGS") ? atoi(getenv("RMU_G3_FLAGS")) : 0;   // 1: no DMA in the loop, 2: no fragment reads, 4: no epilogue (timing only)
-        hipLaunchKernelGGL((k_gemm3<EPI, true>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, dbg, dflags);
+        hipLaunchKernelGGL((k_gemm3<EPI, true>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, dbg, dflags | (a_tiled ? 256 : 0), (long)hm_stride);
         unsigned long long h[6];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, dbg, 48, hipMemcpyDeviceToHost);
@@ -2941,16 +2947,16 @@ static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const 
 #endif
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_gemm3<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
     (void)attr_rc;
-    hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, a_tiled ? 256 : 0);
+    hipLaunchKernelGGL((k_gemm3<EPI, false>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, (unsigned long long*)nullptr, a_tiled ? 256 : 0, (long)hm_stride);
 }
 
 template <int KT>
-static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, bool ctx_tiled, hipStream_t s) {
+static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, bool ctx_tiled, int64_t hm_stride, hipStream_t s) {
     constexpr int lds = KT * 32 * 64 + 32 * (KT * 32 * 2 + 16);
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_attn3<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)attr_rc;
     const dim3 grid((unsigned)((batch + 7) / 8 * 8 * NH));
-    hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx, ctx_tiled ? 1 : 0);
+    hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx, ctx_tiled ? 1 : 0, (long)hm_stride);
 }
 
 #ifdef RMU_DEBUG_KERNELS
@@ -2994,8 +3000,6 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     for (const BertLayer& L : m->layers) {
         ++li;
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
-        if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled);
-        else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         // The round-1/2 kernels k_attention and k_ffn_fused are instantiated in debug builds only (RMU_ATTN_V=1, RMU_FFN_V=1: the A/B
         // numbers of DESIGN.md); the product library carries the kernels it takes by default plus k_ffn2 (RMU_FFN_V=2).
 #ifdef RMU_DEBUG_KERNELS
@@ -3003,13 +3007,19 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
 #else
         constexpr int attn_v = 3;
 #endif
+        // QKV head-major when k_gemm3 writes it and k_attn3 reads it (RMU_QKV_HM=0: row-major); the stride between (part, head) planes is the
+        // workspace's token capacity
+        static const bool hm_env = !(getenv("RMU_QKV_HM") && atoi(getenv("RMU_QKV_HM")) == 0);
+        const int64_t hm_stride = (hm_env && (g3_mask & 1) && cap > SMALL_M && attn_v == 3) ? m->ws_tokens : 0;
+        if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled, hm_stride);
+        else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
         static const bool tiled_env = !(getenv("RMU_CTX_TILED") && atoi(getenv("RMU_CTX_TILED")) == 0);
         const bool ctx_tiled = tiled_env && attn_v == 3 && !(g3_mask & 2) && cap > 32768;
         if (attn_v == 3) {
-            if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
-            else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
-            else launch_attn3<16>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, s);
+            if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
+            else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
+            else launch_attn3<16>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
         }
 #ifdef RMU_DEBUG_KERNELS
         else if (max_len <= 128) launch_attn<8>(at_grid, m->qkv, m->cu, m->ctx, s);

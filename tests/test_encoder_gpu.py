@@ -259,9 +259,9 @@ def test_cross_encoder_100_pairs_tolerance_1e2(cross):
 
 @pytest.mark.parametrize("env", [{"RMU_GEMM3": "0"}, {"RMU_GEMM3": "7"}, {"RMU_GEMM3": "2", "RMU_FUSED_FFN": "0"},
                                  {"RMU_FFN_LNIN": "0"}, {"RMU_FFN_V": "2"}, {"RMU_FFN_V": "2", "RMU_FFN_LNIN": "0"},
-                                 {"RMU_FFN_V": "2", "RMU_FFN_GELU": "1"}, {"RMU_CTX_TILED": "0"}, {"RMU_H_TILED": "0"}],
+                                 {"RMU_FFN_V": "2", "RMU_FFN_GELU": "1"}, {"RMU_CTX_TILED": "0"}, {"RMU_H_TILED": "0"}, {"RMU_QKV_HM": "0"}],
                          ids=["k_gemm_only", "k_gemm3_everywhere", "unfused_ffn", "ffn3_separate_layernorm", "ffn2_one_wave_per_simd",
-                              "ffn2_separate_layernorm", "ffn2_scalar_gelu", "row_major_ctx", "row_major_h_between_layers"])
+                              "ffn2_separate_layernorm", "ffn2_scalar_gelu", "row_major_ctx", "row_major_h_between_layers", "row_major_qkv"])
 def test_every_switchable_kernel_variant_keeps_parity(env):
     """Every kernel the PRODUCT library can be switched to is held to the same bar as the default path (the default itself --
     k_ffn3, k_attn3, k_gemm3 for QKV, tiled activations -- is what every other test of this file runs).  The round-1/2 kernels
