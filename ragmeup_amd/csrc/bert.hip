@@ -10,10 +10,15 @@
 // pooler-tanh + Linear(384,1) head.
 //
 // Layout: tokens are PACKED (no padding rows): sequence b owns rows [cu[b], cu[b+1]) of every [T, *] activation.
-// Activations are bf16 in HBM, every accumulation / LayerNorm / softmax is fp32.  GEMMs are
-// v_mfma_f32_16x16x32_bf16 on 128x128x64 tiles staged through LDS by LDS-DMA (global_load_lds_dwordx4) with the
-// XOR swizzle applied to the per-lane SOURCE address (the DMA writes lane-linear).  Operands are swapped
-// (D^T = W . A^T) so a lane ends up with 4 consecutive output features of one token: 8-byte bf16 stores.
+// Activations are bf16 in HBM, every accumulation / LayerNorm / softmax is fp32.  Per layer, above 16 384 tokens:
+//   k_gemm3   QKV projection: persistent 256 x 192 tiles, v_mfma_f32_32x32x16_bf16, 5-slot LDS-DMA ring, head-major stores
+//   k_attn3   attention per (sequence, head): two-pass softmax off the MFMA accumulator; writes ctx as 1-KiB operand blocks
+//   k_gemm    out-proj + residual (v_mfma_f32_16x16x32_bf16, both operands tiled)
+//   k_ffn3    LayerNorm 1 + FFN1 + GELU + FFN2 + residual + LayerNorm 2, two waves per SIMD; writes h tiled between layers
+// and k_gemm_small / the GEMM pair below that; k_embed_ln in front, k_pool / k_cls_head / k_tokens_out behind.  LDS staging is
+// LDS-DMA (global_load_lds_dwordx4) with the XOR swizzle applied to the per-lane SOURCE address (the DMA writes lane-linear) or
+// baked into a tiled copy of the operand.  In the GEMMs the operands are swapped (D^T = W . A^T) so that a lane ends up with
+// consecutive output features of one token.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
