@@ -43,6 +43,14 @@ constexpr int H = 384, NH = 12, DH = 32, FF = 1536;
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 
+// Swizzle of the SHARED 64-byte-row operand images (k_tile_w's weight copies, the tiled ctx / h activations, the ring slots of k_gemm
+// at 32-k stages and of k_gemm3): logical 16-byte unit u of row r sits at physical unit u ^ tswz(r), tswz = perm[(r >> 2) & 3] with
+// perm = {0, 2, 3, 1}.  The hardware services a ds_read_b128 in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (not 16
+// consecutive lanes): with the identity on those two row bits the 16x16x32 fragment mapping (row = lane & 15, k group = lane >> 4) put
+// rows 0-3 and rows 4-7 of such a group on the same four slots -- HALF of the out-proj GEMM's LDS cycles were bank conflicts
+// (profiles/r03_encoder_lds_pmc.md).  This permutation is conflict-free for that mapping and for the 32x32x16 one (row = lane & 31).
+__host__ __device__ __forceinline__ int tswz(int row) { return (0x78 >> ((row >> 1) & 6)) & 3; }
+
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, two orders below the bf16 resolution of the output):
 // one rcp + one exp + 6 fma instead of libm's ~40-instruction erff
 __device__ __forceinline__ float fast_erf(float x) {
@@ -149,7 +157,7 @@ __global__ void k_pack_ffn3(const bf16* __restrict__ w1, const bf16* __restrict_
 #endif
 
 // Weight copy for k_gemm3's LDS-DMA: block (nb, kb) = rows [16 nb, +16) x k [32 kb, +32) stored as the very 1 KiB its ring
-// slot holds (row r of the block at byte 64 r, logical 16-byte unit u at physical unit u ^ ((r >> 2) & 3)), blocks in [nb][kb]
+// slot holds (row r of the block at byte 64 r, logical 16-byte unit u at physical unit u ^ tswz(r)), blocks in [nb][kb]
 // order: one DMA wave instruction then reads 1 KiB of CONTIGUOUS bytes (8 cache lines) instead of 16 rows x 64 B (16 lines) --
 // the address path of a CU is paid per line touched.  One thread per 16-byte unit of the destination.
 __global__ void k_tile_w(const bf16* __restrict__ src, bf16* __restrict__ dst, int N, int K) {
@@ -157,7 +165,7 @@ __global__ void k_tile_w(const bf16* __restrict__ src, bf16* __restrict__ dst, i
     if (d >= (int64_t)N * K / 8) return;
     const int64_t blk = d >> 6;
     const int within = (int)(d & 63), r = within >> 2, pu = within & 3;
-    const int u = pu ^ ((r >> 2) & 3);
+    const int u = pu ^ tswz(r);
     const int kbn = K / 32;
     const int64_t nb = blk / kbn;
     const int kb = (int)(blk % kbn);
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
     const int wm = w >> 1, wn = w & 1;             // wave -> 64 tokens x 64 features
     char* As = gsm;                                // [ST][BM rows][UPR units]   (tokens x k)
     char* Ws = gsm + ST * SLABA;                   // [ST][128 rows][UPR units]  (features x k)
-    auto swz = [](int row) { return UPR == 8 ? (row & 7) : ((row >> 2) & 3); };
+    auto swz = [](int row) { return UPR == 8 ? (row & 7) : tswz(row); };
 
     // DMA source map: LDS unit f = (it*NWV + w)*64 + lane  ->  row f/UPR, physical unit f%UPR, logical unit p ^ swz(row)
     int arow[NITA], acol[NITA], wrow[NITW], wcol[NITW];
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
                 int64_t roff = off;
                 if (dbg & 256) {                   // the residual is a TILED activation (1-KiB blocks of 16 tokens x 32 features, see k_ffn3's store)
                     const int col = n0 + wn * 64 + u * 8, r = m & 15;
-                    roff = ((int64_t)(m >> 4) * (N / 32) + (col >> 5)) * 512 + r * 32 + ((((col >> 3) & 3) ^ ((r >> 2) & 3)) * 8);
+                    roff = ((int64_t)(m >> 4) * (N / 32) + (col >> 5)) * 512 + r * 32 + ((((col >> 3) & 3) ^ tswz(r)) * 8);
                 }
                 const bf16x8 rv = *(const bf16x8*)(resid + roff);
 #pragma unroll
@@ -1333,7 +1341,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         const int tok = min(m0 + 32 * p + r31, M - 1);
         bf16x8 cf[24];
         if (dflags & 512) {                      // tiled ctx (k_attn3's store): block (token / 16, head = k / 32), unit ^ ((r >> 2) & 3)
-            const int r = tok & 15, sw = (r >> 2) & 3;
+            const int r = tok & 15, sw = tswz(r);
             const bf16* blk = x + (int64_t)(tok >> 4) * (NH * 512) + r * 32;
 #pragma unroll
             for (int ks = 0; ks < 24; ++ks) cf[ks] = *(const bf16x8*)(blk + (ks >> 1) * 512 + ((((ks & 1) * 2 + hh) ^ sw) * 8));
@@ -1391,7 +1399,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         // y = bf16(bf16(acc + bo) + h) (the out-proj kernel's rounding points), kept as fp32 of those bf16 values
         float sm = 0.f;
         {
-            const int r = tok & 15, sw = (r >> 2) & 3;
+            const int r = tok & 15, sw = tswz(r);
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
@@ -1818,10 +1826,10 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
             for (int i = 0; i < 8; ++i) ov[i] = (bf16)((v[i] - mu) * rs * gg[i] + bb[i]);
             if (act) {
                 // dflags bit 8: the TILED activation form -- 1-KiB blocks of 16 tokens x 32 features, [token block][feature block] order, unit u
-                // (8 features) of row r at u ^ ((r >> 2) & 3): exactly what a ring slot of the next layer's QKV GEMM / the out-proj's
+                // (8 features) of row r at u ^ tswz(r): exactly what a ring slot of the next layer's QKV GEMM / the out-proj's
                 // residual piece holds, so their DMA instructions read whole contiguous KiB
                 int64_t off = (int64_t)m * H + c0;
-                if (dflags & 256) { const int r = m & 15; off = ((int64_t)(m >> 4) * (H / 32) + (c0 >> 5)) * 512 + r * 32 + ((((c0 >> 3) & 3) ^ ((r >> 2) & 3)) * 8); }
+                if (dflags & 256) { const int r = m & 15; off = ((int64_t)(m >> 4) * (H / 32) + (c0 >> 5)) * 512 + r * 32 + ((((c0 >> 3) & 3) ^ tswz(r)) * 8); }
                 *(bf16x8*)(out + off) = ov;
             }
         }
@@ -1899,8 +1907,8 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
     };
 
     // ---- issue cursor: the stage the next DMA instructions belong to (runs NSLOT - 1 stages ahead of the MFMAs, across tiles) --
-    // X piece xi = w + 8 i (i = 0, 1): rows 16 xi + (lane >> 2), physical unit lane & 3 holding logical unit (lane & 3) ^ ((row >> 2) & 3)
-    // (= lane >> 4); rows past the last token are clamped (never stored).  W piece wi = w (+ 8 for waves 0..3).
+    // X piece xi = w + 8 i (i = 0, 1): rows 16 xi + (lane >> 2), physical unit lane & 3 holding logical unit (lane & 3) ^ tswz(row)
+    // (row & 15 = lane >> 2); rows past the last token are clamped (never stored).  W piece wi = w (+ 8 for waves 0..3).
     int ij = 0, it = 0, islot = 0;
     const char *ia, *iw;
     u32 xoff[2];
@@ -1918,7 +1926,7 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
             const int row = (w + 8 * i) * 16 + (lane >> 2);
             const int rc = row < rows_here ? row : rows_here - 1;
             // tiled A (1-KiB blocks of 16 tokens x 32 k, already in slot order): piece xi of stage `it` = block (m0 / 16 + xi, it), read whole
-            xoff[i] = a_tiled ? (u32)((w + 8 * i) * (K / 32) * 1024 + lane * 16) : (u32)(((size_t)rc * K + (((lane & 3) ^ (lane >> 4)) * 8)) * 2);
+            xoff[i] = a_tiled ? (u32)((w + 8 * i) * (K / 32) * 1024 + lane * 16) : (u32)(((size_t)rc * K + (((lane & 3) ^ tswz(lane >> 2)) * 8)) * 2);
         }
     };
     auto issue_x = [&](int i) {
@@ -1963,8 +1971,8 @@ __global__ __launch_bounds__(512) void k_gemm3(const bf16* __restrict__ A, const
     u32 xrel[2], wrel[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-        xrel[s2] = (u32)(r31 * 64 + (((2 * s2 + hh) ^ ((r31 >> 2) & 3)) * 16)) + (u32)(wm * 64 * 64);
-        wrel[s2] = (u32)(fr * 64 + (((2 * s2 + hh) ^ ((fr >> 2) & 3)) * 16)) + (u32)(XBYTES + wn * 96 * 64);
+        xrel[s2] = (u32)(r31 * 64 + (((2 * s2 + hh) ^ tswz(r31)) * 16)) + (u32)(wm * 64 * 64);
+        wrel[s2] = (u32)(fr * 64 + (((2 * s2 + hh) ^ tswz(fr)) * 16)) + (u32)(XBYTES + wn * 96 * 64);
     }
     bf16x8 wf[3], xf[2][2];
 
@@ -2480,7 +2488,7 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
                 if (ctx_tiled) {
                     // ctx as the out-proj GEMM's 1-KiB blocks: (16-token block, head) -> [16 rows][4 units of 8 dims], unit u of row r at u ^ ((r >> 2) & 3)
                     const int64_t m = t0 + q;
-                    const int r = (int)(m & 15), sw = (r >> 2) & 3;
+                    const int r = (int)(m & 15), sw = tswz(r);
                     bf16* blk = ctx + ((m >> 4) * NH + head) * 512 + r * 32;
                     *(bf16x8*)(blk + ((2 * hh) ^ sw) * 8) = o0;
                     *(bf16x8*)(blk + ((2 * hh + 1) ^ sw) * 8) = o1;
