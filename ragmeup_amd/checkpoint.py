@@ -60,6 +60,7 @@ class CheckpointSpec:
     vocab_file: Optional[str] = None
     weights_file: Optional[str] = None
     notes: list = field(default_factory=list)
+    config: dict = field(default_factory=dict, repr=False)   # the raw config.json (head-specific readers look things up in it)
 
 
 def read_arch(cfg: dict) -> BertArch:
@@ -106,7 +107,7 @@ def _common(path: str) -> CheckpointSpec:
     spec.tok_lower_case = bool(tcfg.get("do_lower_case", True))
     tmax = tcfg.get("model_max_length")
     spec.max_seq_length = spec.arch.max_pos if not isinstance(tmax, int) or tmax > 10 ** 6 else min(int(tmax), spec.arch.max_pos)
-    spec._cfg = cfg           # raw config.json for the head-specific readers below
+    spec.config = cfg
     return spec
 
 
@@ -159,7 +160,7 @@ def read_cross_encoder(path: str) -> CheckpointSpec:
     spec = _common(path)
     if spec.arch.num_labels != 1:
         raise UnsupportedCheckpoint(f"num_labels={spec.arch.num_labels}: the reranker head is Linear(hidden, 1)")
-    fn = spec._cfg.get("sbert_ce_default_activation_function")
+    fn = spec.config.get("sbert_ce_default_activation_function")
     if fn is None:
         spec.activation = "sigmoid"       # CrossEncoder: Sigmoid when num_labels == 1 and the config names nothing
     else:
@@ -179,4 +180,5 @@ def load_state(spec: CheckpointSpec) -> dict:
         from safetensors.numpy import load_file
         return load_file(spec.weights_file)
     import torch
-    return torch.load(spec.weights_file, map_location="cpu")
+    # weights_only: a checkpoint directory is data, never code (torch < 2.6 unpickles arbitrary objects otherwise)
+    return torch.load(spec.weights_file, map_location="cpu", weights_only=True)

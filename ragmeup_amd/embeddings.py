@@ -23,6 +23,8 @@ pre-tokenised input and are what the kernel benchmarks use.
 """
 from __future__ import annotations
 
+import sys
+import threading
 from typing import Any, Optional, Sequence
 
 import numpy as np
@@ -30,6 +32,33 @@ import numpy as np
 from . import bert as B
 from ._lc import CROSS_ENCODER_BASES, Embeddings
 from .bert import BertEncoder
+
+
+class _SwitchInterval:
+    """Process-wide `sys.setswitchinterval` held short while at least one indexing pipeline runs: the first caller in saves the
+    host application's value, the last caller out restores it (two overlapping calls must not leave the interpreter at 0.2 ms)."""
+    _lock = threading.Lock()
+    _users = 0
+    _saved = None
+
+    def __init__(self, seconds: float):
+        self.seconds = seconds
+
+    def __enter__(self):
+        cls = _SwitchInterval
+        with cls._lock:
+            if cls._users == 0:
+                cls._saved = sys.getswitchinterval()
+                sys.setswitchinterval(min(cls._saved, self.seconds))
+            cls._users += 1
+
+    def __exit__(self, *exc):
+        cls = _SwitchInterval
+        with cls._lock:
+            cls._users -= 1
+            if cls._users == 0:
+                sys.setswitchinterval(cls._saved)
+        return False
 
 
 def _pad(seqs: Sequence[Sequence[int]], pad: int = 0, max_len: Optional[int] = None):
@@ -216,26 +245,20 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         # block; with CPython's default 5 ms switch interval the encoding thread waited up to that long behind the tokenising
         # thread's string handling, every block (~30 ms per 65536 texts measured).  A short interval for the duration of the call.
         import contextlib
-        import sys
-        old_switch = sys.getswitchinterval()
-        sys.setswitchinterval(min(old_switch, 2e-4))
         # the upload slots belong to ONE pipeline at a time: a second thread embedding a large batch on the same encoder waits here
         # (the GPU is the shared resource either way)
         guard = self.encoder.pipeline_lock if can_upload else contextlib.nullcontext()
-        try:
-            with guard, ThreadPoolExecutor(max_workers=1) as pool:
-                fut = pool.submit(prepare, 0)
-                for i, lo in enumerate(starts):
-                    ids, lens, on_device = fut.result()
-                    if i + 1 < len(starts):
-                        fut = pool.submit(prepare, i + 1)
-                    dst = out[lo:lo + ids.shape[0]]
-                    if on_device:
-                        self.encoder.encode_ids(ids, lens, None, mode=self._mode, out=dst)
-                    else:
-                        self.embed_id_arrays(ids, lens, out=dst)
-        finally:
-            sys.setswitchinterval(old_switch)
+        with _SwitchInterval(2e-4), guard, ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(prepare, 0)
+            for i, lo in enumerate(starts):
+                ids, lens, on_device = fut.result()
+                if i + 1 < len(starts):
+                    fut = pool.submit(prepare, i + 1)
+                dst = out[lo:lo + ids.shape[0]]
+                if on_device:
+                    self.encoder.encode_ids(ids, lens, None, mode=self._mode, out=dst)
+                else:
+                    self.embed_id_arrays(ids, lens, out=dst)
         return out
 
     def embed_documents_array(self, texts: list[str]) -> np.ndarray:

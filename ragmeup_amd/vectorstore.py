@@ -151,6 +151,7 @@ class MI355XVectorStore(VectorStore):
         # "atexit" (default): write once at interpreter exit if anything changed; False: only on persist()
         self.auto_persist = auto_persist
         self._dirty = False
+        self._superseded = False             # a newer store took this (uri, collection): this one never writes the files again
         self._index: FlatIndex | None = None
         self._lock = threading.RLock()       # writer lock (add/delete); searches take the C-side shared lock
         self._texts: list[str] = []
@@ -162,12 +163,14 @@ class MI355XVectorStore(VectorStore):
             self._remove_persisted()
         if auto_persist == "atexit" and self._persist_paths():
             ref = weakref.ref(self)
-            atexit.register(lambda: (lambda s: s is not None and s._dirty and s._persist_quietly())(ref()))
+            atexit.register(lambda: (lambda s: s is not None and s._dirty and not s._superseded and s._persist_quietly())(ref()))
 
     def __del__(self):
-        # a dirty "atexit" store that is collected BEFORE interpreter exit would otherwise never be written
+        # a dirty "atexit" store that is collected BEFORE interpreter exit would otherwise never be written -- unless a newer
+        # store replaced it (from_documents(drop_old=True) / a re-created collection): that one owns the files now
         try:
-            if self.auto_persist == "atexit" and self._dirty and self._index is not None and self._persist_paths():
+            if (self.auto_persist == "atexit" and self._dirty and not self._superseded and self._index is not None
+                    and self._persist_paths()):
                 self._persist_quietly()
         except Exception:   # noqa: BLE001 - partially constructed object / interpreter teardown
             pass
@@ -184,8 +187,11 @@ class MI355XVectorStore(VectorStore):
                        ids: list[str] | None = None, **kw) -> "MI355XVectorStore":
         key = f"{(connection_args or {}).get('uri')}::{collection_name}"
         with cls._collections_lock:
-            store = None if drop_old else cls._collections.get(key)
+            old = cls._collections.get(key)
+            store = None if drop_old else old
             if store is None:
+                if old is not None:
+                    old._superseded = True       # its finalizer / atexit hook must not rewrite the files the new store owns
                 store = cls(embeddings=embedding, collection_name=collection_name, connection_args=connection_args,
                             drop_old=drop_old, **kw)
                 cls._collections[key] = store
@@ -226,7 +232,7 @@ class MI355XVectorStore(VectorStore):
     def persist(self) -> bool:
         """Both files are written to temporaries and renamed into place (a crash leaves the previous pair)."""
         paths = self._persist_paths()
-        if paths is None or self._index is None:
+        if paths is None or self._index is None or self._superseded:
             return False
         with self._lock:
             self._index.save(paths[0] + ".tmp")
@@ -261,8 +267,7 @@ class MI355XVectorStore(VectorStore):
         with self._lock:
             with open(paths[1], "r", encoding="utf-8") as f:
                 m = json.load(f)
-            factory = type(self)._index_factory
-            index = factory.load(paths[0]) if factory is not None and hasattr(factory, "load") else FlatIndex.load(paths[0], device=self._device)
+            index = self._open_index(paths[0])
             n = len(m["texts"])
             if not (len(m["metas"]) == len(m["pks"]) == len(m["alive"]) == n == int(m.get("n", n)) == len(index)):
                 raise ValueError(f"{paths[1]} does not describe {paths[0]} ({n} records vs {len(index)} rows)")
@@ -280,20 +285,24 @@ class MI355XVectorStore(VectorStore):
         return True
 
     # ---- helpers ----------------------------------------------------------------------------------------
-    _index_factory = None   # tests may inject a fake; the product path always builds the HIP index
+    def _new_index(self, dim: int):
+        """The HBM-resident flat index (librmu.so); raises when the library is missing -- there is no CPU index."""
+        return FlatIndex(dim, _METRICS[self.metric], device=self._device)
+
+    def _open_index(self, path: str):
+        return FlatIndex.load(path, device=self._device)
 
     def _ensure_index(self, dim: int):
         if self._index is None:
             self._dim = dim
-            factory = type(self)._index_factory or (lambda d: FlatIndex(d, _METRICS[self.metric], device=self._device))
-            self._index = factory(dim)
+            self._index = self._new_index(dim)
         elif dim != self._dim:
             raise ValueError(f"embedding dimension changed: {self._dim} -> {dim}")
 
     def _embed_docs_for_index(self, texts: list[str]):
         """Embeddings for insertion: a torch CUDA tensor when the Embeddings object can produce one (ours: the rows go
         device-to-device into the corpus, no host round trip), else a numpy array."""
-        if hasattr(self._embeddings, "embed_documents_device") and type(self)._index_factory is None:
+        if hasattr(self._embeddings, "embed_documents_device"):
             return self._embeddings.embed_documents_device(texts)
         return self._embed_docs(texts)
 
@@ -457,9 +466,10 @@ class MI355XVectorStore(VectorStore):
                                                 lambda_mult: float = 0.5, **kw) -> list[Document]:
         q = np.asarray(embedding, dtype=np.float32)
         if (self._index is not None and hasattr(self._index, "search_mmr") and len(self._index) > 0
-                and 1 <= k <= min(int(fetch_k), 64)):
-            # dense top-fetch_k and the greedy selection in one library call (rmu_index_search_mmr): one host round trip
-            rows, _ = self._index.search_mmr(q[None], min(int(fetch_k), N.MAX_K, 64), k, lambda_mult)
+                and 1 <= k <= int(fetch_k) <= 64):
+            # dense top-fetch_k and the greedy selection in one library call (rmu_index_search_mmr, fetch_k <= 64): one host
+            # round trip.  A larger pool takes the search + selection below with the FULL fetch_k candidates.
+            rows, _ = self._index.search_mmr(q[None], int(fetch_k), k, lambda_mult)
             return [self._doc(int(x)) for x in rows[0] if x >= 0]
         s, r = self._search_vecs(q[None], fetch_k)
         rows = [int(x) for x in r[0] if x >= 0]

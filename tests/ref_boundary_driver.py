@@ -39,9 +39,7 @@ assert _lc.HAVE_LANGCHAIN and _lc.Document is lcstub.Document
 
 # ---- CPU stand-ins for the two GPU models (the boundary, not the arithmetic, is under test here) --------------------------
 sys.path.insert(0, HERE)
-from test_host_cpu import FakeIndex  # noqa: E402  (oracle-backed index with the FlatIndex call surface)
-
-MI355XVectorStore._index_factory = FakeIndex
+from test_host_cpu import FakeStore  # noqa: E402  (MI355XVectorStore over an oracle-backed index: a TEST subclass)
 
 from ragmeup_amd.embeddings import MI355XCrossEncoder, MI355XEmbeddings  # noqa: E402
 
@@ -92,7 +90,8 @@ os.environ.update({
 import RAGHelper as ref  # noqa: E402  (the reference's module)
 
 out["reference_file"] = ref.__file__
-ref.Milvus = MI355XVectorStore                       # vector store binding
+ref.Milvus = FakeStore                               # vector store binding (here: the test subclass
+                                                     # of MI355XVectorStore whose index is the CPU oracle -- no GPU on this box)
 ref.HuggingFaceCrossEncoder = OverlapCrossEncoder    # cross-encoder binding
 
 h = ref.RAGHelper(logging.getLogger("ref"))
@@ -108,7 +107,7 @@ chunker = h._create_semantic_chunker()                # SemanticChunker(self.emb
 out["semantic_chunker_ok"] = chunker.embeddings is h.embeddings
 
 h._initialize_vector_store()                          # Milvus.from_documents([], emb, drop_old=..., ...) + batch loop
-out["db_type"] = type(h.db).__name__
+out["db_type"] = [c.__name__ for c in type(h.db).__mro__ if c.__module__.startswith("ragmeup_amd.")][0]
 out["db_rows"] = len(h.db)
 out["db_is_VectorStore"] = isinstance(h.db, lcstub.VectorStore)
 
@@ -177,7 +176,8 @@ out["delete_count"] = h.db.delete(expr='source == "alpha.pdf"').delete_count
 
 # env factory (ragmeup_amd.factory): same variables, vector_store=mi355x
 from ragmeup_amd import factory  # noqa: E402
-env = dict(os.environ, vector_store="mi355x", vector_store_initial_load="True", rerank="False")
+env = dict(os.environ, vector_store="mi355x", vector_store_initial_load="True", rerank="False",
+           vector_store_collection="factory_probe")   # a fresh collection: the product class itself (index built lazily)
 hp = factory.from_env(env, embeddings=HashEmbeddings())
 out["factory_db"] = type(hp.db).__name__
 out["factory_retriever"] = [hp.retriever.search_type, hp.retriever.search_kwargs]

