@@ -317,15 +317,25 @@ def leg_index(args) -> dict:
     vdir = tempfile.mkdtemp()
     vp = os.path.join(vdir, "vocab.txt")
     open(vp, "w", encoding="utf-8").write("\n".join(toks) + "\n")
-    texts = synth_texts(words, n)
+    # n distinct texts: a generated base set of <= 131072, then copies of it with one more (distinct, in-vocabulary) word appended
+    # per copy -- 1M texts in a few seconds instead of a minute of Python string building
+    t0 = time.perf_counter()
+    base = synth_texts(words, min(n, 131072))
+    texts = list(base)
+    c = 0
+    while len(texts) < n:
+        c += 1
+        suf = " " + words[c]
+        texts.extend(t + suf for t in base[:n - len(texts)])
     ids = [hashlib.md5(t.encode()).hexdigest() for t in texts]                    # RAGHelper.py:365: id = md5 of the chunk
     docs = [Document(t, {"source": f"doc{i // 50}.pdf", "id": ids[i]}) for i, t in enumerate(texts)]
+    gen_s = time.perf_counter() - t0
     enc = BertEncoder(bert_weights(0, False), layers=6)
     tok = WordPieceTokenizer(vp)
     emb = MI355XEmbeddings(encoder=enc, tokenizer=tok, max_seq_length=256)
     # tokenizer alone (host threads = hardware concurrency)
     t0 = time.perf_counter()
-    tid, _, tlen = tok.encode([t.replace("\n", " ") for t in texts], None, 256)
+    tid, _, tlen = tok.encode(texts, None, 256)
     tok_s = time.perf_counter() - t0
     # encoder alone on those token arrays (device-resident ids, 8192-chunk batches: the C3 leg's measurement on this workload)
     L = int(tlen.max())
@@ -338,39 +348,45 @@ def leg_index(args) -> dict:
         enc.encode_ids(bi, bl, None, 0, out=out[:bi.shape[0]])
     torch.cuda.synchronize()
     enc_s = time.perf_counter() - t0
-    del blocks
+    del blocks, tid
 
-    def run(batch):
+    def run(batch, count=n):
         store = MI355XVectorStore(embeddings=emb, collection_name=f"bench{batch}", auto_persist=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(0, n, batch):
-            store.add_documents(docs[i:i + batch], ids=ids[i:i + batch])
+        for i in range(0, count, batch):
+            store.add_documents(docs[i:min(i + batch, count)], ids=ids[i:min(i + batch, count)])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        assert len(store) == len(set(ids))
+        assert len(store) == len(set(ids[:count]))
+        st = store._index.stats()
         store._index.close()
-        return dt
+        return dt, st
 
-    run(8192)                                                                      # warm-up (workspaces, first-touch)
-    # one pass is one sample of a host-side pipeline (Python threads, GC, page faults): +-5 % run to run on one box -> median of three
-    one_s = sorted(run(n) for _ in range(3))[1]
-    ref_s = sorted(run(1000) for _ in range(3))[1]
+    run(8192, min(n, 65536))                                                       # warm-up (workspaces, first-touch)
+    # a pass is a host-side pipeline (Python threads, GC, page faults: +-5 % run to run on one box).  Up to 262144 texts: median
+    # of three passes; at BASELINE's 1M: ONE timed pass per call pattern (3.5 s each), so the whole leg stays under a minute
+    reps = 3 if n <= 262144 else 1
+    one_s, one_st = sorted((run(n) for _ in range(reps)), key=lambda p: p[0])[reps // 2]
+    ref_s, ref_st = sorted((run(1000) for _ in range(reps)), key=lambda p: p[0])[reps // 2]
     fl = encoder_flops(tlen)
     leg = {"name": "C3 end to end: texts -> add_documents -> tokenizer -> encoder -> HBM-resident corpus (BASELINE.json configs[2] as the reference runs it)",
            "value": round(n / one_s, 1), "unit": "chunks/sec", "ms_per_step": round(one_s * 1e3, 1),
            "config": {"workload": f"{n} synthetic texts of 60-110 words (~{float(tlen.mean()):.0f} tokens), 30522-entry synthetic WordPiece vocabulary, md5 ids, "
-                                  "random-init weights; ONE add_documents call (tokenizer + upload of block i+1 overlap the encoder of block i); median of 3 passes",
-                      "tokens": int(tlen.sum())},
+                                  "random-init weights; ONE add_documents call (tokenizer + upload of block i+1 overlap the encoder of block i); "
+                                  + ("median of 3 passes" if reps == 3 else "one timed pass"),
+                      "texts": n, "tokens": int(tlen.sum()), "text_generation_s": round(gen_s, 2)},
+           "corpus_growth": {"one_call": one_st, "reference_pattern": ref_st,
+                             "note": "rmu_index_stat: re-allocations (x1.5 + D2D copy of corpus matrix and fp16 image) inside the timed passes and their wall "
+                                     "time in ms -- no capacity is known up front, as with the reference's Milvus collection"},
            "reference_pattern_1000_doc_calls": {"chunks_per_sec": round(n / ref_s, 1), "seconds": round(ref_s, 3),
                                                 "note": "server/RAGHelper.py:423-434: each call tokenises, encodes and inserts its 1000 chunks before it returns"},
            "encoder_only": {"chunks_per_sec": round(n / enc_s, 1), "seconds": round(enc_s, 3), "note": "encode_ids on pre-tokenised, device-resident 8192-chunk batches of the same texts"},
            "tokenizer_only": {"texts_per_sec": round(n / tok_s, 1), "seconds": round(tok_s, 3), "threads": os.cpu_count(), "note": "rmu_tok_encode (host C++), all hardware threads"},
-           "end_to_end_over_encoder_only": round(enc_s / one_s, 3), "gpu_busy_fraction": round(enc_s / one_s, 3),
+           "end_to_end_over_encoder_only": round(enc_s / one_s, 3),
            "roofline": encoder_roofline(fl / one_s / 1e12)}
     if not args.no_cpu_baseline:
-        from transformers import BertConfig, BertModel, BertTokenizerFast
-        hf = BertTokenizerFast(vocab_file=vp, do_lower_case=True) if False else None
+        from transformers import BertConfig, BertModel
         try:
             from transformers import BertTokenizer
             hf = BertTokenizer(vocab={t: i for i, t in enumerate(toks)}, do_lower_case=True)
@@ -388,7 +404,8 @@ def leg_index(args) -> dict:
                     e = hf([t.replace("\n", " ") for t in texts[b0:b0 + 32]], padding=True, truncation=True, max_length=256, return_tensors="pt")
                     ii, mk = e["input_ids"], e["attention_mask"]
                 else:
-                    ii = torch.from_numpy(tid[b0:b0 + 32, :int(tlen[b0:b0 + 32].max())].astype(np.int64))
+                    tid32 = tok.encode(texts[b0:b0 + 32], None, 256)[0]
+                    ii = torch.from_numpy(tid32[:, :int(tlen[b0:b0 + 32].max())].astype(np.int64))
                     mk = (torch.arange(ii.shape[1])[None, :] < torch.from_numpy(tlen[b0:b0 + 32].astype(np.int64))[:, None]).long()
                 h = model(input_ids=ii, attention_mask=mk).last_hidden_state
                 mm = mk.unsqueeze(-1).float()
@@ -401,15 +418,16 @@ def leg_index(args) -> dict:
     return leg
 
 
-def leg_mmr(args) -> dict:
-    """The reference's real /chat retrieval: ONE query per call through `db.as_retriever(search_type="mmr", search_kwargs={"k": K})`
-    (server/RAGHelper.py:497-499): embed_query -> dense top-fetch_k (20) -> fetch those vectors -> greedy MMR (host, langchain's
-    expression) -> k documents.  10k-chunk corpus (BASELINE.json configs[0]), text queries through the native tokenizer."""
+def _chat_rig(with_reranker: bool):
+    """What the reference's /chat request touches on the hot path, built from the product classes: a 10k-chunk store
+    (BASELINE.json configs[0]) fed through add_documents, its `mmr` retriever, and (with_reranker) the cross-encoder inside
+    ScoredCrossEncoderReranker(top_n = rerank_k = 3, .env.template)."""
     import hashlib
     import tempfile
     from ragmeup_amd.bert import BertEncoder
     from ragmeup_amd.documents import Document
-    from ragmeup_amd.embeddings import MI355XEmbeddings
+    from ragmeup_amd.embeddings import MI355XCrossEncoder, MI355XEmbeddings
+    from ragmeup_amd.reranker import ScoredCrossEncoderReranker
     from ragmeup_amd.tokenizer import WordPieceTokenizer
     from ragmeup_amd.vectorstore import MI355XVectorStore
     toks, words = synth_vocab_and_words()
@@ -417,13 +435,85 @@ def leg_mmr(args) -> dict:
     open(vp, "w", encoding="utf-8").write("\n".join(toks) + "\n")
     enc = BertEncoder(bert_weights(0, False), layers=6)
     emb = MI355XEmbeddings(encoder=enc, tokenizer=WordPieceTokenizer(vp), max_seq_length=256)
-    n, nq = 10_000, 64
+    n = 10_000
     texts = synth_texts(words, n, seed=3)
-    store = MI355XVectorStore(embeddings=emb, collection_name="bench_mmr", auto_persist=False)
+    store = MI355XVectorStore(embeddings=emb, collection_name="bench_chat", auto_persist=False)
     store.add_documents([Document(t, {"source": f"d{i // 50}.pdf", "id": hashlib.md5(t.encode()).hexdigest()}) for i, t in enumerate(texts)],
                         ids=[hashlib.md5(t.encode()).hexdigest() for t in texts])
-    retriever = store.as_retriever(search_type="mmr", search_kwargs={"k": 10})
-    queries = synth_texts(words, nq, seed=4, wmin=8, wmax=16)
+    rig = {"toks": toks, "words": words, "enc": enc, "emb": emb, "store": store, "texts": texts, "n": n,
+           "retriever": store.as_retriever(search_type="mmr", search_kwargs={"k": 10}), "ce": None, "reranker": None}
+    if with_reranker:
+        ce = BertEncoder(bert_weights(1, True), layers=6)
+        rig["ce"] = ce
+        rig["reranker"] = ScoredCrossEncoderReranker(model=MI355XCrossEncoder(encoder=ce, tokenizer=WordPieceTokenizer(vp), max_seq_length=512), top_n=3)
+    return rig
+
+
+def _close_rig(rig):
+    rig["store"]._index.close()
+    rig["enc"].close()
+    if rig["ce"] is not None:
+        rig["ce"].close()
+
+
+def cpu_chat_baseline(rig, queries, answers, n_req: int, rerank: bool) -> dict:
+    """The reference's per-request pattern on the host cores (what RAGHelper_local runs with force_cpu): transformers
+    BertTokenizer + BertModel fp32 + sentence-transformers pooling per query, a torch-CPU FLAT scan (top-20), langchain's MMR
+    expression in numpy (ragmeup_amd.vectorstore.maximal_marginal_relevance restates it), and -- rerank -- transformers
+    BertForSequenceClassification over the 14 (query, passage) pairs, twice per request.  Same synthetic weights and vocabulary."""
+    from transformers import BertConfig, BertForSequenceClassification, BertModel, BertTokenizer
+    from ragmeup_amd.vectorstore import maximal_marginal_relevance
+    hf = BertTokenizer(vocab={t: i for i, t in enumerate(rig["toks"])}, do_lower_case=True)
+    cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12, intermediate_size=1536,
+                     max_position_embeddings=512, layer_norm_eps=1e-12, num_labels=1)
+    torch.manual_seed(0)
+    model = BertModel(cfg, add_pooling_layer=False).eval()
+    cemodel = BertForSequenceClassification(cfg).eval() if rerank else None
+    store = rig["store"]
+    xc = torch.from_numpy(store._index.get_rows(list(range(rig["n"]))))
+    texts = rig["texts"]
+
+    def retrieve(qy):
+        e = hf([qy], padding=True, truncation=True, max_length=256, return_tensors="pt")
+        h = model(**e).last_hidden_state
+        mk = e["attention_mask"].unsqueeze(-1).float()
+        v = torch.nn.functional.normalize((h * mk).sum(1) / mk.sum(1).clamp(min=1e-9), dim=1)
+        top = torch.topk(v @ xc.T, 20, dim=1).indices[0]
+        cand = xc[top].numpy()
+        return [int(top[i]) for i in maximal_marginal_relevance(v[0].numpy(), cand, k=10, lambda_mult=0.5)]
+
+    def rerank_pass(qy, rows):
+        e = hf([qy] * len(rows), [texts[r] for r in rows], padding=True, truncation="longest_first", max_length=512, return_tensors="pt")
+        lg = cemodel(**e).logits[:, 0]
+        return sorted(zip(rows, lg.tolist()), key=lambda p: p[1], reverse=True)[:3]
+
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(n_req):
+            if rerank:
+                for _ in range(3):
+                    rows = retrieve(queries[i])
+                cand = rows + [(r + 1) % rig["n"] for r in rows[:4]]                      # + the 4 BM25 documents of the ensemble
+                rerank_pass(queries[i], cand)
+                rerank_pass(answers[i], cand)
+            else:
+                retrieve(queries[i])
+    dt = time.perf_counter() - t0
+    what = ("3 x (BertTokenizer + BertModel fp32 query embedding + torch-CPU scan of the 10k rows, top-20 + numpy MMR) + 2 x "
+            "BertForSequenceClassification over 14 pairs" if rerank else
+            "BertTokenizer + BertModel fp32 query embedding + torch-CPU scan of the 10k rows, top-20 + numpy MMR (langchain's expression)")
+    return {"value": round(n_req / dt, 2), "unit": "requests/sec" if rerank else "queries/sec", "cores": torch.get_num_threads(), "kind": "reference",
+            "sample": f"{n_req} {'requests' if rerank else 'single-query calls'}: {what} ({dt:.2f} s)"}
+
+
+def leg_mmr(args) -> dict:
+    """The reference's real /chat retrieval: ONE query per call through `db.as_retriever(search_type="mmr", search_kwargs={"k": K})`
+    (server/RAGHelper.py:497-499): embed_query -> dense top-fetch_k (20) -> greedy MMR over those 20 -> k documents.
+    10k-chunk corpus (BASELINE.json configs[0]), text queries through the native tokenizer."""
+    rig = _chat_rig(with_reranker=False)
+    n, nq = rig["n"], 64
+    retriever = rig["retriever"]
+    queries = synth_texts(rig["words"], nq, seed=4, wmin=8, wmax=16)
 
     def step():
         for qy in queries:
@@ -437,11 +527,75 @@ def leg_mmr(args) -> dict:
     leg = {"name": "C1 the reference's /chat retrieval: one query per call, retriever.invoke with search_type='mmr' (embed_query + dense top-20 + MMR -> 10)",
            "value": round(nq / (ms * 1e-3), 1), "unit": "queries/sec", "ms_per_step": round(per_q, 4),
            "config": {"workload": "10k x 384 corpus built from texts, 64 single-query calls per timed pass, 8-16-word text queries, k = 10, fetch_k = 20, lambda 0.5"},
-           "roofline": {"kernel": "tokenizer + encoder forward at batch 1 + scan over 10k rows + 20-row gather + host MMR (launch-latency-bound)", "bound": "hbm",
+           "roofline": {"kernel": "tokenizer + encoder forward at batch 1 + scan over 10k rows + MMR selection on the device (launch-latency-bound)", "bound": "hbm",
                         "achieved": round(bytes_q / (per_q * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(bytes_q / (per_q * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
                         "basis": "21.3 MB of encoder weights + 15.4 MB of corpus per query; not a bandwidth-bound regime"}}
-    store._index.close(); enc.close()
+    if not args.no_cpu_baseline:
+        leg["cpu_baseline"] = cpu_chat_baseline(rig, queries, None, 32, rerank=False)
+    _close_rig(rig)
+    return leg
+
+
+def leg_chat(args) -> dict:
+    """ONE /chat request of the reference as one measured unit (server/RAGHelper_local.py:190-217 with the
+    template's rerank=True, use_rewrite_loop=True, provenance_method=rerank): the ensemble's dense retriever is invoked three
+    times (twice by the LCEL dict, once by the rewrite loop's rerank_retriever) = 3 x (embed_query + dense top-20 + MMR -> 10),
+    then ScoredCrossEncoderReranker.compress_documents twice over the <= 14 ensemble documents (10 dense + 4 BM25; BM25 itself
+    is out of scope, so 4 more stored chunks stand in for its hits): once against the query (server/RAGHelper.py:487-490),
+    once against the answer (server/provenance.py:100-108).  Everything between them (the LLM) is out of scope."""
+    rig = _chat_rig(with_reranker=True)
+    n, nreq = rig["n"], 32
+    retriever, reranker, store = rig["retriever"], rig["reranker"], rig["store"]
+    queries = synth_texts(rig["words"], nreq, seed=5, wmin=8, wmax=16)
+    answers = synth_texts(rig["words"], nreq, seed=6, wmin=40, wmax=80)
+    t_ret, t_rr = [0.0], [0.0]
+
+    def request(i):
+        t0 = time.perf_counter()
+        for _ in range(3):
+            docs = retriever.invoke(queries[i])
+        rows = [store._pk_to_row[d.metadata["pk"]] for d in docs]
+        cand = docs + [store._doc((r + 1) % n) for r in rows[:4]]
+        t1 = time.perf_counter()
+        top = reranker.compress_documents(cand, queries[i])
+        reranker.compress_documents(cand, answers[i])
+        t2 = time.perf_counter()
+        t_ret[0] += t1 - t0
+        t_rr[0] += t2 - t1
+        return top
+
+    def step():
+        for i in range(nreq):
+            top = request(i)
+        return top
+
+    assert len(step()) == 3
+    t_ret[0] = t_rr[0] = 0.0
+    steps = 3
+    ms = timed(step, steps=steps, warmup=0)
+    per_req = ms / nreq
+    # algorithmic work of one request (real tokens): 3 query forwards + 2 x 14 pair forwards
+    qlens = rig["emb"]._tokenize(queries)[1]
+    ce_m = reranker.model
+    row0 = [store._pk_to_row[d.metadata["pk"]] for d in retriever.invoke(queries[0])]
+    cand0 = [rig["texts"][r] for r in row0] + [rig["texts"][(r + 1) % n] for r in row0[:4]]
+    pl_q = ce_m._tokenize_arrays([queries[0]] * len(cand0), cand0, want_types=True)[2]
+    pl_a = ce_m._tokenize_arrays([answers[0]] * len(cand0), cand0, want_types=True)[2]
+    fl_req = 3 * encoder_flops(qlens) / nreq + encoder_flops(pl_q) + encoder_flops(pl_a)
+    tf = fl_req / (per_req * 1e-3) / 1e12
+    leg = {"name": "chat-pattern: ONE /chat request of the reference = 3 x (embed_query + dense top-20 + MMR -> 10) + 2 x cross-encoder rerank of 14 pairs -> top 3",
+           "value": round(nreq / (ms * 1e-3), 1), "unit": "requests/sec", "ms_per_step": round(per_req, 4),
+           "config": {"workload": "10k x 384 corpus built from texts, 32 requests per timed pass, 8-16-word queries, 40-80-word answers, passages ~87 tokens, "
+                                  "k = 10, fetch_k = 20, rerank_k = 3; one request at a time, synchronous, as server.py serves them"},
+           "retrieval_ms_per_call": round(t_ret[0] * 1e3 / (steps * nreq * 3), 4), "rerank_14_pairs_ms_per_call": round(t_rr[0] * 1e3 / (steps * nreq * 2), 4),
+           "roofline": {"kernel": "3 x (graph-replayed batch-1 forward + scan + MMR) + 2 x 14-pair cross-encoder forward (~1.5k tokens): launch-latency-bound",
+                        "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4),
+                        "traffic": None, "flops_per_request": fl_req,
+                        "basis": "a latency measurement: 3 batch-1 forwards + 2 forwards of 14 pairs (request 0's pair lengths) per request; no roof is approached"}}
+    if not args.no_cpu_baseline:
+        leg["cpu_baseline"] = cpu_chat_baseline(rig, queries, answers, 6, rerank=True)
+    _close_rig(rig)
     return leg
 
 
@@ -552,7 +706,26 @@ def cpu_search_baselines(q_host: np.ndarray, sample: np.ndarray, n_full: int, k:
     return {"batch": batch, "single": single, "rows": best_r.numpy()}
 
 
-def main():
+def _self_launch(n: int, argv: list, script: str | None = None) -> int:
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run: re-exec as N ranks of one node (one process per GPU)
+    and hand their output through -- rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RMU_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None, hooks=None):
+    """hooks: TEST-SIDE injection only (tests/bench_world2_driver.py runs this function's N > 1 control flow on CPU with gloo
+    and an oracle-backed index class): {"device": "cpu", "backend": "gloo", "index_cls": ..., "merge": ...}.  bench.py itself
+    never passes any: without hooks there is no CPU path (exit 2 when no GPU is visible)."""
+    hooks = hooks or {}
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -561,38 +734,53 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c1,mmr,c2,embed,index,rerank")
-    ap.add_argument("--index-texts", type=int, default=131072, help="texts pushed through add_documents by the `index` leg (BASELINE config 3 names 1M)")
+    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c1,mmr,chat,c2,embed,index,rerank")
+    ap.add_argument("--index-texts", type=int, default=1_000_000, help="texts pushed through add_documents by the `index` leg (BASELINE.json configs[2]: 1M chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-identity-check", action="store_true",
                     help="skip the post-run comparison with the exact fp32 scan (keeps rocprofv3 per-kernel statistics to the timed launches)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the hipEvent pass (no roofline block)")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],
                     help="N > 1: rmu_shard_allgather_topk (RCCL from librmu.so) or torch.distributed all_gather + rmu_topk_merge")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N` (the form of the driver's N = 1 command): launch the ranks ourselves
+        sys.exit(_self_launch(args.gpus, argv, hooks.get("script")))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    if not torch.cuda.is_available():
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree", file=sys.stderr)
+        sys.exit(2)
+    on_gpu = hooks.get("device", "cuda") == "cuda"
+    if on_gpu and not torch.cuda.is_available():
         print("bench.py: no GPU visible (the MI355X path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(hooks.get("backend", "gloo"), rank=rank, world_size=world)
 
-    from ragmeup_amd import FlatIndex, _native
+    from ragmeup_amd import _native
     from ragmeup_amd.shard import NativeComm, ShardedSearcher, shard_bounds
+    if "index_cls" in hooks:
+        FlatIndex = hooks["index_cls"]
+    else:
+        from ragmeup_amd import FlatIndex
 
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     lo, hi = shard_bounds(N, world, rank)
@@ -616,25 +804,35 @@ def main():
     if world > 1:
         dist.broadcast(q, 0)
         dist.broadcast(planted, 0)
-    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c1,mmr,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
+    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c1,mmr,chat,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
     sample_host = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample_host = shard[:min(n_local, 2_000_000)].cpu().numpy()
     x1m = shard[:1_000_000].clone() if (legs & {"c2", "rerank"}) and n_local >= 1_000_000 else None
     del shard
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
 
     exchange = "none"
     comm = None
+    n_ranks_seen = 1
     if world > 1:
         exchange = "torch.distributed all_gather_into_tensor + rmu_topk_merge"
-        if args.exchange == "native":
+        if args.exchange == "native" and on_gpu:
             try:
                 comm = NativeComm.from_torch_dist(device=local_rank)
-                exchange = "rmu_shard_allgather_topk (one ncclAllGather issued from librmu.so + device merge)"
+                exchange = ("rmu_shard_allgather_topk (local scan -> pack -> ONE ncclAllGather issued from librmu.so -> device merge, "
+                            "all ordered on one side stream: no host synchronisation inside a step)")
             except Exception as e:  # noqa: BLE001 - the torch.distributed exchange is the same algorithm
                 exchange += f" [native exchange unavailable: {e}]"
-    searcher = ShardedSearcher(index, row_base=lo, comm=comm)
+        if comm is not None and comm.world != world:
+            raise RuntimeError(f"rmu_comm_world reports {comm.world} ranks, the launcher {world}")
+        ones = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(ones)                          # every rank that reached this point is counted once
+        n_ranks_seen = int(ones.item())
+        if n_ranks_seen != world:
+            raise RuntimeError(f"{n_ranks_seen} ranks answered, {world} were launched")
+    searcher = ShardedSearcher(index, row_base=lo, comm=comm, merge=hooks.get("merge"))
 
     def step():
         return searcher.search(q, K)
@@ -642,18 +840,19 @@ def main():
     # ---- headline: exactly K steps, barrier + synchronize on both sides, MAX over ranks ---------------
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_s, out_r = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
+    out_s, out_r = torch.as_tensor(out_s), torch.as_tensor(out_r)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -744,11 +943,14 @@ def main():
                 leg["cpu_baseline"] = dict(cpu, value=round(cpu["value"] * N / n2, 3),
                                            sample=cpu["sample"].replace(f"scaled linearly to {N} rows", f"scaled linearly to {n2} rows"))
     index.close()
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     if "c1" in legs:
         secondary.append(leg_c1(args))
     if "mmr" in legs:
         secondary.append(leg_mmr(args))
+    if "chat" in legs:
+        secondary.append(leg_chat(args))
     if "embed" in legs:
         secondary.append(leg_embed(args))
     if "index" in legs:
@@ -765,7 +967,8 @@ def main():
         "scaling": "strong", "vs_baseline": None,
         "dtype": "f16 screen (fp32 accumulate) + f32 re-score" if path.startswith("screen") else "f32", "data": "synthetic",
         "config": {"workload": f"{N}x{D} fp32 unit-norm corpus, batch {B} queries, top-{K}, inner product",
-                   "rows": N, "dim": D, "batch": B, "k": K,
+                   "rows": N, "dim": D, "batch": B, "k": K, "n_ranks_seen": n_ranks_seen,
+                   "rows_per_rank": n_local, "self_launched": bool(os.environ.get("RMU_BENCH_SELF_LAUNCHED")),
                    "parallelism": f"row-shard x{world}" + (" + 1 RCCL all-gather of per-shard top-k" if world > 1 else ""),
                    "exchange": exchange},
         "recall_at_10": recall, "planted_top1": top1_ok, "sorted": sorted_ok,

@@ -73,6 +73,15 @@ int rmu_index_size(rmu_index_t* idx, int64_t* n_rows);
 int rmu_index_dim(rmu_index_t* idx, int* dim);
 int rmu_index_metric(rmu_index_t* idx, int* metric);
 int rmu_index_set_option(rmu_index_t* idx, int option, int64_t value);
+/* Bookkeeping a host may want to report (bench.py's indexing leg does): allocated row capacity, how often rmu_index_add had to
+ * re-allocate and copy the corpus matrix (+ screening image) and the wall time that took, live (non-tombstoned) rows.
+ * Serves: the growth of the Milvus collection under RAGHelper.py:423-434's 1000-document inserts (no capacity is known
+ * up front there either). */
+#define RMU_STAT_CAPACITY 1
+#define RMU_STAT_GROW_COUNT 2
+#define RMU_STAT_GROW_MS 3
+#define RMU_STAT_LIVE_ROWS 4
+int rmu_index_stat(rmu_index_t* idx, int what, double* out);
 
 /* Append n rows ([n, dim] fp32 row-major, host or device).  *first_row = row id of vecs[0].
  * Serves: RAGHelper.py:431, :525 (db.add_documents -> add_texts -> insert). */

@@ -13,6 +13,7 @@
 // Tombstoned rows are NaN-poisoned in place: every score against them is NaN and fails the scan's
 // `score > threshold` compare, so deletion costs nothing in the hot loop.
 #include <mutex>
+#include <chrono>
 #include <shared_mutex>
 #include <string>
 #include <vector>
@@ -378,6 +379,10 @@ struct rmu_index {
     char* split = nullptr;          // fp16(64 x) image of x (screening pass), 768 B per row; nullptr = disabled
     float xnorm_max = 0.f;          // max row norm (bounds the screening error)
     float dx_max = 0.f;             // max row norm of (x - screening image): the measured rounding error
+    unsigned stat_host[2] = {0, 0}; // landing pair of update_image_stats (|x|^2 max, |dx|^2 max of the rows just added)
+    bool stat_pending = false;
+    int64_t grow_count = 0;         // re-allocations of the corpus matrix (+ image) by rmu_index_add, and their wall time
+    double grow_ms = 0.0;
     bool screen_enabled = true;     // RMU_OPT_SCREEN: searches may take the screening path (when `split` exists)
     int64_t screen_min_nq = 0;      // RMU_OPT_SCREEN_MIN_NQ: > 0 = screen every batch of at least this many queries, whatever the corpus size
     std::vector<uint8_t> alive;
@@ -451,6 +456,18 @@ extern "C" int rmu_index_size(rmu_index_t* idx, int64_t* n_rows) {
     *n_rows = idx->n;
     return RMU_OK;
 }
+extern "C" int rmu_index_stat(rmu_index_t* idx, int what, double* out) {
+    if (!idx || !out) return fail(RMU_E_INVALID, "rmu_index_stat: null");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    switch (what) {
+        case RMU_STAT_CAPACITY: *out = (double)idx->cap; break;
+        case RMU_STAT_GROW_COUNT: *out = (double)idx->grow_count; break;
+        case RMU_STAT_GROW_MS: *out = idx->grow_ms; break;
+        case RMU_STAT_LIVE_ROWS: *out = (double)idx->n_live; break;
+        default: return fail(RMU_E_INVALID, "rmu_index_stat: unknown statistic");
+    }
+    return RMU_OK;
+}
 extern "C" int rmu_index_dim(rmu_index_t* idx, int* dim) {
     if (!idx || !dim) return fail(RMU_E_INVALID, "rmu_index_dim: null");
     *dim = idx->dim;
@@ -459,6 +476,11 @@ extern "C" int rmu_index_dim(rmu_index_t* idx, int* dim) {
 
 static int grow(rmu_index* idx, int64_t need) {
     if (need <= idx->cap) return RMU_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Tick {
+        rmu_index* i; std::chrono::steady_clock::time_point t;
+        ~Tick() { i->grow_count++; i->grow_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
+    } tick{idx, t0};
     int64_t cap = idx->cap;
     while (cap < need) cap = cap + cap / 2 + 1024;
     float* nx = nullptr;
@@ -494,35 +516,43 @@ static int grow(rmu_index* idx, int64_t need) {
     return RMU_OK;
 }
 
-// after `n` rows at `dst` were converted into the screening image: refresh |x|max and the measured image error |dx|max
+// after `n` rows at `dst` were converted into the screening image: |x|max and the measured image error |dx|max of those rows.
+// ENQUEUES only (two reductions into one 8-byte device pair + one 8-byte copy to idx->stat_host): the caller's own final
+// stream synchronisation covers it, then fold_image_stats() folds the pair into the index -- one host round trip per
+// rmu_index_add instead of three (the reference inserts in 1000-document calls, server/RAGHelper.py:423-434).
 static int update_image_stats(rmu_index_t* idx, const float* dst, int64_t n, hipStream_t s) {
     Buf& nb = g_tls.nrm;
     if (nb.ensure((size_t)n * sizeof(float) + 16)) return fail(RMU_E_OOM, "rmu_index_add: norm workspace");
     unsigned* mx = (unsigned*)((char*)nb.p + (size_t)n * sizeof(float));
-    unsigned hmx = 0;
+    HIP_TRY(hipMemsetAsync(mx, 0, 2 * sizeof(unsigned), s));
+    if (idx->metric != RMU_METRIC_COSINE) {
+        hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, const_cast<float*>(dst), idx->dpad, n, 0, (float*)nb.p);
+        hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
+    }
+    int rc = rmu_img_err_launch(dst, n, (float*)nb.p, s);
+    if (rc) return fail(rc, "rmu_index_add: image error");
+    hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx + 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(idx->stat_host, mx, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    idx->stat_pending = true;
+    return RMU_OK;
+}
+
+// after the stream that ran update_image_stats was synchronised
+static void fold_image_stats(rmu_index_t* idx) {
+    if (!idx->stat_pending) return;
+    idx->stat_pending = false;
     float f;
     if (idx->metric == RMU_METRIC_COSINE) {
         idx->xnorm_max = 1.0f;
     } else {
-        HIP_TRY(hipMemsetAsync(mx, 0, sizeof(unsigned), s));
-        hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, const_cast<float*>(dst), idx->dpad, n, 0, (float*)nb.p);
-        hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
-        HIP_TRY(hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        memcpy(&f, &hmx, 4);
+        memcpy(&f, &idx->stat_host[0], 4);
         f = sqrtf(f);
         if (f > idx->xnorm_max) idx->xnorm_max = f;
     }
-    HIP_TRY(hipMemsetAsync(mx, 0, sizeof(unsigned), s));
-    int rc = rmu_img_err_launch(dst, n, (float*)nb.p, s);
-    if (rc) return fail(rc, "rmu_index_add: image error");
-    hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
-    HIP_TRY(hipMemcpyAsync(&hmx, mx, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    memcpy(&f, &hmx, 4);
+    memcpy(&f, &idx->stat_host[1], 4);
     f = sqrtf(f) * 1.0001f;
     if (f > idx->dx_max) idx->dx_max = f;
-    return RMU_OK;
 }
 
 extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int is_device, int64_t* first_row) {
@@ -560,6 +590,7 @@ extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int
         if (rc) return rc;
     }
     HIP_TRY(hipStreamSynchronize(s));
+    fold_image_stats(idx);
     idx->alive.resize((size_t)(idx->n + n), 1);
     idx->n += n;
     idx->n_live += n;
@@ -762,6 +793,7 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
         if (ok && idx->split) ok = rmu_split_launch((const float*)((const char*)idx->x + r0 * rowb), idx->split + r0 * RMU_IMG_ROW_BYTES, nr, s) == RMU_OK;
         if (ok && idx->split) ok = update_image_stats(idx, (const float*)((const char*)idx->x + r0 * rowb), nr, s) == RMU_OK;
         if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
+        if (ok) fold_image_stats(idx);
     }
     fclose(f);
     if (!ok) { rmu_index_free(idx); return fail(RMU_E_INVALID, std::string("rmu_index_load: truncated or unreadable: ") + path); }

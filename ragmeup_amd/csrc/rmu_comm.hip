@@ -31,6 +31,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;          // optional: rmu_comm_world asks the communicator itself
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     std::string error;
 };
 RcclApi g_rccl;
@@ -50,6 +52,8 @@ const RcclApi& rccl() {
         g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.handle, "ncclCommDestroy");
         g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.handle, "ncclAllGather");
         g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.handle, "ncclGetErrorString");
+        g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.handle, "ncclCommCount");
+        g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(g_rccl.handle, "ncclCommUserRank");
         if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString)
             g_rccl.error = "librccl.so lacks a required symbol";
     });
@@ -139,8 +143,16 @@ extern "C" int rmu_comm_init(rmu_comm_t** out, const void* id, int world, int ra
 
 extern "C" int rmu_comm_world(rmu_comm_t* c, int* world, int* rank) {
     if (!c) return cfail(RMU_E_INVALID, "rmu_comm_world: null");
-    if (world) *world = c->world;
-    if (rank) *rank = c->rank;
+    // what RCCL says the communicator is (ncclCommCount / ncclCommUserRank), not what rmu_comm_init was asked for
+    int w = c->world, r = c->rank;
+    const RcclApi& api = rccl();
+    if (c->comm && api.CommCount && api.CommUserRank) {
+        ncclResult_t e = api.CommCount(c->comm, &w);
+        if (e == ncclSuccess) e = api.CommUserRank(c->comm, &r);
+        if (e != ncclSuccess) return cfail(RMU_E_RCCL, std::string("ncclCommCount/ncclCommUserRank: ") + api.GetErrorString(e));
+    }
+    if (world) *world = w;
+    if (rank) *rank = r;
     return RMU_OK;
 }
 

@@ -68,6 +68,16 @@ class FlatIndex:
         N.check(self._lib.rmu_index_size(self._h, ctypes.byref(n)), "rmu_index_size")
         return int(n.value)
 
+    def stats(self) -> dict:
+        """rmu_index_stat: allocated capacity, re-allocations by add() and their wall time, live rows."""
+        out = {}
+        for name, what in (("capacity", N.STAT_CAPACITY), ("grow_count", N.STAT_GROW_COUNT), ("grow_ms", N.STAT_GROW_MS),
+                           ("live_rows", N.STAT_LIVE_ROWS)):
+            v = ctypes.c_double()
+            N.check(self._lib.rmu_index_stat(self._h, what, ctypes.byref(v)), "rmu_index_stat")
+            out[name] = float(v.value) if name == "grow_ms" else int(v.value)
+        return out
+
     # -- mutation ----------------------------------------------------------------------------------
     def add(self, vecs) -> int:
         """Append rows; returns the row id of the first one."""
@@ -131,8 +141,11 @@ class FlatIndex:
         return rows, scores
 
     # -- search ------------------------------------------------------------------------------------
-    def search(self, q, k: int, row_base: int = 0):
-        """Exact top-k.  numpy in -> numpy out; torch CUDA in -> torch CUDA out (same device)."""
+    def search(self, q, k: int, row_base: int = 0, stream: int | None = None):
+        """Exact top-k.  numpy in -> numpy out; torch CUDA in -> torch CUDA out (same device).
+        `stream` (torch CUDA input only): a non-zero hipStream_t handle (`torch.cuda.Stream.cuda_stream`) the search is ORDERED
+        on -- the call returns without any host synchronisation (include/rmu.h stream contract) and the outputs are valid for
+        work queued behind it on that stream.  Default: complete on return."""
         if _is_torch_cuda(q):
             import torch
             qq = q.detach().to(torch.float32).contiguous()
@@ -141,9 +154,10 @@ class FlatIndex:
             nq = qq.shape[0]
             out_s = torch.empty((nq, k), dtype=torch.float32, device=qq.device)
             out_r = torch.empty((nq, k), dtype=torch.int64, device=qq.device)
-            torch.cuda.current_stream().synchronize()
+            if not stream:
+                torch.cuda.current_stream().synchronize()
             N.check(self._lib.rmu_index_search(self._h, qq.data_ptr(), nq, int(k), N.F_Q_DEVICE | N.F_OUT_DEVICE,
-                                               int(row_base), out_s.data_ptr(), out_r.data_ptr(), 0),
+                                               int(row_base), out_s.data_ptr(), out_r.data_ptr(), int(stream or 0)),
                     "rmu_index_search")
             return out_s, out_r
         qq = np.ascontiguousarray(q, dtype=np.float32)
@@ -203,9 +217,9 @@ class FlatIndex:
         return {"grid": g.value, "block": b.value, "lds_bytes": l.value, "launches": p.value}
 
 
-def topk_merge(part_scores, part_rows, k: int | None = None, smaller_better: bool = False):
+def topk_merge(part_scores, part_rows, k: int | None = None, smaller_better: bool = False, stream: int | None = None):
     """Merge [parts, nq, k] shard lists (numpy or torch CUDA) -> [nq, k].  smaller_better: the scores are distances
-    (lists of an RMU_METRIC_L2SQ index)."""
+    (lists of an RMU_METRIC_L2SQ index).  `stream` as in FlatIndex.search (torch CUDA lists only)."""
     lib = N.lib()
     fl = N.F_SMALLER_BETTER if smaller_better else 0
     if _is_torch_cuda(part_scores):
@@ -215,9 +229,10 @@ def topk_merge(part_scores, part_rows, k: int | None = None, smaller_better: boo
         parts, nq, kk = s.shape
         out_s = torch.empty((nq, kk), dtype=torch.float32, device=s.device)
         out_r = torch.empty((nq, kk), dtype=torch.int64, device=s.device)
-        torch.cuda.current_stream().synchronize()
+        if not stream:
+            torch.cuda.current_stream().synchronize()
         N.check(lib.rmu_topk_merge(s.data_ptr(), r.data_ptr(), parts, nq, kk, N.F_Q_DEVICE | N.F_OUT_DEVICE | fl,
-                                   out_s.data_ptr(), out_r.data_ptr(), 0), "rmu_topk_merge")
+                                   out_s.data_ptr(), out_r.data_ptr(), int(stream or 0)), "rmu_topk_merge")
         return out_s, out_r
     s = np.ascontiguousarray(part_scores, dtype=np.float32)
     r = np.ascontiguousarray(part_rows, dtype=np.int64)

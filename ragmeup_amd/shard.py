@@ -38,7 +38,13 @@ class NativeComm:
         h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(unique_id, N.COMM_ID_BYTES)
         N.check(self._lib.rmu_comm_init(ctypes.byref(h), buf, int(world), int(rank)), "rmu_comm_init")
-        self._h, self.world, self.rank = h, int(world), int(rank)
+        self._h = h
+        # what the communicator itself reports (rmu_comm_world), not what the caller asked for
+        w, r = ctypes.c_int(), ctypes.c_int()
+        N.check(self._lib.rmu_comm_world(h, ctypes.byref(w), ctypes.byref(r)), "rmu_comm_world")
+        self.world, self.rank = int(w.value), int(r.value)
+        if (self.world, self.rank) != (int(world), int(rank)):
+            raise RuntimeError(f"rmu_comm_init: asked for rank {rank} of {world}, the communicator reports {self.rank} of {self.world}")
 
     @staticmethod
     def unique_id() -> bytes:
@@ -54,17 +60,21 @@ class NativeComm:
         dist.broadcast_object_list(ids, src=0, group=group)
         return cls(ids[0], world, rank, device=device)
 
-    def allgather_topk(self, s, r, smaller_better: bool = False):
-        """Local [nq, k] torch CUDA lists -> merged global [nq, k] (identical on every rank)."""
+    def allgather_topk(self, s, r, smaller_better: bool = False, stream: int | None = None):
+        """Local [nq, k] torch CUDA lists -> merged global [nq, k] (identical on every rank).
+        `stream`: a non-zero hipStream_t handle -> pack, all-gather and merge are ORDERED on it and the call returns without a
+        host synchronisation (the inputs must have been produced on that stream or be ordered before it); default: the inputs'
+        torch stream is drained first and the result is complete on return."""
         N = self._N
         s = s.contiguous()
         r = r.contiguous()
         nq, k = s.shape
         out_s, out_r = torch.empty_like(s), torch.empty_like(r)
-        torch.cuda.current_stream(s.device).synchronize()
+        if not stream:
+            torch.cuda.current_stream(s.device).synchronize()
         N.check(self._lib.rmu_shard_allgather_topk(self._h, s.data_ptr(), r.data_ptr(), nq, k,
                                                    N.F_Q_DEVICE | N.F_OUT_DEVICE | (N.F_SMALLER_BETTER if smaller_better else 0),
-                                                   out_s.data_ptr(), out_r.data_ptr(), 0), "rmu_shard_allgather_topk")
+                                                   out_s.data_ptr(), out_r.data_ptr(), int(stream or 0)), "rmu_shard_allgather_topk")
         return out_s, out_r
 
     def close(self):
@@ -100,6 +110,8 @@ class ShardedSearcher:
         self.row_base = int(row_base)
         self.group = group
         self.comm = comm                       # the C-ABI RCCL path when given (else torch.distributed)
+        self._native_local = local_search is None
+        self._stream = None                    # the searcher's own side stream (stream-ordered steps, torch CUDA queries)
         if local_search is None:
             if index is None:
                 raise ValueError("need an index or a local_search callable")
@@ -111,6 +123,24 @@ class ShardedSearcher:
         self._merge = merge
         self.force_collective = bool(force_collective)   # run the all-gather + merge even at world size 1 (tests)
 
+    def _search_stream_ordered(self, q, k: int):
+        """The sharded step with ZERO host synchronisations: local scan -> pack -> ONE RCCL all-gather -> merge, all ordered on
+        the searcher's own side stream (torch's default stream is the NULL stream, which the C-ABI reads as "internal + blocking");
+        the side stream waits for the caller's stream first (the queries) and the caller's stream waits for it afterwards (the
+        results), both by device-side events."""
+        cur = torch.cuda.current_stream(q.device)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(q.device)
+        side = self._stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            s, r = self.index.search(q, k, row_base=self.row_base, stream=side.cuda_stream)
+            out = self.comm.allgather_topk(s, r, smaller_better=self.smaller_better, stream=side.cuda_stream)
+            for t in (q, s, r, *out):
+                t.record_stream(side)
+        cur.wait_stream(side)
+        return out
+
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -118,6 +148,9 @@ class ShardedSearcher:
     def search(self, q, k: int):
         """q: [B, d] (torch tensor on this rank's device, identical on every rank).
         Returns (scores [B,k] f32, rows [B,k] i64) -- identical on every rank."""
+        if (self._native_local and self.comm is not None and (self.comm.world > 1 or self.force_collective)
+                and torch.is_tensor(q) and q.is_cuda):
+            return self._search_stream_ordered(q, k)
         s, r = self._search(q, k)
         if self.comm is not None and (self.comm.world > 1 or self.force_collective):
             return self.comm.allgather_topk(torch.as_tensor(s), torch.as_tensor(r), smaller_better=self.smaller_better)
