@@ -872,7 +872,11 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
         slots += S.parts;
     }
     const size_t part_keys = (size_t)nb * kp;
-    const size_t gbytes = (size_t)((nb + 255) / 256 * 256 + 64) * sizeof(u32);
+    const size_t gwords = (size_t)((nb + 255) / 256 * 256 + 64);
+    size_t pwords = 0;                                   // sibling-pacing progress words: [s_chunks][4] per paced launch
+    for (int l = 0; l < nl; ++l)
+        if (lv[(size_t)l].pace) pwords += (size_t)lv[(size_t)l].s_chunks * 4;
+    const size_t gbytes = (gwords + pwords) * sizeof(u32);    // one memset zeroes thresholds and progress words
     if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
         t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.ensure_events(2 * nl))
         return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
@@ -883,10 +887,13 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
     if (rc) return fail(rc, "rmu_index_search: query conversion");
     u64* base = (u64*)t.partial.p;
     int cursor = 0;     // slot index: [merged keys of the ranges so far][this range's parts] ...
+    u32* prog_next = (u32*)t.gthr.p + gwords;
     for (int l = 0; l < nl; ++l) {
         ScanLaunch& S = lv[(size_t)l];
         const int first = cursor;               // slot of the running top-K' (l > 0), else of this range's first part
         if (l > 0) cursor += 1;
+        S.prog = nullptr;
+        if (S.pace) { S.prog = prog_next; prog_next += (size_t)S.s_chunks * 4; }
         S.partial = base + (size_t)cursor * part_keys;
         S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = g_dbg; S.q = (const float*)t.qsplit.p;
         if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l)], s));

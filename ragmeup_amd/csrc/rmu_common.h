@@ -120,6 +120,10 @@ struct ScanLaunch {
     int qg;                // screening scan only: 32-query groups per wave (rmu_screen_plan)
     int nt;                // 1 = stream the corpus with non-temporal loads (every byte is read by exactly one workgroup)
     RmuCond cond;          // exact scan only: device-side launch predicate (zero-initialised = always)
+    // screening scan only: sibling pacing (scan_screen.hip).  prog = [s_chunks][4] progress words of the query-tile workgroups
+    // of each row chunk (zeroed per launch; nullptr = off), pace = how many tiles a workgroup may run ahead of its slowest sibling
+    u32* prog;
+    int pace;
 };
 
 int rmu_scan_plan(ScanLaunch* p);                        // chooses geometry; returns 0 or RMU_E_INVALID

@@ -153,9 +153,42 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
     }
     u32* gthr_w = a.gthr + q_base;
     const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
+    // ---- sibling pacing (G = 1, <= 4 query tiles, one workgroup per CU: rmu_screen_plan decides) ----------------------------
+    // The nqt workgroups that scan the SAME row chunk for different query tiles sit on one XCD (block map above) so that the
+    // chunk's image bytes come from HBM once and from that XCD's L2 nqt - 1 times -- which only works while the siblings stay
+    // within an L2 window of each other, and left alone they drift (slow tiles, compactions): round 3 measured 1.97x the image
+    // in HBM fetches, L2 hit 0.53 of an ideal 0.75.  The whole grid is resident at once (one workgroup per CU, no second wave
+    // of blocks), so the kernel lasts as long as its slowest workgroup and a leader that waits loses nothing: every workgroup
+    // publishes ~tile (0 = not started / finished = "ignore me") once per tile, reads its siblings' words one tile stale through
+    // the same 4-byte LDS-DMA that refreshes the shared thresholds (lanes 32..35: no extra VMEM instruction), and wave 0 holds the
+    // workgroup at the ring barrier while it is more than a.pace tiles ahead of the slowest sibling.  A HINT only: the wait is
+    // bounded (a sibling that is not resident -- another kernel on the device -- switches pacing off for this workgroup).
+    const bool pace_on = G == 1 && a.prog != nullptr;
+    u32* prog_w = a.prog + (size_t)s_idx * 4;
+    bool pace_live = pace_on;
+    const u32* gsrc = gthr_w + (lane & (C::QW - 1));
+    if (G == 1 && pace_on && lane >= 32 && lane < 36) gsrc = prog_w + (lane - 32);
     auto refresh_gthr = [&]() {   // 4-byte LDS-DMA of this wave's shared thresholds (G = 1: both lane halves load the same)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gthr_w + (lane & (C::QW - 1))),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                          (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
+    };
+    auto pace_step = [&](int tile) {   // wave 0, once per tile, after the barrier that made the DMA'd words visible
+        if (lane == 0) __hip_atomic_store(prog_w + qt, ~(u32)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 m4 = max(max(gt_lds[32], gt_lds[33]), max(gt_lds[34], gt_lds[35]));   // uniform LDS reads (words of wave 0's area)
+        int lead = m4 ? tile - (int)~m4 : -1;                     // all zero: nobody to wait for
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(lead) > a.pace, 0)) {
+            int spins = 0;
+            do {
+                __builtin_amdgcn_s_sleep(24);
+                u32 v = 0;
+                if (lane < 4) v = __hip_atomic_load(prog_w + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = max(v, (u32)__shfl_xor((int)v, 1));
+                v = max(v, (u32)__shfl_xor((int)v, 2));
+                const u32 vm = (u32)__builtin_amdgcn_readfirstlane((int)v);
+                lead = vm ? tile - (int)~vm : -1;
+            } while (lead > a.pace && ++spins < 400);
+            if (spins >= 400) pace_live = false;
+        }
     };
 
     // ---- query fragments: step T covers k [16T, 16T+16); lane half h owns 8 of them -----------------------------------
@@ -346,6 +379,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
                     thr_g[g] = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
                 }
                 set_thr();
+                if (G == 1 && w == 0 && pace_live) pace_step(cc >> 1);
             } else {
                 refresh_gthr();
             }
@@ -389,6 +423,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
             tile_body(accA, accB, rb(tl - 1));              // (tile -1 = the -inf accumulators: nothing passes)
             if (tl + 1 < ntiles) tile_body(accB, accA, rb(tl));
         }
+        if (pace_on && w == 0 && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // finished: ignore me
         // the fragment reads issued for a chunk that does not exist are still in flight: their registers must stay
         // allocated until the data has landed (the compiler sees dead values and would reuse the registers under them)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -565,6 +600,16 @@ int rmu_screen_plan(ScanLaunch* p) {
     static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
     p->lds_bytes = p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
+    // sibling pacing (see the kernel): query tiles of a chunk on one XCD, 2..4 of them, the whole grid resident at once (these
+    // kernels take > 80 KiB of LDS: one workgroup per CU), and enough tiles per workgroup for drift to matter
+    const int pace_env = getenv("RMU_SCREEN_PACE") ? atoi(getenv("RMU_SCREEN_PACE")) : 8;   // (read per plan while the window is being tuned)
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+    }();
+    p->pace = (pace_env > 0 && p->qg == 1 && p->nqt >= 2 && p->nqt <= 4 && (p->s_chunks & 7) == 0 && p->grid <= n_cu &&
+               p->tiles_per_chunk >= 4 * pace_env) ? pace_env : 0;
     return RMU_OK;
 }
 
