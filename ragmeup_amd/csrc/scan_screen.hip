@@ -160,9 +160,13 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
     // in HBM fetches, L2 hit 0.53 of an ideal 0.75.  The whole grid is resident at once (one workgroup per CU, no second wave
     // of blocks), so the kernel lasts as long as its slowest workgroup and a leader that waits loses nothing: every workgroup
     // publishes ~tile (0 = not started / finished = "ignore me") once per tile, reads its siblings' words one tile stale through
-    // the same 4-byte LDS-DMA that refreshes the shared thresholds (lanes 32..35: no extra VMEM instruction), and wave 0 holds the
-    // workgroup at the ring barrier while it is more than a.pace tiles ahead of the slowest sibling.  A HINT only: the wait is
-    // bounded (a sibling that is not resident -- another kernel on the device -- switches pacing off for this workgroup).
+    // the same 4-byte LDS-DMA that refreshes the shared thresholds (lanes 32..35: no extra VMEM instruction), and the pacing wave
+    // holds the workgroup at the ring barrier while it is more than a.pace tiles ahead of the slowest sibling.  A HINT only: the
+    // wait is bounded (a sibling that is not resident -- another kernel on the device -- switches pacing off for this workgroup).
+    // The pacing wave is the LAST one (with 8 waves it carries no corpus DMA): vmcnt retires in order, so a store issued by a DMA
+    // wave sits in front of that wave's counted ring waits until the write is acknowledged -- the first version (wave 0, agent-scope
+    // store) doubled the kernel's time.  The store is a plain one: the siblings share this XCD's L2, which is where it lands, and
+    // they read with sc1 (past their vector L1).
     const bool pace_on = G == 1 && a.prog != nullptr;
     u32* prog_w = a.prog + (size_t)s_idx * 4;
     bool pace_live = pace_on;
@@ -172,9 +176,10 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                          (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
     };
-    auto pace_step = [&](int tile) {   // wave 0, once per tile, after the barrier that made the DMA'd words visible
-        if (lane == 0) __hip_atomic_store(prog_w + qt, ~(u32)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u32 m4 = max(max(gt_lds[32], gt_lds[33]), max(gt_lds[34], gt_lds[35]));   // uniform LDS reads (words of wave 0's area)
+    constexpr int PW = NW - 1;         // the pacing wave
+    auto pace_step = [&](int tile) {   // once per tile, after the barrier (the DMA'd words may be a few tiles stale: harmless)
+        if (lane == 0) __hip_atomic_store(prog_w + qt, ~(u32)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 m4 = max(max(gt_lds[32], gt_lds[33]), max(gt_lds[34], gt_lds[35]));   // uniform LDS reads (words of this wave's area)
         int lead = m4 ? tile - (int)~m4 : -1;                     // all zero: nobody to wait for
         if (__builtin_expect(__builtin_amdgcn_readfirstlane(lead) > a.pace, 0)) {
             int spins = 0;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
                     thr_g[g] = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
                 }
                 set_thr();
-                if (G == 1 && w == 0 && pace_live) pace_step(cc >> 1);
+                if (G == 1 && w == PW && pace_live) pace_step(cc >> 1);
             } else {
                 refresh_gthr();
             }
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
             tile_body(accA, accB, rb(tl - 1));              // (tile -1 = the -inf accumulators: nothing passes)
             if (tl + 1 < ntiles) tile_body(accB, accA, rb(tl));
         }
-        if (pace_on && w == 0 && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // finished: ignore me
+        if (pace_on && w == PW && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // finished: ignore me
         // the fragment reads issued for a chunk that does not exist are still in flight: their registers must stay
         // allocated until the data has landed (the compiler sees dead values and would reuse the registers under them)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
