@@ -1296,6 +1296,16 @@ static_assert(LDS_BYTES <= 160 * 1024 && TOK * TSTR <= LDS_BYTES, "LDS");
 // DMA instructions per wave that may still be in flight when slab i must have landed (W1 slab = 2 per wave, W2 slab = 3; issue
 // order per iteration as in k_ffn2: S4 during slab 0; S0', S1', S2' during slab 3; S3' during slab 4)
 __host__ __device__ constexpr int wait_n(int i) { return i == 0 ? 7 : i == 1 ? 8 : i == 2 ? 6 : i == 3 ? 3 : 6; }
+// VAR bit 2, LOOK-AHEAD (round 4): at the barrier that opens slab i, slab i + 1 has landed as well, so the first PF fragments of slab
+// i + 1 are read during the last PF steps of slab i and the MFMAs behind a barrier start at once -- without it all eight waves of a
+// workgroup (both waves of every SIMD) sit out an LDS round trip behind each of the five barriers of a chunk at the same time.  The
+// ring stays one chunk deep (5 slots = 5 slabs); the price is paid in DMA lead instead: the refill of slot j is issued during slab
+// j + 1 (everybody has passed barrier j + 1, i.e. is done reading slot j) and must have landed by barrier j - 1 of the next round:
+// three slab times for every slab (issue order R4, R0', R1', R2', R3', one refill per slab).  In flight at barrier i: the refills
+// issued during slabs i - 1 and i - 2, i.e. of slots i - 2 and i - 3 (2 instructions per wave for a W1 slot, 3 for a W2 slot).
+__host__ __device__ constexpr int slot_ni(int j) { return ((j % 5) + 5) % 5 < 3 ? 2 : 3; }
+__host__ __device__ constexpr int wait_la(int i) { return slot_ni(i - 2) + slot_ni(i - 3); }
+static_assert(wait_la(0) == 5 && wait_la(1) == 6 && wait_la(2) == 5 && wait_la(3) == 4 && wait_la(4) == 4, "look-ahead wait counts");
 }  // namespace ffn3
 
 template <bool LN_IN, int PF, bool DBG, int VAR, bool OP = false>   // OP: x is the attention output ctx -- the out-proj GEMM + bias + residual runs in the prologue (see below); VAR bit 0: activation as packed-f32 instructions (else hipcc's vector code), bit 1: k_pack_ffn3 weight streams (else W1 / W2p rows); DBG: ablation flags (RMU_FFN3_DBG, debug build): 1 no activation, 2 no fragment reads, 4 no DMA, 8 no exchange, 16 no barriers
@@ -1671,30 +1681,50 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         if constexpr (i == 3) issue_part(0, ic, std::integral_constant<int, 2>{});
     });
     load_bias(0);
+    constexpr bool LA = (VAR & 4) != 0;
+    if constexpr (LA) {
+        // slab 0 of iteration 0 has no barrier in front of it that proves everybody's pieces landed: one extra wait + barrier, then
+        // its first fragments (in flight behind it: slabs 1, 2, 3 = 2 + 2 + 3 instructions)
+        asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        static_for<PF>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            ds_read16<0>(fq[n], (n & 1) ? a1B[n >> 1] : a1A[n >> 1]);
+        });
+    }
 
     // Iteration c (ONE body, as k_ffn2): FFN1 partials of chunk min(c, NCH - 1); activation of the own tile of chunk c - 1;
     // FFN2 of chunk c - 1 over this half's outputs.
     for (int c = 0; c <= NCH; ++c) {
         static_for<5>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(wait_n(i)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LA ? wait_la(i) : wait_n(i)) : "memory");
             if (!DBG || !(dflags & 16)) __builtin_amdgcn_s_barrier();
             if constexpr (i == 0) asm volatile("" : "+v"(accA));      // the bias reads have landed (the wait above)
             if constexpr (i < 3) {
                 // ---- FFN1 slab i: 4 k-steps x 2 tiles, n = 2 ks + (0: own tile, 1: partner's); behind MFMA n: activation stage 8 i + n
-                static_for<PF>([&](auto nc) {
+                if constexpr (!LA) static_for<PF>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     if (!DBG || !(dflags & 2)) ds_read16<i * S1>(fq[n], (n & 1) ? a1B[n >> 1] : a1A[n >> 1]);
                 });
                 static_for<8>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     if constexpr (n % 2 == 0)
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"(n + PF <= 8 ? PF - 2 : 8 - 2 - n));
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"((LA || n + PF <= 8) ? PF - 2 : 8 - 2 - n));
                     if constexpr (n & 1) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], hf[i * 4 + (n >> 1)], accB, 0, 0, 0);
                     else accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], hf[i * 4 + (n >> 1)], accA, 0, 0, 0);
                     if constexpr (n + PF < 8) { if (!DBG || !(dflags & 2)) ds_read16<i * S1>(fq[n % PF], ((n + PF) & 1) ? a1B[(n + PF) >> 1] : a1A[(n + PF) >> 1]); }
-                    else asm volatile("" : "+v"(fq[n % PF]));
-                    if constexpr (i == 0 && n % 2 == 1 && n / 2 < 3) issue_part(c, std::integral_constant<int, 4>{}, std::integral_constant<int, n / 2>{});
+                    else if constexpr (LA) {                   // fragment m of the NEXT slab (landed: look-ahead wait at this slab's barrier)
+                        constexpr int m = n + PF - 8;
+                        if constexpr (i < 2) ds_read16<(i + 1) * S1>(fq[n % PF], (m & 1) ? a1B[m >> 1] : a1A[m >> 1]);
+                        else ds_read16<(m % 6) * 2048>(fq[n % PF], a2[m / 6]);
+                    } else asm volatile("" : "+v"(fq[n % PF]));
+                    if constexpr (LA) {                        // one refill per slab: slot 4 during slab 0, W1 slot i - 1 of the next chunk during slabs 1, 2
+                        if constexpr (i == 0 && n % 2 == 1 && n / 2 < 3) issue_part(c, std::integral_constant<int, 4>{}, std::integral_constant<int, n / 2>{});
+                        if constexpr (i > 0 && n % 2 == 1 && n / 2 < 2) issue_part(c + 1, std::integral_constant<int, i - 1>{}, std::integral_constant<int, n / 2>{});
+                    } else {
+                        if constexpr (i == 0 && n % 2 == 1 && n / 2 < 3) issue_part(c, std::integral_constant<int, 4>{}, std::integral_constant<int, n / 2>{});
+                    }
                     gelu_stage((8 * i + n) / 6, (8 * i + n) % 6);
                 });
                 if constexpr (i == 2) if (!DBG || !(dflags & 8)) {
@@ -1728,20 +1758,30 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
                     asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(pp[2]) : "v"(xp_r));
                     asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(pp[3]) : "v"(xp_r));
                 }
-                static_for<PF>([&](auto nc) {
+                if constexpr (!LA) static_for<PF>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
                     if (!DBG || !(dflags & 2)) ds_read16<t * S2 + (n % 6) * 2048>(fq[n], a2[n / 6]);
                 });
                 static_for<12>([&](auto nc) {
                     constexpr int n = decltype(nc)::value;
-                    if constexpr (n % 2 == 0)
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"(n + PF <= 12 ? PF - 2 : 12 - 2 - n));
+                    // look-ahead: the slab's first PF fragments are OLDER than the exchange reads above (they were issued during the previous
+                    // slab); the first wait must reach past them to pf[0] (2, resp. 2 + 4 exchange reads, all but the first may stay in flight)
+                    if constexpr (LA && n == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[0]), "+v"(fq[1]) : "n"(t == 0 ? 5 : 1));
+                    else if constexpr (n % 2 == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[n % PF]), "+v"(fq[(n + 1) % PF]) : "n"((LA || n + PF <= 12) ? PF - 2 : 12 - 2 - n));
                     if constexpr (n == 0) asm volatile("" : "+v"(pf[0]), "+v"(pf[1]));
                     acc2[n % 6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % PF], __builtin_bit_cast(bf16x8, pf[n / 6]), acc2[n % 6], 0, 0, 0);
                     if constexpr (n + PF < 12) { if (!DBG || !(dflags & 2)) ds_read16<t * S2 + ((n + PF) % 6) * 2048>(fq[n % PF], a2[(n + PF) / 6]); }
-                    else asm volatile("" : "+v"(fq[n % PF]));
+                    else if constexpr (LA) {                   // fragment m of the next slab: W2 tile 1, resp. W1 slab 0 of the next iteration
+                        constexpr int m = n + PF - 12;
+                        if constexpr (t == 0) ds_read16<S2 + (m % 6) * 2048>(fq[n % PF], a2[m / 6]);
+                        else ds_read16<0>(fq[n % PF], (m & 1) ? a1B[m >> 1] : a1A[m >> 1]);
+                    } else asm volatile("" : "+v"(fq[n % PF]));
                     if constexpr (t == 0) {
-                        if constexpr (n % 2 == 0) {          // S0', S1', S2' of iteration c + 1: 6 instructions over 12 steps
+                        if constexpr (LA) {                  // refill of W1 slot 2 (chunk c + 1): 2 instructions
+                            if constexpr (n == 0 || n == 2) issue_part(c + 1, std::integral_constant<int, 2>{}, std::integral_constant<int, n / 2>{});
+                        } else if constexpr (n % 2 == 0) {          // S0', S1', S2' of iteration c + 1: 6 instructions over 12 steps
                             constexpr int k = n / 2;
                             issue_part(c + 1, std::integral_constant<int, k / 2>{}, std::integral_constant<int, k % 2>{});
                         }
@@ -2931,6 +2971,12 @@ static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps
     switch (var & 3) { RMU_FFN3_CASE(1) RMU_FFN3_CASE(2) RMU_FFN3_CASE(3) default: break; }
 #undef RMU_FFN3_CASE
 #endif
+    const int la = getenv("RMU_FFN3_LA") ? atoi(getenv("RMU_FFN3_LA")) : 1;   // (read per launch while the look-ahead form is being A/B-ed)
+    if (la) {
+        if (ln_in) launch_ffn3_t<true, 4, 4>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
+        else launch_ffn3_t<false, 4, 4>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
+        return;
+    }
     if (ln_in) launch_ffn3_t<true, 4, 0>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
     else launch_ffn3_t<false, 4, 0>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
 }
