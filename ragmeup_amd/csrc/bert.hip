@@ -496,14 +496,20 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
 // sit in registers as MFMA A fragments (K/64 of them), token fragments come straight from global memory (no LDS staging), the
 // four partial sums meet in LDS and all 256 threads run the epilogue (bias | + GELU | + residual).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int SMALL_M = 256;                           // tokens (upper bound batch * max_len) up to which this path is taken
+constexpr int SMALL_M = 256;                           // tokens (upper bound batch * max_len) one graph-replayed host call may carry (rmu_bert_encode_host)
+// Round 4: the token dimension is a grid dimension too -- workgroup (x, y) takes features [32 x, +32) of tokens [SMALL_TB y, +SMALL_TB)
+// -- so the same kernel serves a few THOUSAND tokens (the reference's rerank call: <= 14 (query, passage) pairs, ~1.5k tokens,
+// twice per /chat request): the tiled kernels run 6-36 workgroups there (10-17 us per launch), this one N/32 x M/128 short ones.
 template <int EPI, int K>
 __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
                                                     const bf16* __restrict__ resid, bf16* __restrict__ out, const int* __restrict__ cu,
-                                                    int batch, int N) {
+                                                    int batch, int N, int SMALL_TB /* tokens per workgroup along grid.y, a multiple of 32 */) {
     constexpr int KW = K / 4, NF = KW / 16;
     __shared__ float red[4][32][36];                   // [K quarter][token][feature (+4 pad)]
     const int M = cu[batch];
+    const int tb0 = blockIdx.y * SMALL_TB;
+    if (tb0 >= M) return;                              // (the grid is sized by the shape's upper bound batch * max_len)
+    const int tb1 = min(M, tb0 + SMALL_TB);
     const int n0 = blockIdx.x * 32;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r31 = lane & 31, hh = lane >> 5;
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, 
     }
     const int et = threadIdx.x >> 3, ef = (threadIdx.x & 7) * 4;       // epilogue: token et, features ef .. ef + 3
     const f32x4 bv = *(const f32x4*)(bias + n0 + ef);
-    for (int t0 = 0; t0 < M; t0 += 32) {
+    for (int t0 = tb0; t0 < tb1; t0 += 32) {
         const int tok = min(t0 + r31, M - 1);
         const bf16* xr = A + (int64_t)tok * K + w * KW + hh * 8;
         bf16x8 xf[NF];
@@ -2612,30 +2618,46 @@ __global__ __launch_bounds__(256) void k_tokens_out(const bf16* __restrict__ h, 
 }
 
 // BertForSequenceClassification(num_labels=1): logit = wc . tanh(Wp h_cls + bp) + bc ; one block per sequence
-__global__ __launch_bounds__(128) void k_cls_head(const bf16* __restrict__ h, const int* __restrict__ cu,
+__global__ __launch_bounds__(512) void k_cls_head(const bf16* __restrict__ h, const int* __restrict__ cu,
                                                   const float* __restrict__ wp, const float* __restrict__ bp,
                                                   const float* __restrict__ wc, const float* __restrict__ bc,
                                                   float* __restrict__ out) {
-    __shared__ float hc[H];
-    __shared__ float red[128];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // logit = wc . tanh(Wp h_cls + bp) + bc.  One workgroup of 8 waves per sequence; wave w takes pooler rows [48 w, +48), sixteen at a
+    // time: the 64 lanes read a row's 384 fp32 weights as six coalesced 256-byte pieces, 96 loads in flight per lane before the first
+    // use, then shuffle reductions.  (Round 3 walked one row per THREAD -- 1536-byte strides between the lanes of a load, 384 dependent
+    // steps: 26 us for 14 sequences, as long as two encoder layers of the rerank call it ends.  The kernel is a chain of L2 / fabric
+    // round trips either way; this form has three of them instead of hundreds.)
+    __shared__ float red[8];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t0 = cu[b], L = cu[b + 1] - t0;
-    for (int c = tid; c < H; c += 128) hc[c] = L > 0 ? bf2f(h[(int64_t)t0 * H + c]) : 0.f;
-    __syncthreads();
+    float hc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hc[j] = L > 0 ? bf2f(h[(int64_t)t0 * H + lane + 64 * j]) : 0.f;
     float part = 0.f;
-    for (int o = tid; o < H; o += 128) {
-        const float* wr = wp + (int64_t)o * H;
-        float a = bp[o];
-        for (int c = 0; c < H; ++c) a = fmaf(wr[c], hc[c], a);
-        part = fmaf(wc[o], tanhf(a), part);
+#pragma unroll 1
+    for (int o0 = w * 48; o0 < w * 48 + 48; o0 += 16) {
+        float wv[16][6];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) wv[r][j] = wp[(int64_t)(o0 + r) * H + lane + 64 * j];
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[r] = fmaf(wv[r][j], hc[j], a[r]);
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] += __shfl_xor(a[r], sft);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = fmaf(wc[o0 + r], tanhf(a[r] + bp[o0 + r]), part);
     }
-    red[tid] = part;
+    if (lane == 0) red[w] = part;
     __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    if (tid == 0) out[b] = red[0] + bc[0];
+    if (threadIdx.x == 0) out[b] = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) + bc[0];
 }
 
 }  // namespace
@@ -2861,18 +2883,40 @@ static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, con
 #endif
     hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST, TA>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg | (resid_tiled ? 256 : 0));
 }
+// tokens (batch * max_len) up to which all four GEMMs of a layer take k_gemm_small (features AND token blocks spread over the chip)
+static int64_t mid_tokens() {
+    const int64_t v = getenv("RMU_MID_TOKENS") ? atoll(getenv("RMU_MID_TOKENS")) : 256;   // (read per launch while the threshold is being tuned)
+    return v < SMALL_M ? SMALL_M : v;
+}
+// tokens from which the QKV projection takes the persistent k_gemm3 (below: launch_gemm's choice)
+static int64_t g3_min_tokens() {
+    const int64_t v = getenv("RMU_G3_MIN") ? atoll(getenv("RMU_G3_MIN")) : 0;
+    return v > mid_tokens() ? v : mid_tokens();
+}
 template <int EPI>
 static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
                         int batch, int64_t m_cap, int N, int K, hipStream_t s) {
     static const bool small_ok = !(getenv("RMU_GEMM_SMALL") && atoi(getenv("RMU_GEMM_SMALL")) == 0);
-    if (small_ok && m_cap <= SMALL_M && (K == H || K == FF)) {
-        if (K == H) hipLaunchKernelGGL((k_gemm_small<EPI, H>), dim3((unsigned)(N / 32)), dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N);
-        else hipLaunchKernelGGL((k_gemm_small<EPI, FF>), dim3((unsigned)(N / 32)), dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N);
+    if (small_ok && m_cap <= mid_tokens() && (K == H || K == FF)) {
+        const int tb = getenv("RMU_SMALL_TB") ? atoi(getenv("RMU_SMALL_TB")) / 32 * 32 : 32;   // (read per launch while being tuned)
+        const dim3 grid((unsigned)(N / 32), (unsigned)((m_cap + tb - 1) / tb));
+        if (K == H) hipLaunchKernelGGL((k_gemm_small<EPI, H>), grid, dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N, tb);
+        else hipLaunchKernelGGL((k_gemm_small<EPI, FF>), grid, dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N, tb);
         return;
     }
     // few tiles (latency-bound: every workgroup walks K alone): 128 x 128 tiles in 64-k stages halve the stage count and double
     // the workgroups -- 4k tokens 0.70 -> 0.60 ms per forward, 16k tokens 1.12 -> 1.07; big batches keep 256 x 128 / 32-k stages
     // (best of the seven tile / stage / ring combinations measured in round 2)
+    {   // (A/B while the mid-size shapes are being tuned: RMU_GEMM_CFG = 1: 128x128 / 3 stages, 2: 128x128 / 4, 3: 64x128 / 4, 4: 64x128 / 6)
+        const int cfgv = getenv("RMU_GEMM_CFG") ? atoi(getenv("RMU_GEMM_CFG")) : 0;
+        const int64_t lim = getenv("RMU_GEMM_CFG_MAX") ? atoll(getenv("RMU_GEMM_CFG_MAX")) : 8192;
+        if (cfgv && m_cap <= lim) {
+            if (cfgv == 1) return launch_gemm_cfg<EPI, 2, 64, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+            if (cfgv == 2) return launch_gemm_cfg<EPI, 2, 64, 4>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+            if (cfgv == 3) return launch_gemm_cfg<EPI, 1, 64, 4>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+            if (cfgv == 4) return launch_gemm_cfg<EPI, 1, 64, 6>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
+        }
+    }
     if (m_cap <= 32768) return launch_gemm_cfg<EPI, 2, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
     return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
 }
@@ -3048,7 +3092,8 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     const int64_t cap = (int64_t)batch * max_len;
     const float eps = m->cfg.ln_eps;
 
-    hipLaunchKernelGGL(k_cu_seqlens, dim3(1), dim3(1024), 0, s, (const int*)lens, batch, max_len, m->cu);
+    // (thread 0 folds one partial per thread serially: a block no wider than the batch needs -- 1024 threads cost 12 us for 14 sequences)
+    hipLaunchKernelGGL(k_cu_seqlens, dim3(1), dim3(batch <= 64 ? 64 : batch <= 256 ? 256 : 1024), 0, s, (const int*)lens, batch, max_len, m->cu);
     hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, (const int*)ids, (const int*)type_ids,
                        (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
                        m->cfg.type_vocab, m->h);
@@ -3069,8 +3114,8 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // QKV head-major when k_gemm3 writes it and k_attn3 reads it (RMU_QKV_HM=0: row-major); the stride between (part, head) planes is the
         // workspace's token capacity
         static const bool hm_env = !(getenv("RMU_QKV_HM") && atoi(getenv("RMU_QKV_HM")) == 0);
-        const int64_t hm_stride = (hm_env && (g3_mask & 1) && cap > SMALL_M && attn_v == 3) ? m->ws_tokens : 0;
-        if ((g3_mask & 1) && cap > SMALL_M) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled, hm_stride);
+        const int64_t hm_stride = (hm_env && (g3_mask & 1) && cap > g3_min_tokens() && attn_v == 3) ? m->ws_tokens : 0;
+        if ((g3_mask & 1) && cap > g3_min_tokens()) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled, hm_stride);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
         static const bool tiled_env = !(getenv("RMU_CTX_TILED") && atoi(getenv("RMU_CTX_TILED")) == 0);
@@ -3155,7 +3200,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         hipLaunchKernelGGL(k_tokens_out, dim3((unsigned)((cap * (H / 8) + 255) / 256)), dim3(256), 0, s, (const bf16*)m->h, (const int*)m->cu, batch,
                            out_dev, out_stride);
     else
-        hipLaunchKernelGGL(k_cls_head, dim3((unsigned)batch), dim3(128), 0, s, (const bf16*)m->h, (const int*)m->cu, m->wp, m->bp, m->wc, m->bc, out_dev);
+        hipLaunchKernelGGL(k_cls_head, dim3((unsigned)batch), dim3(512), 0, s, (const bf16*)m->h, (const int*)m->cu, m->wp, m->bp, m->wc, m->bc, out_dev);
 }
 
 extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
