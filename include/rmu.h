@@ -212,12 +212,25 @@ int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, 
                     int batch, int max_len, int mode, float* out_dev, int64_t out_stride,
                     uint64_t hip_stream);
 
-/* The same forward for a HANDFUL of tokens (batch * max_len <= 256: embed_query, a few passages to rerank) from HOST buffers to a
- * HOST result: the interactive per-request pattern of the reference (one query per /chat call, RAGHelper.py:497-499).  The
- * library replays one captured hipGraph per input shape (H2D, ~45 launches, D2H: one graph launch, one synchronisation).
+/* The same forward for a HANDFUL of tokens (batch * max_len <= 4096 and <= 256 result rows: embed_query, the <= 14 (query, passage)
+ * pairs of one rerank call) from HOST buffers to a HOST result: the interactive per-request pattern of the reference (one query per
+ * /chat call, RAGHelper.py:497-499; ScoredCrossEncoderReranker.py:42).  The library replays one captured hipGraph per input shape
+ * (H2D, ~45 launches, D2H: one graph launch, one synchronisation) and keeps the 64 most recently used shapes: callers should bucket
+ * batch and max_len (a padded sequence has lens = 0 and costs nothing).
  * ids / type_ids (may be NULL) [batch, max_len], lens [batch]: host int32; out_host as out_dev above, on the host. */
 int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens,
                          int batch, int max_len, int mode, float* out_host, int64_t out_stride);
+
+/* The reference's per-request retrieval as ONE call with ONE synchronisation (VectorStoreRetriever.invoke with search_type="mmr",
+ * RAGHelper.py:497-499: embed_query -> dense top-fetch_k -> maximal_marginal_relevance): HOST token ids of `batch` queries in (as
+ * rmu_bert_encode_host; mode = RMU_BERT_POOL_MEAN | RMU_BERT_POOL_CLS [| RMU_BERT_NO_NORMALIZE]), HOST out_rows [batch, k] int64 (row ids
+ * + row_base in pick order, -1 past the number of candidates) and out_scores [batch, k] fp32 (the search score of each pick; may be
+ * NULL) out.  The pooled query vectors stay on the device between the forward and the search (out_vecs, if not NULL, receives
+ * them: [batch, 384] fp32).  lambda_mult < 0: no selection -- the top-k in score order (k <= fetch_k), i.e. rmu_index_search.
+ * fetch_k <= 64, k <= fetch_k; the index must hold 384-d rows.  Results equal rmu_bert_encode_host + rmu_index_search_mmr. */
+int rmu_bert_search_mmr(rmu_bert_t* m, rmu_index_t* idx, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
+                        int max_len, int mode, int fetch_k, int k, double lambda_mult, int64_t row_base, int64_t* out_rows,
+                        float* out_scores, float* out_vecs);
 
 /* ---- WordPiece tokenizer (host C++; the step in front of both encoder forwards) --------------------
  * Restates transformers' BertTokenizer (BasicTokenizer + WordPiece) as used by sentence-transformers `tokenize`

@@ -26,7 +26,7 @@ SYMBOLS = [
     "rmu_index_remove_rows", "rmu_index_get_rows", "rmu_index_save", "rmu_index_load", "rmu_index_mmr", "rmu_index_search_mmr", "rmu_index_search", "rmu_topk_merge",
     "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing", "rmu_last_screened",
     "rmu_comm_unique_id", "rmu_comm_init", "rmu_comm_free", "rmu_comm_world", "rmu_shard_allgather_topk", "rmu_index_screen_candidates",
-    "rmu_bert_create", "rmu_bert_free", "rmu_bert_encode", "rmu_bert_encode_host",
+    "rmu_bert_create", "rmu_bert_free", "rmu_bert_encode", "rmu_bert_encode_host", "rmu_bert_search_mmr",
     "rmu_tok_create", "rmu_tok_free", "rmu_tok_vocab_size", "rmu_tok_encode", "rmu_tok_encode_blob",
 ]
 
@@ -83,6 +83,7 @@ def _declare(lib):
         lib.rmu_bert_free.argtypes = [vp]
         lib.rmu_bert_encode.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i64, u64]
         lib.rmu_bert_encode_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, i64]
+        lib.rmu_bert_search_mmr.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, c.c_double, i64, vp, vp, vp]
 
 
 def lib():

@@ -129,27 +129,80 @@ class BertEncoder:
             pass
 
     # ---- forward ------------------------------------------------------------------------------------------
-    SMALL_TOKENS = 256          # rmu_bert_encode_host: batch * max_len it accepts
+    SMALL_TOKENS = 256          # one query through the host entry points (embed_query)
+    HOST_TOKENS = 4096          # rmu_bert_encode_host / rmu_bert_search_mmr: bucketed batch * max_len they accept
+    HOST_ROWS = 256             # ... and result rows (pooled vectors / token states) per call
+
+    @staticmethod
+    def _bucket(n: int, steps=(1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256)) -> int:
+        for v in steps:
+            if n <= v:
+                return v
+        return n
+
+    def host_shape(self, batch: int, max_len: int, mode: int) -> tuple[int, int] | None:
+        """The bucketed (batch, max_len) a host call of this shape runs at -- the library keeps one captured graph per SHAPE, so
+        shapes are rounded up to a few sizes (a padded sequence has length 0: the packed-token kernels spend nothing on it, the
+        results are those of the unpadded call bit for bit) -- or None when the call does not fit the host entry points."""
+        kind = mode & 0xff
+        lb = min(-(-max(int(max_len), 1) // 32) * 32, self.max_pos) if max_len > 16 else 16
+        if kind == MODE_TOKENS:                            # packed token states: the row count is the token count, no padding rows
+            return (batch, lb) if batch * lb <= self.HOST_ROWS else None
+        bb = self._bucket(int(batch))
+        if bb * lb > self.HOST_TOKENS or (kind != MODE_CE and bb > self.HOST_ROWS):
+            bb = int(batch)                                # the exact batch may still fit
+        if bb * lb > self.HOST_TOKENS or (kind != MODE_CE and bb > self.HOST_ROWS) or lb < max_len:
+            return None
+        return bb, lb
+
+    def _host_arrays(self, ids, lens, type_ids, mode):
+        ids = np.asarray(ids)
+        lens = np.asarray(lens)
+        B, L = ids.shape
+        shp = self.host_shape(B, L, mode)
+        if shp is None:
+            raise ValueError(f"a host call carries at most {self.HOST_TOKENS} tokens and {self.HOST_ROWS} result rows: got batch {B} x max_len {L}")
+        bb, lb = shp
+        pi = np.zeros((bb, lb), dtype=np.int32)
+        pi[:B, :L] = ids
+        pl = np.zeros((bb,), dtype=np.int32)
+        pl[:B] = np.minimum(np.maximum(lens, 0), L)
+        pt = None
+        if type_ids is not None:
+            pt = np.zeros((bb, lb), dtype=np.int32)
+            pt[:B, :L] = type_ids
+        return pi, pl, pt, B, bb, lb
 
     def encode_host(self, ids, lens, type_ids=None, mode: int = 0) -> np.ndarray:
-        """The interactive path (embed_query, a few pairs): HOST int32 arrays in, HOST fp32 array out, batch * L <= 256.  One
-        captured hipGraph per input shape is replayed inside librmu.so (rmu_bert_encode_host): one graph launch + one
-        synchronisation instead of ~45 launches and three torch tensor copies."""
-        ids = np.ascontiguousarray(ids, dtype=np.int32)
-        lens = np.ascontiguousarray(lens, dtype=np.int32)
-        B, L = ids.shape
-        tt = None if type_ids is None else np.ascontiguousarray(type_ids, dtype=np.int32)
+        """The interactive path (embed_query, the <= 14 pairs of a rerank call): HOST int arrays in, HOST fp32 array out, up to 4096
+        tokens.  One captured hipGraph per bucketed input shape is replayed inside librmu.so (rmu_bert_encode_host): one graph
+        launch + one synchronisation instead of ~45 launches and three torch tensor copies."""
+        pi, pl, pt, B, bb, lb = self._host_arrays(ids, lens, type_ids, mode)
         kind = mode & 0xff
         if kind == MODE_CE:
-            out = np.empty((B,), dtype=np.float32)
+            out = np.empty((bb,), dtype=np.float32)
         elif kind == MODE_TOKENS:
-            out = np.empty((int(np.minimum(np.maximum(lens, 0), L).sum()), self.HIDDEN), dtype=np.float32)
+            out = np.empty((int(pl.sum()), self.HIDDEN), dtype=np.float32)
         else:
-            out = np.empty((B, self.HIDDEN), dtype=np.float32)
-        N.check(self._lib.rmu_bert_encode_host(self._h, ids.ctypes.data, tt.ctypes.data if tt is not None else None, lens.ctypes.data,
-                                               int(B), int(L), int(mode), out.ctypes.data, 1 if kind == MODE_CE else self.HIDDEN),
+            out = np.empty((bb, self.HIDDEN), dtype=np.float32)
+        N.check(self._lib.rmu_bert_encode_host(self._h, pi.ctypes.data, pt.ctypes.data if pt is not None else None, pl.ctypes.data,
+                                               int(bb), int(lb), int(mode), out.ctypes.data, 1 if kind == MODE_CE else self.HIDDEN),
                 "rmu_bert_encode_host")
-        return out
+        return out if kind == MODE_TOKENS else out[:B]
+
+    def search_host(self, index, ids, lens, mode: int, fetch_k: int, k: int, lambda_mult: float | None = 0.5, row_base: int = 0,
+                    want_vectors: bool = False):
+        """rmu_bert_search_mmr: the query's token ids in, result rows out -- forward (graph replay), dense top-fetch_k and the greedy
+        MMR selection (lambda_mult None: no selection, the top-k in score order) in ONE library call with ONE synchronisation; the
+        query vector never visits the host.  -> rows [B, k] int64, scores [B, k] fp32 (, vectors [B, 384] fp32)."""
+        pi, pl, pt, B, bb, lb = self._host_arrays(ids, lens, None, mode)
+        rows = np.empty((bb, int(k)), dtype=np.int64)
+        scores = np.empty((bb, int(k)), dtype=np.float32)
+        vecs = np.empty((bb, self.HIDDEN), dtype=np.float32) if want_vectors else None
+        N.check(self._lib.rmu_bert_search_mmr(self._h, index._h, pi.ctypes.data, None, pl.ctypes.data, int(bb), int(lb), int(mode), int(fetch_k),
+                                              int(k), -1.0 if lambda_mult is None else float(lambda_mult), int(row_base), rows.ctypes.data,
+                                              scores.ctypes.data, vecs.ctypes.data if vecs is not None else None), "rmu_bert_search_mmr")
+        return (rows[:B], scores[:B], vecs[:B]) if want_vectors else (rows[:B], scores[:B])
 
     def encode_ids(self, ids, lens, type_ids=None, mode: int = 0, out=None):
         """ids [B, L] int (numpy or torch, padded), lens [B].  mode = MODE_MEAN / MODE_CLS (| NO_NORMALIZE) -> [B, 384] fp32

@@ -2689,12 +2689,18 @@ struct rmu_bert {
     // small-batch host path (rmu_bert_encode_host): one captured graph per (batch, max_len, mode, token types) shape -- H2D of the
     // ids, the ~45 launches of a forward, D2H of the result -- replayed with ONE hipGraphLaunch.  All addresses inside are
     // the fixed staging buffers below, so a replay needs no node updates.
-    struct SmallGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool warm = false; };
+    struct SmallGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool warm = false; uint64_t last_use = 0; };
     std::map<uint64_t, SmallGraph> graphs;
+    uint64_t graph_clock = 0;                      // bumps per host call: the least recently used graph goes when the cache is full
     int32_t *h_in = nullptr, *d_in = nullptr;      // [ids | type ids | lens], pinned host / device
     float *h_out = nullptr, *d_out = nullptr;
 };
-static constexpr int SMALL_IN_INTS = 2 * 256 + 256, SMALL_OUT_FLOATS = 256 * 384;   // SMALL_M = 256 tokens at most
+// rmu_bert_encode_host / rmu_bert_search_mmr carry up to HOST_TOKENS tokens (batch * max_len): one query, or the <= 14 (query, passage)
+// pairs of one rerank call (server/ScoredCrossEncoderReranker.py:42) -- staging: ids | type ids | lens; results: <= 256 rows of 384
+// floats (pooled vectors / the token states of a 256-token call) or one logit per sequence
+static constexpr int HOST_TOKENS = 4096;
+static constexpr int SMALL_IN_INTS = 3 * HOST_TOKENS, SMALL_OUT_FLOATS = 256 * 384 > HOST_TOKENS ? 256 * 384 : HOST_TOKENS;
+static constexpr size_t MAX_GRAPHS = 64;
 
 extern "C" void rmu_set_error_(const char* msg);   // rmu_api.hip: thread-local message behind rmu_last_error()
 static int bfail(int code, const std::string& m) { rmu_set_error_(m.c_str()); return code; }
@@ -3217,30 +3223,30 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     return RMU_OK;
 }
 
-// The interactive path (embed_query, a handful of passages to rerank: batch * max_len <= 256 tokens) from HOST buffers.  A forward at
-// that size is ~45 launches of 1-3 us of work each: launch-latency-bound.  The first call of a shape runs eagerly, the second
-// captures H2D + launches + D2H into a hipGraph, every later one is ONE hipGraphLaunch + ONE synchronisation.
-extern "C" int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch, int max_len,
-                                    int mode, float* out_host, int64_t out_stride) {
-    int rc = check_encode_args(m, ids, lens, out_host, batch, max_len, mode, out_stride);
-    if (rc) return rc;
+// The interactive path (embed_query, a handful of passages to rerank) from HOST buffers.  A forward at that size is ~45 launches of
+// 1-15 us of work each: launch-latency-bound.  The first call of a shape runs eagerly, the second captures H2D + launches + D2H into a
+// hipGraph, every later one is ONE hipGraphLaunch.  Shapes are (batch, max_len, mode, token types): callers bucket them (the Python
+// binding pads batch and max_len up to a few sizes -- padded sequences have length 0 and cost nothing in the packed-token kernels).
+// The cache holds MAX_GRAPHS shapes, least recently used out.  m->mu is held by the caller; the forward is left IN FLIGHT on
+// m->stream (result in m->d_out, and on its way to m->h_out): the caller synchronises.
+static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch, int max_len, int mode,
+                               const char* who) {
     const int64_t cap = (int64_t)batch * max_len;
-    if (cap > SMALL_M) return bfail(RMU_E_INVALID, "rmu_bert_encode_host: batch * max_len must be <= 256 (use rmu_bert_encode for bulk work)");
-    std::lock_guard<std::mutex> lk(m->mu);
-    rc = ensure_ws(m, cap, batch);
-    if (rc) return bfail(rc, "rmu_bert_encode_host: workspace");
+    const int kind = mode & 0xff;
+    if (cap > HOST_TOKENS) return bfail(RMU_E_INVALID, std::string(who) + ": batch * max_len must be <= 4096 (use rmu_bert_encode for bulk work)");
+    if (kind != RMU_BERT_CE_LOGIT && (kind == RMU_BERT_TOKENS ? cap : (int64_t)batch) > 256)
+        return bfail(RMU_E_INVALID, std::string(who) + ": at most 256 result rows (pooled vectors, or token states of a <= 256-token call)");
+    int rc = ensure_ws(m, cap, batch);
+    if (rc) return bfail(rc, std::string(who) + ": workspace");
     if (!m->h_in) {
         if (hipHostMalloc((void**)&m->h_in, SMALL_IN_INTS * sizeof(int32_t)) != hipSuccess || hipHostMalloc((void**)&m->h_out, SMALL_OUT_FLOATS * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&m->d_in, SMALL_IN_INTS * sizeof(int32_t)) != hipSuccess || hipMalloc((void**)&m->d_out, SMALL_OUT_FLOATS * sizeof(float)) != hipSuccess)
-            return bfail(RMU_E_OOM, "rmu_bert_encode_host: staging buffers");
+            return bfail(RMU_E_OOM, std::string(who) + ": staging buffers");
     }
-    const int kind = mode & 0xff;
     // staging layout: ids [cap] | type ids [cap] | lens [batch]
     memcpy(m->h_in, ids, (size_t)cap * 4);
     if (type_ids) memcpy(m->h_in + cap, type_ids, (size_t)cap * 4);
     memcpy(m->h_in + 2 * cap, lens, (size_t)batch * 4);
-    int64_t n_tok = 0;
-    for (int b = 0; b < batch; ++b) n_tok += std::min(std::max(lens[b], 0), max_len);
     const int64_t rows_out = kind == RMU_BERT_TOKENS ? cap : batch;                       // (the graph copies the shape's upper bound)
     const size_t out_floats = kind == RMU_BERT_CE_LOGIT ? (size_t)batch : (size_t)rows_out * H;
     const size_t in_bytes = (size_t)(2 * cap + batch) * 4;
@@ -3252,7 +3258,17 @@ extern "C" int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int
     };
     static const bool use_graph = !(getenv("RMU_GRAPH") && atoi(getenv("RMU_GRAPH")) == 0);
     const uint64_t key = ((uint64_t)batch << 32) | ((uint64_t)max_len << 16) | ((uint64_t)(mode & 0xfff) << 1) | (type_ids ? 1u : 0u);
+    if (use_graph && !m->graphs.count(key) && m->graphs.size() >= MAX_GRAPHS) {          // full: the least recently used shape goes
+        auto victim = m->graphs.begin();
+        for (auto it = m->graphs.begin(); it != m->graphs.end(); ++it)
+            if (it->second.last_use < victim->second.last_use) victim = it;
+        B_TRY(hipStreamSynchronize(s));                                                   // (a replay of it may still be running)
+        if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
+        if (victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
+        m->graphs.erase(victim);
+    }
     rmu_bert::SmallGraph& g = m->graphs[key];
+    g.last_use = ++m->graph_clock;
     if (use_graph && g.exec) {
         B_TRY(hipGraphLaunch(g.exec, s));
     } else if (use_graph && g.warm) {
@@ -3274,15 +3290,52 @@ extern "C" int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int
         }
     } else {
         enqueue_all();
-        if (use_graph && m->graphs.size() <= 512) g.warm = true;
+        if (use_graph) g.warm = true;
     }
     B_TRY(hipGetLastError());
-    B_TRY(hipStreamSynchronize(s));
+    return RMU_OK;
+}
+
+extern "C" int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch, int max_len,
+                                    int mode, float* out_host, int64_t out_stride) {
+    int rc = check_encode_args(m, ids, lens, out_host, batch, max_len, mode, out_stride);
+    if (rc) return rc;
+    const int kind = mode & 0xff;
+    std::lock_guard<std::mutex> lk(m->mu);
+    rc = host_forward_locked(m, ids, type_ids, lens, batch, max_len, mode, "rmu_bert_encode_host");
+    if (rc) return rc;
+    B_TRY(hipStreamSynchronize(m->stream));
     if (kind == RMU_BERT_CE_LOGIT) {
         memcpy(out_host, m->h_out, (size_t)batch * sizeof(float));
     } else {
+        int64_t n_tok = 0;
+        for (int b = 0; b < batch; ++b) n_tok += std::min(std::max(lens[b], 0), max_len);
         const int64_t rows = kind == RMU_BERT_TOKENS ? n_tok : batch;
         for (int64_t r = 0; r < rows; ++r) memcpy(out_host + r * out_stride, m->h_out + r * H, H * sizeof(float));
     }
+    return RMU_OK;
+}
+
+// The reference's per-request retrieval in ONE call with ONE synchronisation (VectorStoreRetriever.invoke, server/RAGHelper.py:497-499:
+// embed_query -> dense top-fetch_k -> maximal_marginal_relevance): the query's token ids in, row ids out.  The forward is the graph
+// replay above; its pooled vector stays on the device and feeds the search + selection enqueued behind it on the same stream
+// (rmu_api.hip), so the vector's round trip to the host, the second synchronisation and a second host call are gone.
+extern "C" int rmu_index_search_mmr_dev_(rmu_index_t* idx, const float* q_dev, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
+                                         int64_t* out_rows, float* out_scores, void* hip_stream);
+extern "C" int rmu_bert_search_mmr(rmu_bert_t* m, rmu_index_t* idx, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
+                                   int max_len, int mode, int fetch_k, int k, double lambda_mult, int64_t row_base, int64_t* out_rows,
+                                   float* out_scores, float* out_vecs) {
+    if (!idx || !out_rows) return bfail(RMU_E_INVALID, "rmu_bert_search_mmr: null argument");
+    int rc = check_encode_args(m, ids, lens, out_rows, batch, max_len, mode, H);
+    if (rc) return rc;
+    const int kind = mode & 0xff;
+    if (kind != RMU_BERT_POOL_MEAN && kind != RMU_BERT_POOL_CLS) return bfail(RMU_E_INVALID, "rmu_bert_search_mmr: mode must be a pooling mode");
+    std::lock_guard<std::mutex> lk(m->mu);
+    rc = host_forward_locked(m, ids, type_ids, lens, batch, max_len, mode, "rmu_bert_search_mmr");
+    if (rc) return rc;
+    // drains m->stream: forward, search, selection and the copies of the results
+    rc = rmu_index_search_mmr_dev_(idx, m->d_out, batch, fetch_k, k, lambda_mult, row_base, out_rows, out_scores, (void*)m->stream);
+    if (rc) { (void)hipStreamSynchronize(m->stream); return rc; }
+    if (out_vecs) memcpy(out_vecs, m->h_out, (size_t)batch * H * sizeof(float));
     return RMU_OK;
 }

@@ -363,7 +363,7 @@ __global__ void k_take_picks(const int* __restrict__ pos, const int64_t* __restr
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq * k) return;
     const int64_t qi = i / k;
-    const int p = pos[i];
+    const int p = pos ? pos[i] : (int)(i - qi * k);      // pos == nullptr: no selection, the first k candidates in score order
     const int64_t r = p >= 0 ? rows[qi * fetch_k + p] : -1;
     out_rows[i] = r >= 0 ? r + row_base : -1;
     out_scores[i] = p >= 0 ? scores[qi * fetch_k + p] : -INFINITY;
@@ -695,37 +695,63 @@ extern "C" int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const
     return RMU_OK;
 }
 
-extern "C" int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
-                                    int64_t* out_rows, float* out_scores) {
-    if (!idx || !q || !out_rows) return fail(RMU_E_INVALID, "rmu_index_search_mmr: null pointer");
-    if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1 || k > fetch_k)
-        return fail(RMU_E_INVALID, "rmu_index_search_mmr: nq >= 1, fetch_k in [1, 64], k in [1, fetch_k]");
+// dense top-fetch_k + greedy selection of `nq` queries (host or device fp32 [nq, dim]) on stream s; HOST results; drains s.
+// lambda_mult < 0: no selection -- the top-k (k <= fetch_k) in score order, as rmu_index_search returns them.
+static int search_mmr_on(rmu_index_t* idx, const float* q, bool q_dev, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
+                         int64_t* out_rows, float* out_scores, hipStream_t s, const char* who) {
     Tls& t = g_tls;
-    int rc = t.ensure_stream();
-    if (rc) return fail(rc, "rmu_index_search_mmr: stream");
-    hipStream_t s = t.stream;
     const size_t nf = (size_t)nq * fetch_k, nk = (size_t)nq * k;
     // candidate scores / rows, the raw queries (the search normalises its own copy for COSINE), picks, and the results (rows | scores)
     if (t.mm_s.ensure(nf * sizeof(float)) || t.mm_r.ensure(nf * sizeof(int64_t)) || t.mm_q.ensure((size_t)nq * idx->dim * sizeof(float)) ||
         t.mm_p.ensure(nk * (sizeof(int) + sizeof(int64_t) + sizeof(float))))
-        return fail(RMU_E_OOM, "rmu_index_search_mmr: workspace");
-    // the search on this thread's own stream, results left on the device (no synchronisation inside)
-    rc = rmu_index_search(idx, q, nq, fetch_k, RMU_F_OUT_DEVICE, 0, (float*)t.mm_s.p, (int64_t*)t.mm_r.p, (uint64_t)(uintptr_t)s);
+        return fail(RMU_E_OOM, std::string(who) + ": workspace");
+    // the search on the given stream, results left on the device (no synchronisation inside)
+    int rc = rmu_index_search(idx, q, nq, fetch_k, RMU_F_OUT_DEVICE | (q_dev ? RMU_F_Q_DEVICE : 0u), 0, (float*)t.mm_s.p, (int64_t*)t.mm_r.p,
+                              (uint64_t)(uintptr_t)s);
     if (rc) return rc;
     std::shared_lock<std::shared_mutex> lk(idx->mu);
-    HIP_TRY(hipMemcpyAsync(t.mm_q.p, q, (size_t)nq * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    const float* dq = q;
+    if (!q_dev) {
+        HIP_TRY(hipMemcpyAsync(t.mm_q.p, q, (size_t)nq * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+        dq = (const float*)t.mm_q.p;
+    }
     int64_t* d_rows = (int64_t*)t.mm_p.p;
     float* d_sc = (float*)(d_rows + nk);
     int* d_pos = (int*)(d_sc + nk);
-    launch_mmr(idx, (const float*)t.mm_q.p, (const int64_t*)t.mm_r.p, nq, fetch_k, k, lambda_mult, d_pos, s);
-    hipLaunchKernelGGL(k_take_picks, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, (const int*)d_pos, (const int64_t*)t.mm_r.p,
-                       (const float*)t.mm_s.p, nq, fetch_k, k, row_base, d_rows, d_sc);
+    if (lambda_mult >= 0.0) launch_mmr(idx, dq, (const int64_t*)t.mm_r.p, nq, fetch_k, k, lambda_mult, d_pos, s);
+    hipLaunchKernelGGL(k_take_picks, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, lambda_mult >= 0.0 ? (const int*)d_pos : (const int*)nullptr,
+                       (const int64_t*)t.mm_r.p, (const float*)t.mm_s.p, nq, fetch_k, k, row_base, d_rows, d_sc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_rows, d_rows, nk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (out_scores) HIP_TRY(hipMemcpyAsync(out_scores, d_sc, nk * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     t.finished(s, true);
     return RMU_OK;
+}
+
+extern "C" int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
+                                    int64_t* out_rows, float* out_scores) {
+    if (!idx || !q || !out_rows) return fail(RMU_E_INVALID, "rmu_index_search_mmr: null pointer");
+    if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1 || k > fetch_k)
+        return fail(RMU_E_INVALID, "rmu_index_search_mmr: nq >= 1, fetch_k in [1, 64], k in [1, fetch_k]");
+    if (lambda_mult < 0.0) return fail(RMU_E_INVALID, "rmu_index_search_mmr: lambda_mult must be >= 0");
+    Tls& t = g_tls;
+    int rc = t.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_search_mmr: stream");
+    return search_mmr_on(idx, q, false, nq, fetch_k, k, lambda_mult, row_base, out_rows, out_scores, t.stream, "rmu_index_search_mmr");
+}
+
+// bert.hip (rmu_bert_search_mmr): the same behind an encoder forward -- DEVICE queries on the encoder's stream
+extern "C" int rmu_index_search_mmr_dev_(rmu_index_t* idx, const float* q_dev, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
+                                         int64_t* out_rows, float* out_scores, void* hip_stream) {
+    if (!idx || !q_dev || !out_rows || !hip_stream) return fail(RMU_E_INVALID, "rmu_bert_search_mmr: null pointer");
+    if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1 || k > fetch_k)
+        return fail(RMU_E_INVALID, "rmu_bert_search_mmr: nq >= 1, fetch_k in [1, 64], k in [1, fetch_k]");
+    if (idx->dim != 384) return fail(RMU_E_INVALID, "rmu_bert_search_mmr: the index must hold 384-d rows (the encoder's width)");
+    Tls& t = g_tls;
+    int rc = t.ensure_stream((hipStream_t)hip_stream);
+    if (rc) return fail(rc, "rmu_bert_search_mmr: stream");
+    return search_mmr_on(idx, q_dev, true, nq, fetch_k, k, lambda_mult, row_base, out_rows, out_scores, (hipStream_t)hip_stream, "rmu_bert_search_mmr");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -267,6 +267,15 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
     def embed_documents(self, texts: list[str]) -> list[list[float]]:
         return self.embed_documents_array(texts).tolist()
 
+    def query_ids(self, text: str):
+        """(ids [1, L] int32, lens [1]) of one query when it can go through the library's host entry points (native encoder +
+        tokenizer, <= 256 tokens), else None.  What MI355XVectorStore hands to `BertEncoder.search_host`."""
+        enc = getattr(self, "encoder", None)
+        if not isinstance(enc, BertEncoder) or getattr(self, "tokenizer", None) is None:
+            return None
+        ids, lens = self._tokenize([text])
+        return (ids, lens) if ids.shape[1] <= enc.SMALL_TOKENS else None
+
     def _embed_query_fast(self, text: str):
         """One query of up to 256 tokens through the graph-replayed host entry point (rmu_bert_encode_host): the reference's
         per-request pattern (one embed_query per /chat call, server/RAGHelper.py:497-499) is launch-bound.  None when this object
@@ -326,4 +335,13 @@ class MI355XCrossEncoder(_EncoderBase, *CROSS_ENCODER_BASES):
         if not text_pairs:
             return []
         ids, tt, lens = self._tokenize_arrays([p[0] for p in text_pairs], [p[1] for p in text_pairs], want_types=True)
+        enc = self.encoder
+        lens = np.minimum(np.asarray(lens, dtype=np.int32), min(ids.shape[1], self.max_seq_length))
+        Lmax = max(1, int(lens.max()))
+        if isinstance(enc, BertEncoder) and enc.host_shape(ids.shape[0], Lmax, B.MODE_CE) is not None:
+            # the reference's rerank call (<= 14 pairs, ScoredCrossEncoderReranker.py:42): host ids in, host logits out, one graph replay
+            logits = enc.encode_host(ids[:, :Lmax], lens, tt[:, :Lmax], B.MODE_CE).astype(np.float64)
+            if self.activation == "sigmoid":
+                logits = 1.0 / (1.0 + np.exp(-logits))
+            return logits.tolist()
         return self.score_id_arrays(ids, tt, lens).cpu().numpy().astype(np.float64).tolist()

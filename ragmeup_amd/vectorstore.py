@@ -446,7 +446,23 @@ class MI355XVectorStore(VectorStore):
         s, r = self._search_vecs(np.asarray(embedding, dtype=np.float32)[None], k)
         return [(self._doc(int(row)), self._convert(float(sc))) for sc, row in zip(s[0], r[0]) if row >= 0]
 
+    def _fused_query(self, query: str, fetch_k: int, k: int, lambda_mult):
+        """One query through `rmu_bert_search_mmr` (token ids in, rows out: forward, dense top-fetch_k and the selection in ONE library
+        call with one synchronisation) when the Embeddings object and the index are the native ones; None otherwise."""
+        emb, idx = self._embeddings, self._index
+        if (idx is None or not hasattr(idx, "_h") or len(idx) == 0 or not hasattr(emb, "query_ids") or not (1 <= k <= fetch_k <= 64)
+                or idx.dim != 384):
+            return None
+        q = emb.query_ids(query)
+        if q is None:
+            return None
+        rows, scores = emb.encoder.search_host(idx, q[0], q[1], emb._mode, fetch_k, k, lambda_mult)
+        return rows[0], scores[0]
+
     def similarity_search_with_score(self, query: str, k: int = 4, **kw) -> list[tuple[Document, float]]:
+        hit = self._fused_query(query, int(k), int(k), None)
+        if hit is not None:
+            return [(self._doc(int(row)), self._convert(float(sc))) for row, sc in zip(*hit) if row >= 0]
         return self.similarity_search_with_score_by_vector(self._embed_query(query), k, **kw)
 
     def similarity_search(self, query: str, k: int = 4, **kw) -> list[Document]:
@@ -486,6 +502,9 @@ class MI355XVectorStore(VectorStore):
 
     def max_marginal_relevance_search(self, query: str, k: int = 4, fetch_k: int = 20, lambda_mult: float = 0.5,
                                       **kw) -> list[Document]:
+        hit = self._fused_query(query, int(fetch_k), int(k), float(lambda_mult))     # the reference's per-request call (RAGHelper.py:497-499)
+        if hit is not None:
+            return [self._doc(int(x)) for x in hit[0] if x >= 0]
         return self.max_marginal_relevance_search_by_vector(self._embed_query(query), k, fetch_k, lambda_mult)
 
     def max_marginal_relevance_search_batch(self, queries: list[str], k: int = 4, fetch_k: int = 20,

@@ -307,7 +307,68 @@ def test_host_entry_point_replays_a_graph_and_matches_the_device_path(bi, cross)
     for rep in range(3):
         assert np.array_equal(ce.encode_host(ids, lens, tt, mode=1), ce.encode_ids(ids, lens, tt, mode=1).cpu().numpy())
     with pytest.raises(Exception):
-        enc.encode_host(np.zeros((2, 200), np.int32), np.array([200, 200], np.int32))          # 400 tokens: not the small path
+        enc.encode_host(np.zeros((40, 128), np.int32), np.full(40, 128, np.int32))             # 5120 tokens: beyond the host entry point
+
+
+def test_rerank_sized_host_call_equals_the_device_path_and_the_graph_cache_evicts(cross):
+    """The reference's rerank call (<= 14 (query, passage) pairs, ~1.5k tokens; ScoredCrossEncoderReranker.py:42) through the host
+    entry point: bucketed shape (14 -> 16 sequences, max_len -> a multiple of 32), graph-replayed from the third call on, logits equal
+    to rmu_bert_encode on the same ids bit for bit.  Then more shapes than the cache holds (64): the least recently used graphs are
+    dropped and every shape still answers correctly when it comes back."""
+    ce, _ = cross
+    ids, tt, lens = synth_tokens(14, seed=12, lmin=60, lmax=170, mean=110, std=25, pair=True)
+    want = ce.encode_ids(ids, lens, tt, mode=1).cpu().numpy()
+    assert ce.host_shape(14, ids.shape[1], 1) == (16, -(-ids.shape[1] // 32) * 32)
+    for rep in range(4):
+        assert np.array_equal(ce.encode_host(ids, lens, tt, mode=1), want), rep
+    rng = np.random.default_rng(8)
+    shapes = [(b, L) for b in (1, 2, 3, 5, 7, 9) for L in (20, 40, 70, 100, 130, 160, 190, 220, 250, 300, 330, 370)]      # 72 bucketed shapes
+    ref = {}
+    for rnd in range(2):
+        for b, L in shapes:
+            i2, t2, l2 = synth_tokens(b, seed=100 + b * 1000 + L, lmin=max(8, L - 15), lmax=L, mean=L - 5, std=4, pair=True)
+            got = ce.encode_host(i2, l2, t2, mode=1)
+            if rnd == 0:
+                # the same BUCKETED shape through the device entry point (which kernels serve a call depends on batch * max_len:
+                # include/rmu.h; across size classes results agree to bf16 noise, inside one bit for bit)
+                pi, pl, pt, nb, _, _ = ce._host_arrays(i2, l2, t2, 1)
+                ref[(b, L)] = ce.encode_ids(pi, pl, pt, mode=1).cpu().numpy()[:nb]
+                loose = ce.encode_ids(i2, l2, t2, mode=1).cpu().numpy()
+                assert np.abs(got - loose).max() <= 8e-3 * (1 + np.abs(loose).max())
+            assert np.array_equal(got, ref[(b, L)]), (rnd, b, L)
+    assert np.array_equal(ce.encode_host(ids, lens, tt, mode=1), want)
+
+
+def test_fused_query_call_equals_embed_then_search(bi):
+    """rmu_bert_search_mmr (the reference's per-request retrieval as one call, RAGHelper.py:497-499): token ids in, rows out -- must
+    equal rmu_bert_encode_host followed by rmu_index_search_mmr / rmu_index_search on the vector it returns, rows AND scores, for
+    both pooling heads, several query lengths, MMR and plain top-k, cosine and inner-product indexes, a row_base, and a batch of 3."""
+    from ragmeup_amd import FlatIndex, _native
+    enc, _ = bi
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((6000, 384)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x[100:140] = x[100] + 0.01 * rng.standard_normal((40, 384)).astype(np.float32)          # a cluster: MMR has something to diversify
+    for metric in (_native.METRIC_IP, _native.METRIC_COSINE):
+        idx = FlatIndex(384, metric)
+        idx.add(x)
+        for n, L in ((1, 9), (1, 16), (1, 47), (3, 30)):
+            lens = rng.integers(4, L + 1, n).astype(np.int32); lens[0] = L
+            ids = rng.integers(1000, 30522, (n, L)).astype(np.int32)
+            ids[:, 0] = 101
+            ids[np.arange(n), lens - 1] = 102
+            for mode in (0, 2):
+                for rep in range(3):                                                # eager, capture, replay
+                    v = enc.encode_host(ids, lens, None, mode=mode)
+                    r_want, s_want = idx.search_mmr(v, 20, 10, 0.5, row_base=7)
+                    r_got, s_got, v_got = enc.search_host(idx, ids, lens, mode, 20, 10, 0.5, row_base=7, want_vectors=True)
+                    assert np.array_equal(v_got, v) and np.array_equal(r_got, r_want) and np.array_equal(s_got, s_want), (metric, n, L, mode, rep)
+                s_top, r_top = idx.search(v, 10)
+                r2, s2 = enc.search_host(idx, ids, lens, mode, 10, 10, None)
+                assert np.array_equal(r2, r_top) and np.array_equal(s2, s_top)
+        idx.close()
+    with pytest.raises(Exception):
+        enc.search_host(FlatIndex(128), np.zeros((1, 8), np.int32), np.array([8], np.int32), 0, 5, 5, 0.5)       # not the encoder's width
 
 
 def test_embed_query_takes_the_host_path_and_equals_embed_documents(bi, tmp_path):
@@ -324,3 +385,39 @@ def test_embed_query_takes_the_host_path_and_equals_embed_documents(bi, tmp_path
             qv = np.asarray(emb.embed_query(t), np.float32)
             assert np.abs(qv - docs[i]).max() < 2e-3 and float((qv * docs[i]).sum()) > 0.9999    # batch of 6 vs batch of 1: bf16 noise only
             assert np.array_equal(qv, emb.embed_query_array(t))
+
+
+def test_store_queries_take_the_fused_call_and_equal_the_two_step_path(bi, tmp_path):
+    """MI355XVectorStore: retriever.invoke (search_type="mmr") and similarity_search_with_score go through rmu_bert_search_mmr when the
+    Embeddings object and the index are the native ones; documents and scores equal embed_query + search on the vector."""
+    from ragmeup_amd.documents import Document
+    from ragmeup_amd.embeddings import MI355XEmbeddings
+    from ragmeup_amd.tokenizer import WordPieceTokenizer
+    from ragmeup_amd.vectorstore import MI355XVectorStore
+    from tests.helpers import synth_texts, synth_vocab
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(synth_vocab()) + "\n", encoding="utf-8")
+    emb = MI355XEmbeddings(encoder=bi[0], tokenizer=WordPieceTokenizer(str(vp)), max_seq_length=256)
+    texts = synth_texts(400, seed=5, wmin=20, wmax=60)
+    store = MI355XVectorStore(embeddings=emb, collection_name="fused", auto_persist=False)
+    store.add_documents([Document(t, {"source": "s", "id": str(i)}) for i, t in enumerate(texts)], ids=[str(i) for i in range(len(texts))])
+    calls = []
+    real = bi[0].search_host
+    bi[0].search_host = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        retr = store.as_retriever(search_type="mmr", search_kwargs={"k": 10})
+        for q in synth_texts(5, seed=6, wmin=5, wmax=14):
+            for rep in range(3):
+                got = [d.page_content for d in retr.invoke(q)]
+                want = [d.page_content for d in store.max_marginal_relevance_search_by_vector(emb.embed_query_array(q), 10, 20, 0.5)]
+                assert got == want and len(got) == 10
+                g2 = store.similarity_search_with_score(q, k=5)
+                w2 = store.similarity_search_with_score_by_vector(emb.embed_query_array(q), 5)
+                assert [(d.page_content, s) for d, s in g2] == [(d.page_content, s) for d, s in w2]
+        assert len(calls) == 5 * 3 * 2
+        # fetch_k > 64: not the fused call's range -> the two-step path, still correct
+        n0 = len(calls)
+        assert len(store.max_marginal_relevance_search(texts[3], k=10, fetch_k=100)) == 10 and len(calls) == n0
+    finally:
+        bi[0].search_host = real
+        store._index.close()
