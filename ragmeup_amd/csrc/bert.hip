@@ -500,12 +500,24 @@ constexpr int SMALL_M = 256;                           // tokens (upper bound ba
 // Round 4: the token dimension is a grid dimension too -- workgroup (x, y) takes features [32 x, +32) of tokens [SMALL_TB y, +SMALL_TB)
 // -- so the same kernel serves a few THOUSAND tokens (the reference's rerank call: <= 14 (query, passage) pairs, ~1.5k tokens,
 // twice per /chat request): the tiled kernels run 6-36 workgroups there (10-17 us per launch), this one N/32 x M/128 short ones.
-template <int EPI, int K>
+// LayerNorm folded into its consumers (round 4; one query per call is ~45 launches of ~4.4 us each: the two k_layernorm launches of
+// a layer are 12 of them).  A pre-LN sum y [M, 384] stays what it is in memory and
+//   * LNA: a GEMM whose A operand is LN(y) normalises its token fragments on the way in -- the two-pass statistics of k_layernorm
+//     (fp32 mean, then variance about it) over the four waves' K quarters through LDS, the same rounding point (bf16 of the
+//     normalised value) -- and workgroup x = 0 leaves (mean, rstd) per token in `stats_out`;
+//   * LNR: a GEMM whose RESIDUAL is LN(y) rebuilds it in the epilogue from y and those statistics (the launch that wrote them is
+//     always an earlier one on the stream: FFN1 -> FFN2, next layer's QKV -> its out-proj).
+template <int EPI, int K, bool LNA = false, bool LNR = false>
 __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
                                                     const bf16* __restrict__ resid, bf16* __restrict__ out, const int* __restrict__ cu,
-                                                    int batch, int N, int SMALL_TB /* tokens per workgroup along grid.y, a multiple of 32 */) {
+                                                    int batch, int N, int SMALL_TB /* tokens per workgroup along grid.y, a multiple of 32 */,
+                                                    const float* __restrict__ lng = nullptr, const float* __restrict__ lnb = nullptr, float eps = 0.f,
+                                                    float2* __restrict__ stats_out = nullptr, const float* __restrict__ rg = nullptr,
+                                                    const float* __restrict__ rb = nullptr, const float2* __restrict__ rstats = nullptr) {
+    static_assert(!LNA || K == H, "the normalised operand is a hidden-state row");
     constexpr int KW = K / 4, NF = KW / 16;
     __shared__ float red[4][32][36];                   // [K quarter][token][feature (+4 pad)]
+    __shared__ float lnp[2][4][32];                    // LNA: [sum | squared deviations][K quarter][token]
     const int M = cu[batch];
     const int tb0 = blockIdx.y * SMALL_TB;
     if (tb0 >= M) return;                              // (the grid is sized by the shape's upper bound batch * max_len)
@@ -519,14 +531,52 @@ __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, 
 #pragma unroll
         for (int f = 0; f < NF; ++f) wf[f] = *(const bf16x8*)(wr + f * 16);
     }
+    float lg[LNA ? NF : 1][8], lb[LNA ? NF : 1][8];    // LNA: gamma / beta of this lane's k positions (k = w KW + 16 f + 8 hh + e)
+    if constexpr (LNA) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int k0 = w * KW + f * 16 + hh * 8;
+            const f32x4 g0 = *(const f32x4*)(lng + k0), g1 = *(const f32x4*)(lng + k0 + 4);
+            const f32x4 b0 = *(const f32x4*)(lnb + k0), b1 = *(const f32x4*)(lnb + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lg[f][e] = g0[e]; lg[f][4 + e] = g1[e]; lb[f][e] = b0[e]; lb[f][4 + e] = b1[e]; }
+        }
+    }
     const int et = threadIdx.x >> 3, ef = (threadIdx.x & 7) * 4;       // epilogue: token et, features ef .. ef + 3
     const f32x4 bv = *(const f32x4*)(bias + n0 + ef);
+    f32x4 rgv = {}, rbv = {};
+    if constexpr (LNR) { rgv = *(const f32x4*)(rg + n0 + ef); rbv = *(const f32x4*)(rb + n0 + ef); }
     for (int t0 = tb0; t0 < tb1; t0 += 32) {
         const int tok = min(t0 + r31, M - 1);
         const bf16* xr = A + (int64_t)tok * K + w * KW + hh * 8;
         bf16x8 xf[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) xf[f] = *(const bf16x8*)(xr + f * 16);
+        if constexpr (LNA) {
+            float v[NF][8], sm = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[f][e] = bf2f(xf[f][e]); sm += v[f][e]; }
+            sm += __shfl_xor(sm, 32);
+            if (hh == 0) lnp[0][w][r31] = sm;
+            __syncthreads();
+            const float mu = ((lnp[0][0][r31] + lnp[0][1][r31]) + (lnp[0][2][r31] + lnp[0][3][r31])) * (1.0f / H);
+            float qv = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[f][e] - mu; qv = fmaf(d, d, qv); }
+            qv += __shfl_xor(qv, 32);
+            if (hh == 0) lnp[1][w][r31] = qv;
+            __syncthreads();
+            const float rs = rsqrtf(((lnp[1][0][r31] + lnp[1][1][r31]) + (lnp[1][2][r31] + lnp[1][3][r31])) * (1.0f / H) + eps);
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xf[f][e] = (bf16)((v[f][e] - mu) * rs * lg[f][e] + lb[f][e]);
+            if (stats_out && blockIdx.x == 0 && w == 0 && hh == 0 && t0 + r31 < M) stats_out[t0 + r31] = float2{mu, rs};
+        }
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -548,7 +598,12 @@ __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, 
             for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
             const int64_t off = (int64_t)m * N + n0 + ef;
             if (EPI == EPI_RESID) {
-                const bf16x4 rv = *(const bf16x4*)(resid + off);
+                bf16x4 rv = *(const bf16x4*)(resid + off);
+                if constexpr (LNR) {                   // the residual is LN(resid row): (mean, rstd) from the launch that normalised it as ITS operand
+                    const float2 st = rstats[m];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[e] = (bf16)((bf2f(rv[e]) - st.x) * st.y * rgv[e] + rbv[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)(bf2f(o[e]) + bf2f(rv[e]));
             }
@@ -2684,6 +2739,7 @@ struct rmu_bert {
     int64_t ws_tokens = 0;
     int ws_batch = 0;
     bf16 *h = nullptr, *h1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr;
+    float2 *st1 = nullptr, *st2 = nullptr;        // (mean, rstd) per token of the two LayerNorms folded into their consumers (small path)
     int* cu = nullptr;
     hipStream_t stream = nullptr;
     // small-batch host path (rmu_bert_encode_host): one captured graph per (batch, max_len, mode, token types) shape -- H2D of the
@@ -2735,7 +2791,7 @@ extern "C" int rmu_bert_free(rmu_bert_t* m) {
     if (!m) return RMU_OK;
     (void)hipDeviceSynchronize();
     for (void* p : m->owned) (void)hipFree(p);
-    for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->cu})
+    for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->cu, (void*)m->st1, (void*)m->st2})
         if (p) (void)hipFree(p);
     for (auto& kv : m->graphs) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -2850,14 +2906,17 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
     if (tokens > m->ws_tokens || batch + 1 > m->ws_batch) drop_graphs(m);
     if (tokens > m->ws_tokens) {
         (void)hipDeviceSynchronize();
-        for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid})
+        for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->st1, (void*)m->st2})
             if (p) (void)hipFree(p);
         m->h = m->h1 = m->y = m->qkv = m->ctx = m->mid = nullptr;
+        m->st1 = m->st2 = nullptr;
         m->ws_tokens = 0;
         const int64_t t = tokens + tokens / 8 + 512;       // (+ a whole 256-token tile: the tiled out-proj operand is read in full blocks)
         if (hipMalloc((void**)&m->h, t * H * 2) != hipSuccess || hipMalloc((void**)&m->h1, t * H * 2) != hipSuccess ||
             hipMalloc((void**)&m->y, t * H * 2) != hipSuccess || hipMalloc((void**)&m->qkv, t * 3 * H * 2) != hipSuccess ||
-            hipMalloc((void**)&m->ctx, t * H * 2) != hipSuccess || hipMalloc((void**)&m->mid, t * FF * 2) != hipSuccess)
+            hipMalloc((void**)&m->ctx, t * H * 2) != hipSuccess || hipMalloc((void**)&m->mid, t * FF * 2) != hipSuccess ||
+            hipMalloc((void**)&m->st1, (size_t)std::min<int64_t>(t, SMALL_M + 64) * sizeof(float2)) != hipSuccess ||
+            hipMalloc((void**)&m->st2, (size_t)std::min<int64_t>(t, SMALL_M + 64) * sizeof(float2)) != hipSuccess)
             return RMU_E_OOM;
         m->ws_tokens = t;
     }
@@ -2889,22 +2948,37 @@ static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, con
 #endif
     hipLaunchKernelGGL((k_gemm<EPI, WM, BK, ST, TA>), grid, dim3(128 * WM), lds, s, A, W, bias, resid, out, cu, batch, N, K, dbg | (resid_tiled ? 256 : 0));
 }
-// tokens (batch * max_len) up to which all four GEMMs of a layer take k_gemm_small (features AND token blocks spread over the chip)
+// Tokens (batch * max_len) up to which all four GEMMs of a layer take k_gemm_small, and from which the QKV projection takes the
+// persistent k_gemm3.  Round 4 measured the rerank shape (14 pairs, ~1.5k tokens, tools/ce_probe.py) with k_gemm_small over token blocks
+// of 32 / 64 / 128 up to 4k-64k tokens and with deeper / smaller tiled configurations (128x128 x 3-4 stages, 64x128 x 4-6): nothing beat
+// the round-3 choice (0.48-0.50 ms per call either way; every launch there is 5-15 us of latency, not of work), so the thresholds stay.
+// Debug builds keep the switches: RMU_MID_TOKENS, RMU_SMALL_TB, RMU_GEMM_CFG (+ RMU_GEMM_CFG_MAX), RMU_G3_MIN.
 static int64_t mid_tokens() {
-    const int64_t v = getenv("RMU_MID_TOKENS") ? atoll(getenv("RMU_MID_TOKENS")) : 256;   // (read per launch while the threshold is being tuned)
+#ifdef RMU_DEBUG_KERNELS
+    const int64_t v = getenv("RMU_MID_TOKENS") ? atoll(getenv("RMU_MID_TOKENS")) : SMALL_M;
     return v < SMALL_M ? SMALL_M : v;
+#else
+    return SMALL_M;
+#endif
 }
-// tokens from which the QKV projection takes the persistent k_gemm3 (below: launch_gemm's choice)
 static int64_t g3_min_tokens() {
+#ifdef RMU_DEBUG_KERNELS
     const int64_t v = getenv("RMU_G3_MIN") ? atoll(getenv("RMU_G3_MIN")) : 0;
     return v > mid_tokens() ? v : mid_tokens();
+#else
+    return SMALL_M;
+#endif
 }
 template <int EPI>
 static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
                         int batch, int64_t m_cap, int N, int K, hipStream_t s) {
     static const bool small_ok = !(getenv("RMU_GEMM_SMALL") && atoi(getenv("RMU_GEMM_SMALL")) == 0);
     if (small_ok && m_cap <= mid_tokens() && (K == H || K == FF)) {
-        const int tb = getenv("RMU_SMALL_TB") ? atoi(getenv("RMU_SMALL_TB")) / 32 * 32 : 32;   // (read per launch while being tuned)
+#ifdef RMU_DEBUG_KERNELS
+        const int tb = getenv("RMU_SMALL_TB") ? atoi(getenv("RMU_SMALL_TB")) / 32 * 32 : 128;
+#else
+        const int tb = 128;
+#endif
         const dim3 grid((unsigned)(N / 32), (unsigned)((m_cap + tb - 1) / tb));
         if (K == H) hipLaunchKernelGGL((k_gemm_small<EPI, H>), grid, dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N, tb);
         else hipLaunchKernelGGL((k_gemm_small<EPI, FF>), grid, dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N, tb);
@@ -2913,7 +2987,8 @@ static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const b
     // few tiles (latency-bound: every workgroup walks K alone): 128 x 128 tiles in 64-k stages halve the stage count and double
     // the workgroups -- 4k tokens 0.70 -> 0.60 ms per forward, 16k tokens 1.12 -> 1.07; big batches keep 256 x 128 / 32-k stages
     // (best of the seven tile / stage / ring combinations measured in round 2)
-    {   // (A/B while the mid-size shapes are being tuned: RMU_GEMM_CFG = 1: 128x128 / 3 stages, 2: 128x128 / 4, 3: 64x128 / 4, 4: 64x128 / 6)
+#ifdef RMU_DEBUG_KERNELS
+    {   // (A/B of the mid-size shapes, measured and not adopted: RMU_GEMM_CFG = 1: 128x128 / 3 stages, 2: 128x128 / 4, 3: 64x128 / 4, 4: 64x128 / 6)
         const int cfgv = getenv("RMU_GEMM_CFG") ? atoi(getenv("RMU_GEMM_CFG")) : 0;
         const int64_t lim = getenv("RMU_GEMM_CFG_MAX") ? atoll(getenv("RMU_GEMM_CFG_MAX")) : 8192;
         if (cfgv && m_cap <= lim) {
@@ -2923,6 +2998,7 @@ static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const b
             if (cfgv == 4) return launch_gemm_cfg<EPI, 1, 64, 6>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
         }
     }
+#endif
     if (m_cap <= 32768) return launch_gemm_cfg<EPI, 2, 64, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
     return launch_gemm_cfg<EPI, 4, 32, 2>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
 }
@@ -3107,6 +3183,34 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     const dim3 at_grid(NH, (unsigned)batch);   // k_attention: one workgroup per (head, sequence); k_attn3: one per sequence
     size_t li = 0;
     bool h_in_tiled = false;                   // m->h as this layer reads it: row-major from k_embed_ln, tiled from a k_ffn3 that was told so
+    // ---- the interactive sizes (<= 256 tokens: one query, two short pairs): five launches per layer instead of seven -- both LayerNorms
+    // are folded into the k_gemm_small launches that consume them (see there): y1 = out-proj + residual lives in m->y, y2 = FFN2 +
+    // residual in m->h1, neither is ever normalised in memory; one k_layernorm after the last layer feeds the pooling heads.
+    static const bool small_ok_f = !(getenv("RMU_GEMM_SMALL") && atoi(getenv("RMU_GEMM_SMALL")) == 0);
+    static const bool ln_fuse = !(getenv("RMU_LN_FUSE") && atoi(getenv("RMU_LN_FUSE")) == 0);
+    if (cap <= SMALL_M && small_ok_f && ln_fuse) {
+        const dim3 gq((unsigned)(3 * H / 32), (unsigned)((cap + 127) / 128)), gh((unsigned)(H / 32), (unsigned)((cap + 127) / 128)),
+            gf((unsigned)(FF / 32), (unsigned)((cap + 127) / 128));
+        const int* cu = m->cu;
+        bf16 *y1 = m->y, *y2 = m->h1;
+        const BertLayer* prev = nullptr;
+        for (const BertLayer& L : m->layers) {
+            if (!prev) hipLaunchKernelGGL((k_gemm_small<EPI_BIAS, H>), gq, dim3(256), 0, s, (const bf16*)m->h, L.wqkv, L.bqkv, (const bf16*)nullptr, m->qkv, cu, batch, 3 * H, 128);
+            else hipLaunchKernelGGL((k_gemm_small<EPI_BIAS, H, true>), gq, dim3(256), 0, s, (const bf16*)y2, L.wqkv, L.bqkv, (const bf16*)nullptr, m->qkv, cu, batch, 3 * H, 128,
+                                    (const float*)prev->ln2g, (const float*)prev->ln2b, eps, m->st2);
+            if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
+            else launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
+            if (!prev) hipLaunchKernelGGL((k_gemm_small<EPI_RESID, H>), gh, dim3(256), 0, s, (const bf16*)m->ctx, L.wo, L.bo, (const bf16*)m->h, y1, cu, batch, H, 128);
+            else hipLaunchKernelGGL((k_gemm_small<EPI_RESID, H, false, true>), gh, dim3(256), 0, s, (const bf16*)m->ctx, L.wo, L.bo, (const bf16*)y2, y1, cu, batch, H, 128,
+                                    (const float*)nullptr, (const float*)nullptr, eps, (float2*)nullptr, (const float*)prev->ln2g, (const float*)prev->ln2b, (const float2*)m->st2);
+            hipLaunchKernelGGL((k_gemm_small<EPI_GELU, H, true>), gf, dim3(256), 0, s, (const bf16*)y1, L.w1, L.b1, (const bf16*)nullptr, m->mid, cu, batch, FF, 128,
+                               (const float*)L.ln1g, (const float*)L.ln1b, eps, m->st1);
+            hipLaunchKernelGGL((k_gemm_small<EPI_RESID, FF, false, true>), gh, dim3(256), 0, s, (const bf16*)m->mid, L.w2, L.b2, (const bf16*)y1, y2, cu, batch, H, 128,
+                               (const float*)nullptr, (const float*)nullptr, eps, (float2*)nullptr, (const float*)L.ln1g, (const float*)L.ln1b, (const float2*)m->st1);
+            prev = &L;
+        }
+        if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);
+    } else
     for (const BertLayer& L : m->layers) {
         ++li;
         static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)

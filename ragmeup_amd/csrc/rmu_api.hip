@@ -293,17 +293,23 @@ __global__ __launch_bounds__(256) void k_mmr(const float* __restrict__ x, int dp
     for (int t = want + lane; t < k; t += 64) out_pos[qi * k + t] = -1;
 }
 
-// The same selection for ONE query per workgroup with the candidates staged in LDS: k_mmr's lane walks its own row in global memory
-// one float at a time (a dependent load per fp64 fma: 0.32 ms for the reference's per-request call, 20 candidates, 10 picks); here
-// all 256 threads first copy the <= 64 rows (coalesced) into LDS rows of dim + 1 floats (odd stride: lane i's column c sits in bank
-// (i + c) % 64), then wave 0 runs k_mmr's arithmetic unchanged -- the same fp64 fma chain in the same order, so the picks are
-// bit-identical to k_mmr's.  dim <= 384 (98.6 KiB).
+// The same selection for ONE query per workgroup with the candidates staged in LDS and their GRAM MATRIX computed up front by all 256
+// threads (round 4).  k_mmr's lane walks its own row in global memory one float at a time (a dependent load per fp64 fma: 0.32 ms for
+// the reference's per-request call, 20 candidates, 10 picks); round 3 staged the rows in LDS and ran the unchanged chain on wave 0 --
+// still one 384-step fp64 chain per pick and lane, 58 us.  Every cosine the greedy loop can ask for is an entry of G = X X^T, so:
+//   1. all threads copy the <= 64 rows (coalesced) into LDS rows of dim + 1 floats (odd stride: conflict-free column walks) and q;
+//   2. one task per thread: G[i][j] for i <= j, q . x_i, q . q -- fp64 fma over the dims, FOUR interleaved partial chains
+//      ((s0 + s1) + (s2 + s3): the chain length, not the issue rate, bounded the old kernel); 231 tasks for 20 candidates = one round;
+//   3. wave 0 runs the greedy loop on look-ups: cos(x_i, x_sel) = G[i][sel] / (|x_i| |x_sel|).
+// Same rule and tie order as k_mmr (langchain's); the fp64 sums differ from k_mmr's in the last bits only (summation order).
+// dim <= 384: 98.6 KiB of rows + 32.5 KiB of G.
 __global__ __launch_bounds__(256) void k_mmr_lds(const float* __restrict__ x, int dpad, int dim, int64_t n_rows,
                                                  const float* __restrict__ q, const int64_t* __restrict__ rows, int64_t nq,
                                                  int fetch_k, int k, double lambda, int* __restrict__ out_pos) {
     extern __shared__ __attribute__((aligned(16))) float mm[];
     const int ld = dim + 1;
     float* qs = mm + 64 * ld;
+    double* G = (double*)(mm + 64 * 385 + 384);               // [65][64]: rows 0..63 = X X^T (upper triangle), row 64 = q . x_j; then q . q
     const int64_t qi = blockIdx.x;
     for (int i = threadIdx.x; i < fetch_k * dim; i += 256) {
         const int r = i / dim, c = i - r * dim;
@@ -312,21 +318,41 @@ __global__ __launch_bounds__(256) void k_mmr_lds(const float* __restrict__ x, in
     }
     for (int c = threadIdx.x; c < dim; c += 256) qs[c] = q[qi * dim + c];
     __syncthreads();
+    const int n = fetch_k;
+    const int n_tri = n * (n + 1) / 2, n_tasks = n_tri + n + 1;
+    for (int p = threadIdx.x; p < n_tasks; p += 256) {
+        const float *a, *b;
+        double* dst;
+        if (p < n_tri) {
+            int i = 0, rem = p;
+            while (rem >= n - i) { rem -= n - i; ++i; }
+            const int j = i + rem;
+            a = mm + i * ld; b = mm + j * ld; dst = G + i * 64 + j;
+        } else if (p < n_tri + n) {
+            const int j = p - n_tri;
+            a = qs; b = mm + j * ld; dst = G + 64 * 64 + j;
+        } else {
+            a = qs; b = qs; dst = G + 65 * 64;
+        }
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = 0;
+        for (; c + 4 <= dim; c += 4) {
+            s0 = fma((double)a[c], (double)b[c], s0);
+            s1 = fma((double)a[c + 1], (double)b[c + 1], s1);
+            s2 = fma((double)a[c + 2], (double)b[c + 2], s2);
+            s3 = fma((double)a[c + 3], (double)b[c + 3], s3);
+        }
+        for (; c < dim; ++c) s0 = fma((double)a[c], (double)b[c], s0);
+        *dst = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     const int64_t row = lane < fetch_k ? rows[qi * fetch_k + lane] : -1;
     const bool valid = row >= 0 && row < n_rows;
-    const float* xr = mm + (lane < fetch_k ? lane : 0) * ld;
-    double dq = 0.0, nx = 0.0, nqq = 0.0;
-#pragma unroll 16
-    for (int c = 0; c < dim; ++c) {                            // (unrolled: the LDS reads of 16 steps go out ahead of the fma chain)
-        const double a = (double)xr[c], b = (double)qs[c];
-        dq = fma(a, b, dq);
-        nx = fma(a, a, nx);
-        nqq = fma(b, b, nqq);
-    }
-    nx = sqrt(nx); nqq = sqrt(nqq);
-    double sim_q = dq / (nx * nqq);
+    const int li = lane < fetch_k ? lane : 0;
+    const double nx = sqrt(G[li * 64 + li]), nqq = sqrt(G[65 * 64]);
+    double sim_q = G[64 * 64 + li] / (nx * nqq);
     if (!(sim_q == sim_q) || isinf(sim_q)) sim_q = 0.0;
     const int n_valid = __builtin_popcountll(__ballot(valid));
     const int want = k < n_valid ? k : n_valid;
@@ -345,10 +371,7 @@ __global__ __launch_bounds__(256) void k_mmr_lds(const float* __restrict__ x, in
         if (lane == sel) picked = true;
         if (t + 1 == want) break;
         const double ns = __shfl(nx, sel);
-        const float* xs = mm + sel * ld;                       // uniform address: an LDS broadcast
-        double d = 0.0;
-#pragma unroll 16
-        for (int c = 0; c < dim; ++c) d = fma((double)xr[c], (double)xs[c], d);
+        const double d = li <= sel ? G[li * 64 + sel] : G[sel * 64 + li];
         double cs = d / (nx * ns);
         if (!(cs == cs) || isinf(cs)) cs = 0.0;
         red = fmax(red, cs);
@@ -653,8 +676,10 @@ static void launch_mmr(const rmu_index* idx, const float* dq, const int64_t* dr,
                        hipStream_t s) {
     static const bool lds_off = getenv("RMU_MMR_LDS") && atoi(getenv("RMU_MMR_LDS")) == 0;
     if (idx->dim <= 384 && nq <= 65535 && !lds_off) {          // one workgroup per query, candidates staged in LDS (bit-identical picks)
-        const size_t lds = (size_t)(64 * (idx->dim + 1) + idx->dim) * sizeof(float);
-        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_mmr_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (64 * 385 + 384) * 4);
+        // rows [64][dim + 1] + q [dim] at the head of a (64 * 385 + 384)-float area, then the fp64 Gram block [65][64] + 1
+        const size_t lds = (size_t)(64 * 385 + 384) * sizeof(float) + (size_t)(65 * 64 + 1) * sizeof(double);
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_mmr_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                              (64 * 385 + 384) * 4 + (65 * 64 + 1) * 8);
         (void)attr_rc;
         hipLaunchKernelGGL(k_mmr_lds, dim3((unsigned)nq), dim3(256), lds, s, idx->x, idx->dpad, idx->dim, idx->n, dq, dr, nq, fetch_k, k, lambda_mult, dout);
     } else {

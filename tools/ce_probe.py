@@ -17,7 +17,7 @@ for n in pairs:
         # "MID[:TB[:CFG[:G3MIN]]]"
         f = mid.split(":")
         os.environ["RMU_MID_TOKENS"] = f[0]
-        os.environ["RMU_SMALL_TB"] = f[1] if len(f) > 1 else "128"
+        os.environ["RMU_SMALL_TB"] = f[1] if len(f) > 1 else "128"   # (debug builds only)
         os.environ["RMU_GEMM_CFG"] = f[2] if len(f) > 2 else "0"
         os.environ["RMU_G3_MIN"] = f[3] if len(f) > 3 else "0"
         out = ce.encode_ids(a[0], a[1], a[2], mode=1)
