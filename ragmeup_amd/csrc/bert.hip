@@ -2606,6 +2606,218 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_attn4 -- k_attn3 made PERSISTENT (round 4).  k_attn3 starts one workgroup per (sequence, head): 98k of them for 8192 chunks, each
+// paying a cold global round trip for its K / V / Q pieces before the first MFMA -- by the round-3 ablation 0.45 of its 0.82 ms per
+// layer is that start-up, not arithmetic.  Here a workgroup walks a list of (sequence, head) items (item it -> XCD it & 7, as the
+// grid map of k_attn3: the heads of a sequence stay on one XCD) and the NEXT item's K / V pieces and Q fragments are requested
+// before the current item's MFMAs begin, landing in registers while it computes; they go into the (single) LDS image after the
+// barrier that ends the current item.  Same arithmetic, same LDS layouts, same output as k_attn3 bit for bit.
+// ------------------------------------------------------------------------------------------------------------
+template <int KT, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_attn4(const bf16* __restrict__ qkv, const int* __restrict__ cu, int batch, bf16* __restrict__ ctx, int ctx_tiled, long hm_stride) {
+    constexpr int LP = KT * 32;
+    constexpr int VSTR = LP * 2 + 16;
+    constexpr int KBYTES = LP * 64;
+    constexpr int NR = KT / 4;                     // staging rounds of 512 sixteen-byte pieces (two per thread for K, two for V)
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    char* ks = gsm;
+    char* vt = gsm + KBYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c31 = lane & 31, hh = lane >> 5;
+    const int n_items = (batch + 7) / 8 * 8 * NH;
+    const int64_t rs = hm_stride > 0 ? DH : 3 * H;
+    const int64_t koff = hm_stride > 0 ? (int64_t)NH * hm_stride * DH : H, voff = 2 * koff;
+    struct Item { int t0, L, nkt, head; const bf16* base; bool ok; };
+    auto item = [&](int it) -> Item {
+        Item c{0, 0, 0, 0, qkv, false};
+        if (it >= n_items) return c;
+        const int xcd = it & 7, idx = it >> 3;
+        const int b = (idx / NH) * 8 + xcd;
+        c.head = idx % NH;
+        if (b >= batch) return c;
+        c.t0 = cu[b];
+        c.L = cu[b + 1] - c.t0;
+        if (c.L <= 0) return c;
+        c.nkt = (c.L + 31) >> 5;
+        c.base = hm_stride > 0 ? qkv + ((int64_t)c.head * hm_stride + c.t0) * DH : qkv + (int64_t)c.t0 * rs + c.head * DH;
+        c.ok = true;
+        return c;
+    };
+    uint4 kv[NR][2], vv[NR][2];
+    auto request = [&](const Item& c, bf16x8 (&qf)[2]) {       // global loads of an item's K / V pieces and this wave's first Q fragments
+        qf[0] = bf16x8{}; qf[1] = bf16x8{};
+        if (w < c.nkt) {
+            const int q = min(w * 32 + c31, c.L - 1);
+            qf[0] = *(const bf16x8*)(c.base + (int64_t)q * rs + hh * 8);
+            qf[1] = *(const bf16x8*)(c.base + (int64_t)q * rs + 16 + hh * 8);
+        }
+#pragma unroll
+        for (int rd = 0; rd < NR; ++rd)
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const int p = rd * 512 + u2 * 256 + tid, r = p >> 2, u = p & 3;
+                kv[rd][u2] = uint4{0u, 0u, 0u, 0u};
+                vv[rd][u2] = uint4{0u, 0u, 0u, 0u};
+                if (r < c.L) {
+                    kv[rd][u2] = *(const uint4*)(c.base + (int64_t)r * rs + koff + u * 8);
+                    vv[rd][u2] = *(const uint4*)(c.base + (int64_t)r * rs + voff + u * 8);
+                }
+            }
+    };
+    auto stage = [&](const Item& c) {                           // registers -> the LDS images (K row-major swizzled, V^T key-permuted)
+#pragma unroll
+        for (int rd = 0; rd < NR; ++rd)
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const int p = rd * 512 + u2 * 256 + tid, r = p >> 2, u = p & 3;
+                if (p < c.nkt * 128) {
+                    *(uint4*)(ks + r * 64 + ((u ^ ((r >> 2) & 3)) * 16)) = kv[rd][u2];
+                    const int r16 = r & 15, slot = (r & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
+                    const unsigned short* ve = (const unsigned short*)&vv[rd][u2];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) *(unsigned short*)(vt + (u * 8 + e) * VSTR + slot * 2) = ve[e];
+                }
+            }
+    };
+    const u32 kaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ks + (u32)(c31 * 64);
+    const u32 ksw = (u32)((c31 >> 2) & 3);
+    auto kfrag = [&](int kt, int s2) -> bf16x8 {
+        return *(const bf16x8*)((const __attribute__((address_space(3))) char*)(uintptr_t)(kaddr + (u32)(kt * 2048) + (((u32)(2 * s2 + hh) ^ ksw) * 16)));
+    };
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+
+    // OCC == 4 (126 registers, k_attn3's occupancy): no room for the next item's pieces in registers -- they are pulled into this XCD's L2
+    // instead (one 128-byte line per lane, value discarded), and requested for real when the item starts
+    auto touch_l2 = [&](const Item& c) {
+        const int n_lines = c.L * 64 / 128;                       // (head-major planes: an item's Q, K and V are three contiguous blocks)
+        if (hm_stride > 0 && tid < 3 * n_lines) {
+            const int part = tid / n_lines, ln = tid - part * n_lines;
+            const char* p = (const char*)(c.base + (int64_t)part * koff) + ln * 128;
+            u32 sink;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
+        }
+    };
+    int it = blockIdx.x;
+    Item cur = item(it);
+    bf16x8 qf[2], qnx[2];
+    request(cur, qf);
+    for (;;) {
+        if (cur.ok) stage(cur);
+        __syncthreads();
+        const int itn = it + (int)gridDim.x;
+        const Item nxt = item(itn);
+        qnx[0] = bf16x8{}; qnx[1] = bf16x8{};
+        if (OCC == 4) { if (nxt.ok) touch_l2(nxt); }
+        else if (nxt.ok) request(nxt, qnx);                      // in flight while this item computes
+        if (cur.ok) {
+            const int L = cur.L, nkt = cur.nkt, t0 = cur.t0, head = cur.head;
+            const bf16* base = cur.base;
+            f32x16 maskc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) maskc[r] = ((nkt - 1) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3) < L) ? 0.f : -INFINITY;
+            for (int qt = w; qt < nkt; qt += 4) {
+                bf16x8 qn[2] = {qf[0], qf[1]};
+                if (qt + 4 < nkt) {
+                    const int q = min((qt + 4) * 32 + c31, L - 1);
+                    qn[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
+                    qn[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
+                }
+                float mx = -INFINITY;
+                auto pass1 = [&](int kt, const f32x16& c0) {
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 0), qf[0], c0, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 1), qf[1], acc, 0, 0, 0);
+                    float m3 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+                    for (int r = 3; r + 1 < 16; r += 2) m3 = fmaxf(fmaxf(m3, acc[r]), acc[r + 1]);
+                    mx = fmaxf(mx, fmaxf(m3, acc[15]));
+                };
+#pragma unroll 1
+                for (int kt = 0; kt < nkt - 1; ++kt) pass1(kt, zero16);
+                pass1(nkt - 1, maskc);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                f32x16 negm, negmm;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { negm[r] = -mx; negmm[r] = maskc[r] - mx; }
+                f32x16 ot;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+                float sum = 0.f;
+                const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+                auto pass2 = [&](int kt, const f32x16& c0) {
+                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 0), qf[0], c0, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 1), qf[1], acc, 0, 0, 0);
+                    u32x4 pu[2];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        bf16x2 pb;
+                        pb[0] = (bf16)__builtin_amdgcn_exp2f(acc[r]);
+                        pb[1] = (bf16)__builtin_amdgcn_exp2f(acc[r + 1]);
+                        sum = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, sum, false);
+                        pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 vf = *(const bf16x8*)(vt + c31 * VSTR + (kt * 32 + s2 * 16 + hh * 8) * 2);
+                        ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pu[s2]), ot, 0, 0, 0);
+                    }
+                };
+#pragma unroll 1
+                for (int kt = 0; kt < nkt - 1; ++kt) pass2(kt, negm);
+                pass2(nkt - 1, negmm);
+                sum += __shfl_xor(sum, 32);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                {
+                    union { bf16x4 v; int i[2]; } pc[4], rcv[2];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pc[g4].v[e] = (bf16)(ot[4 * g4 + e] * inv);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int snd0 = hh ? pc[j].i[0] : pc[2 + j].i[0], snd1 = hh ? pc[j].i[1] : pc[2 + j].i[1];
+                        rcv[j].i[0] = __shfl_xor(snd0, 32);
+                        rcv[j].i[1] = __shfl_xor(snd1, 32);
+                    }
+                    const int q = qt * 32 + c31;
+                    if (q < L) {
+                        bf16x8 o0, o1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o0[e] = hh ? rcv[0].v[e] : pc[0].v[e];
+                            o0[4 + e] = hh ? pc[2].v[e] : rcv[0].v[e];
+                            o1[e] = hh ? rcv[1].v[e] : pc[1].v[e];
+                            o1[4 + e] = hh ? pc[3].v[e] : rcv[1].v[e];
+                        }
+                        if (ctx_tiled) {
+                            const int64_t m = t0 + q;
+                            const int r = (int)(m & 15), sw = tswz(r);
+                            bf16* blk = ctx + ((m >> 4) * NH + head) * 512 + r * 32;
+                            *(bf16x8*)(blk + ((2 * hh) ^ sw) * 8) = o0;
+                            *(bf16x8*)(blk + ((2 * hh + 1) ^ sw) * 8) = o1;
+                        } else {
+                            bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 16;
+                            *(bf16x8*)dst = o0;
+                            *(bf16x8*)(dst + 8) = o1;
+                        }
+                    }
+                }
+                qf[0] = qn[0];
+                qf[1] = qn[1];
+            }
+        }
+        if (itn >= n_items) break;
+        __syncthreads();                                         // everybody is done reading this item's LDS images
+        cur = nxt; it = itn;
+        if (OCC == 4) request(cur, qf);
+        else { qf[0] = qnx[0]; qf[1] = qnx[1]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // pooling heads
 // ------------------------------------------------------------------------------------------------------------
 // sentence-transformers Pooling + Normalize: one wave per sequence.  pool_cls = 0: masked mean over the sequence's tokens
@@ -3097,12 +3309,18 @@ static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps
     switch (var & 3) { RMU_FFN3_CASE(1) RMU_FFN3_CASE(2) RMU_FFN3_CASE(3) default: break; }
 #undef RMU_FFN3_CASE
 #endif
-    const int la = getenv("RMU_FFN3_LA") ? atoi(getenv("RMU_FFN3_LA")) : 1;   // (read per launch while the look-ahead form is being A/B-ed)
+#ifdef RMU_DEBUG_KERNELS
+    // VAR bit 2, the LOOK-AHEAD form (round 4; ffn3::wait_la): bit-identical output, and MEASURED EQUAL -- bench.py's embed leg 34.49-34.76 ms
+    // per 8192-chunk forward without it, 34.58-34.70 with it (three interleaved runs each, one box), k_ffn3 3346.7 vs 3351.7 us per launch
+    // under rocprofv3, MFMA busy 0.393 vs 0.378: the LDS round trip behind each of a chunk's five barriers is NOT what the kernel waits
+    // for (the second wave of the SIMD and the 3-slab DMA lead already cover it).  Debug builds: RMU_FFN3_LA=1.
+    static const int la = getenv("RMU_FFN3_LA") ? atoi(getenv("RMU_FFN3_LA")) : 0;
     if (la) {
         if (ln_in) launch_ffn3_t<true, 4, 4>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
         else launch_ffn3_t<false, 4, 4>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
         return;
     }
+#endif
     if (ln_in) launch_ffn3_t<true, 4, 0>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
     else launch_ffn3_t<false, 4, 0>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
 }
@@ -3145,6 +3363,16 @@ static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, b
 }
 
 #ifdef RMU_DEBUG_KERNELS
+template <int KT, int OCC>
+static void launch_attn4(int batch, const bf16* qkv, const int* cu, bf16* ctx, bool ctx_tiled, int64_t hm_stride, hipStream_t s) {
+    constexpr int lds = KT * 32 * 64 + 32 * (KT * 32 * 2 + 16);
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_attn4<KT, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)attr_rc;
+    static const int n_cu = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus; }();
+    const int items = (batch + 7) / 8 * 8 * NH;
+    const int grid = std::min(items, std::max(8, n_cu * OCC / 8 * 8));
+    hipLaunchKernelGGL((k_attn4<KT, OCC>), dim3((unsigned)grid), dim3(256), lds, s, qkv, cu, batch, ctx, ctx_tiled ? 1 : 0, (long)hm_stride);
+}
 template <int MAXT>
 static void launch_attn(dim3 grid, const bf16* qkv, const int* cu, bf16* ctx, hipStream_t s) {
     constexpr int lds = MAXT * 16 * 80 + DH * (MAXT * 16 * 2 + 8);
@@ -3230,6 +3458,23 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
         static const bool tiled_env = !(getenv("RMU_CTX_TILED") && atoi(getenv("RMU_CTX_TILED")) == 0);
         const bool ctx_tiled = tiled_env && attn_v == 3 && !(g3_mask & 2) && cap > 32768;
+#ifdef RMU_DEBUG_KERNELS
+        // k_attn4, the PERSISTENT form (round 4): measured SLOWER in every variant -- 8192 chunks, per layer under rocprofv3: k_attn3 837-851 us;
+        // k_attn4 with the next item's pieces prefetched into registers 1372-1384 us (2 workgroups per CU), with an L2 touch of the next item
+        // and k_attn3's occupancy 1244 us; bench.py's embed leg 33.8-34.0 ms vs 35.7-36.2.  The hardware dispatcher already overlaps one
+        // workgroup's cold start with three others' arithmetic AND balances the 16..256-token items dynamically; a static item list
+        // loses both.  Debug builds: RMU_ATTN4=1, RMU_ATTN4_OCC=2|3|4.
+        static const int attn4 = getenv("RMU_ATTN4") ? atoi(getenv("RMU_ATTN4")) : 0;
+        if (attn_v == 3 && attn4 && batch * NH > 4096 && max_len <= 256) {
+            static const int occ = getenv("RMU_ATTN4_OCC") ? atoi(getenv("RMU_ATTN4_OCC")) : 3;
+            if (max_len <= 128) {
+                if (occ == 2) launch_attn4<4, 2>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
+                else if (occ == 4) launch_attn4<4, 4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
+                else launch_attn4<4, 3>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
+            } else if (occ == 4) launch_attn4<8, 4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
+            else launch_attn4<8, 2>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
+        } else
+#endif
         if (attn_v == 3) {
             if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
             else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);

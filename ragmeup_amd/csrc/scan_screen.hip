@@ -33,7 +33,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int SD = 384;                 // floats per row
-constexpr int ROWB = SD * 4;            // fp32 row bytes (re-score)
 constexpr int IMGB = RMU_IMG_ROW_BYTES; // 768: screening-image bytes per row
 static_assert(IMGB == SD * 2, "image geometry");
 constexpr int S_RT = 32;                // rows per tile (the 4 waves of a workgroup share it)
@@ -42,7 +41,6 @@ constexpr int S_U16 = S_CKB / 16;       // 24 16-byte units per row per chunk
 constexpr int S_TS = SD / 16;           // 24 MFMA steps per tile ...
 constexpr int S_CS = S_TS / 2;          // ... 12 per chunk
 constexpr int S_SLOT = S_RT * S_CKB;    // 12 KiB ring slot
-constexpr int S_NI = S_RT * S_U16 / 256;  // 3 DMA wave-instructions per wave per chunk
 // G = 32-query groups per wave.  The v2 kernel (G = 1) was bound by LDS bandwidth: four waves each reading the whole tile
 // need 4 x 1 KiB per 32-cycle MFMA = all 128 B/clk of the LDS before the DMA writes are counted (ablations in
 // DESIGN.md 4.3).  With G = 2 every A fragment feeds two MFMAs (64 queries per wave, 256 per workgroup), halving LDS
@@ -216,7 +214,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
         dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16);
     }
     const int nchunks = 2 * ntiles;
-    // one of the S_NI LDS-DMA instructions of chunk cc.  They are issued one at a time between MFMA steps, not as a burst
+    // one of the LDS-DMA instructions of chunk cc (twelve 1-KiB pieces per chunk and workgroup).  They are issued one at a time between MFMA steps, not as a burst
     // behind the barrier: a wave that cannot hand its VMEM instruction to the (busy) address unit cannot issue MFMAs either,
     // and twelve back-to-back 1-KiB DMA instructions per chunk and workgroup cost ~700 cycles per tile that way.
     auto issue_part = [&](int cc, int n) {
@@ -607,7 +605,10 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->lds_bytes = p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
     // sibling pacing (see the kernel): query tiles of a chunk on one XCD, 2..4 of them, the whole grid resident at once (these
     // kernels take > 80 KiB of LDS: one workgroup per CU), and enough tiles per workgroup for drift to matter
-    const int pace_env = getenv("RMU_SCREEN_PACE") ? atoi(getenv("RMU_SCREEN_PACE")) : 8;   // (read per plan while the window is being tuned)
+    // window in tiles (0 = off).  Measured (tools/pace_probe.py, 10M x 1024): 0 / 4 / 8 / 16 / 32 all 7.82-7.86 ms of scan kernels -- the pacing
+    // costs nothing -- and on the round-4 boxes the siblings did not drift without it either (FETCH_SIZE 7.75-7.80 GB per batch = 1.01x
+    // the image, L2 hit 0.758 with pacing off AND on; round 3's boxes: 15.1 GB, 0.53): kept on as the bound on that drift.
+    static const int pace_env = getenv("RMU_SCREEN_PACE") ? atoi(getenv("RMU_SCREEN_PACE")) : 8;
     static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;

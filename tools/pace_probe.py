@@ -24,7 +24,7 @@ q /= q.norm(dim=1, keepdim=True)
 del x
 ref = None
 for w in [int(v) for v in a.pace.split(",")]:
-    os.environ["RMU_SCREEN_PACE"] = str(w)
+    os.environ["RMU_SCREEN_PACE"] = str(w)   # NOTE: read once per process since the tuning ended: run one window per process
     for _ in range(3):
         s, r = idx.search(q, 10)
     torch.cuda.synchronize()
