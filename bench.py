@@ -187,10 +187,12 @@ def encoder_flops(lens) -> float:
     return float((l * (2 * 6 * (4 * 384 * 384 + 2 * 384 * 1536)) + 6 * 4 * l * l * 384).sum())
 
 
-def encoder_roofline(tf: float) -> dict:
-    return {"kernel": "whole forward: k_ffn3 (bf16 MFMA 32x32x16, two waves per SIMD: LayerNorm1 + FFN1 + GELU + FFN2 + residual + LayerNorm2), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj + residual, both operands as 1-KiB tiled blocks), k_attn3 (32x32x16, two-pass softmax off the MFMA accumulator), k_embed_ln, k_pool", "bound": "mfma", "achieved": round(tf, 2),
-            "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None,
-            "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches)"}
+def encoder_roofline(tf: float, traffic_key=None) -> dict:
+    traffic = TRAFFIC.get(traffic_key) if traffic_key else None
+    return {"traffic_source": TRAFFIC_SOURCE if traffic else None, "kernel": "whole forward: k_ffn3 (bf16 MFMA 32x32x16, two waves per SIMD: LayerNorm1 + FFN1 + GELU + FFN2 + residual + LayerNorm2), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj + residual, both operands as 1-KiB tiled blocks), k_attn3 (32x32x16, two-pass softmax off the MFMA accumulator), k_embed_ln, k_pool", "bound": "mfma", "achieved": round(tf, 2),
+            "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
+            "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches); traffic = HBM bytes of ONE "
+                     "forward of this workload, all encoder kernels (2 x FETCH_SIZE + WRITE_SIZE)"}
 
 
 def leg_embed(args) -> dict:
@@ -204,7 +206,7 @@ def leg_embed(args) -> dict:
     leg = {"name": "C3 embed chunks (BERT-6x384 bf16 MFMA, mean-pool, L2-norm)", "value": round(8192 / (ms * 1e-3), 1), "unit": "chunks/sec",
            "ms_per_step": round(ms, 3), "config": {"workload": "8192-chunk batches, L ~ clip(N(128,32),16,256), synthetic ids, random-init weights",
                                                    "tokens_per_step": int(lens.sum())},
-           "tokens_per_sec": round(float(lens.sum()) / (ms * 1e-3), 1), "roofline": encoder_roofline(fl / (ms * 1e-3) / 1e12)}
+           "tokens_per_sec": round(float(lens.sum()) / (ms * 1e-3), 1), "roofline": encoder_roofline(fl / (ms * 1e-3) / 1e12, ("embed", 8192, 0))}
     if not args.no_cpu_baseline:
         leg["cpu_baseline"] = cpu_encoder_baseline(head=False)
     enc.close()
@@ -357,6 +359,7 @@ def leg_index(args) -> dict:
         t0 = time.perf_counter()
         for i in range(0, count, batch):
             store.add_documents(docs[i:min(i + batch, count)], ids=ids[i:min(i + batch, count)])
+        store.flush()                                    # the last call's GPU half (1000-document calls are pipelined across calls)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert len(store) == len(set(ids[:count]))
@@ -381,7 +384,8 @@ def leg_index(args) -> dict:
                              "note": "rmu_index_stat: re-allocations (x1.5 + D2D copy of corpus matrix and fp16 image) inside the timed passes and their wall "
                                      "time in ms -- no capacity is known up front, as with the reference's Milvus collection"},
            "reference_pattern_1000_doc_calls": {"chunks_per_sec": round(n / ref_s, 1), "seconds": round(ref_s, 3),
-                                                "note": "server/RAGHelper.py:423-434: each call tokenises, encodes and inserts its 1000 chunks before it returns"},
+                                                "note": "server/RAGHelper.py:423-434's loop; a call returns when its host half is done (ids, records, row numbers fixed) and its GPU half "
+                                                        "(forward + append) overlaps the next call's tokenising -- every reader / writer of the index waits for it first"},
            "encoder_only": {"chunks_per_sec": round(n / enc_s, 1), "seconds": round(enc_s, 3), "note": "encode_ids on pre-tokenised, device-resident 8192-chunk batches of the same texts"},
            "tokenizer_only": {"texts_per_sec": round(n / tok_s, 1), "seconds": round(tok_s, 3), "threads": os.cpu_count(), "note": "rmu_tok_encode (host C++), all hardware threads"},
            "end_to_end_over_encoder_only": round(enc_s / one_s, 3),
@@ -633,7 +637,7 @@ def leg_rerank(args, x1m) -> dict:
                                          "bound": "hbm", "achieved": round(dense_bytes / (kms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                          "frac": round(dense_bytes / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None, "kernel_ms": round(kms, 4),
                                          "algorithmic_bytes": dense_bytes, "launch": geom}},
-           "roofline": encoder_roofline(fl / (ms_ce * 1e-3) / 1e12)}
+           "roofline": encoder_roofline(fl / (ms_ce * 1e-3) / 1e12, ("rerank", nqr * 100, 0))}
     if not args.no_cpu_baseline:
         leg["cpu_baseline"] = cpu_encoder_baseline(head=True)
     idx.close(); ce.close()

@@ -261,6 +261,19 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
                     self.embed_id_arrays(ids, lens, out=dst)
         return out
 
+    def tokenize_for_index(self, texts: list[str]):
+        """The HOST half of `embed_documents_device` for one pipeline block (<= pipeline_block texts): (ids, lens) numpy arrays, or
+        None when this object is not backed by the native tokenizer + encoder.  MI355XVectorStore runs it for call i + 1 while the
+        GPU half of call i (`embed_token_arrays_device` + the index append) is still in flight."""
+        from .tokenizer import WordPieceTokenizer
+        if not isinstance(getattr(self, "encoder", None), BertEncoder) or not isinstance(getattr(self, "tokenizer", None), WordPieceTokenizer):
+            return None
+        return self._tokenize(list(texts))
+
+    def embed_token_arrays_device(self, ids: np.ndarray, lens: np.ndarray):
+        """The GPU half: token arrays of `tokenize_for_index` -> torch CUDA [n, 384] fp32 (what `embed_documents_device` returns)."""
+        return self.embed_id_arrays(ids, lens)
+
     def embed_documents_array(self, texts: list[str]) -> np.ndarray:
         return self.embed_documents_device(texts).cpu().numpy()
 

@@ -159,6 +159,8 @@ class MI355XVectorStore(VectorStore):
         self._pks: list[str] = []
         self._alive: list[bool] = []
         self._pk_to_row: dict[str, int] = {}
+        self._pending = None                 # the GPU half of the last add_texts call, still in flight (see _add_pipelined)
+        self._worker = None
         if drop_old:
             self._remove_persisted()
         if auto_persist == "atexit" and self._persist_paths():
@@ -235,6 +237,7 @@ class MI355XVectorStore(VectorStore):
         if paths is None or self._index is None or self._superseded:
             return False
         with self._lock:
+            self._drain()
             self._index.save(paths[0] + ".tmp")
             with open(paths[1] + ".tmp", "w", encoding="utf-8") as f:
                 json.dump({"format": 1, "n": len(self._texts), "dim": self._dim, "metric": self.metric,
@@ -329,7 +332,93 @@ class MI355XVectorStore(VectorStore):
         return float(s)
 
     def __len__(self) -> int:
+        if self._pending is not None:
+            self.flush()
         return sum(self._alive)
+
+    # ---- the reference's insert loop, pipelined ACROSS calls ---------------------------------------------------------
+    # server/RAGHelper.py:423-434 inserts in 1000-document calls; each call is tokenise (host, ~1 ms) -> forward + append (GPU, ~3.4 ms)
+    # -> Python bookkeeping, strictly in series: 0.81 of the rate of one big call (whose blocks overlap inside the call).  A call of
+    # that size therefore returns once its HOST half is done -- ids fixed, records appended, the row numbers it will occupy known --
+    # and hands the GPU half to a worker thread; the next call's tokenising overlaps it.  Nothing can observe the difference: every
+    # entry point that reads or changes the index (search, delete, persist, the next GPU half, flush()) first waits for the pending
+    # half, and a failure in it rolls that call's records back and is raised there.
+    def _drain(self):
+        """(under self._lock) wait for the pending GPU half; on failure undo its call's host records and re-raise."""
+        pend, self._pending = self._pending, None
+        if pend is None:
+            return
+        fut, n0, cnt, undo, stale = pend
+        try:
+            fut.result()
+        except _RowsOutOfStep as e:
+            # the rows ARE in the index (tombstoned by the worker): dead placeholder records keep row numbers and records in step
+            for r in range(min(n0, e.first), len(self._alive)):
+                self._alive[r] = False
+            while len(self._texts) < e.first + cnt:
+                self._texts.append(""); self._metas.append({}); self._pks.append(""); self._alive.append(False)
+            self._undo_pks(undo, stale)
+            raise RuntimeError(f"index rows ({e.first}) and host records ({n0}) out of step: the batch was rolled back") from None
+        except Exception:
+            del self._texts[n0:], self._metas[n0:], self._pks[n0:], self._alive[n0:]
+            self._undo_pks(undo, stale)
+            raise
+
+    def _undo_pks(self, undo, stale):
+        for pk, old in undo:
+            if old is None:
+                self._pk_to_row.pop(pk, None)
+            else:
+                self._pk_to_row[pk] = old
+        for r in stale:
+            self._alive[r] = True
+
+    def flush(self):
+        """Wait until everything added so far is in the HBM-resident index (and raise what a pending add failed with)."""
+        with self._lock:
+            self._drain()
+
+    def _gpu_half(self, tok, n0: int, cnt: int, stale: list):
+        import torch
+        emb = self._embeddings
+        with torch.cuda.device(emb.encoder.device):
+            vecs = emb.embed_token_arrays_device(*tok)
+            first = self._index.add(vecs)
+            if first != n0:
+                self._index.remove_rows(list(range(min(n0, first), first + cnt)))
+                raise _RowsOutOfStep(first)
+            if stale:
+                self._index.remove_rows(stale)
+
+    def _add_pipelined(self, sel_texts, sel_ids, sel_metas_fn) -> bool:
+        emb = self._embeddings
+        if (self.auto_persist is True or not hasattr(emb, "tokenize_for_index") or not (128 <= len(sel_texts) <= getattr(emb, "pipeline_block", 0))
+                or (self._index is not None and not hasattr(self._index, "_h")) or type(self)._new_index is not MI355XVectorStore._new_index):
+            return False
+        tok = emb.tokenize_for_index(sel_texts)          # the previous call's GPU half may still be running: this is the overlap
+        if tok is None:
+            return False
+        sel_metas = sel_metas_fn()
+        with self._lock:
+            self._drain()
+            self._ensure_index(int(emb.encoder.HIDDEN))
+            n0 = len(self._texts)
+            self._texts.extend(sel_texts)
+            self._metas.extend(sel_metas)
+            self._pks.extend(sel_ids)
+            self._alive.extend([True] * len(sel_ids))
+            old_rows = self._pk_to_row
+            stale = [old_rows[pk] for pk in sel_ids if pk in old_rows and self._alive[old_rows[pk]]] if old_rows else []
+            undo = [(pk, old_rows.get(pk)) for pk in sel_ids] if old_rows else [(pk, None) for pk in sel_ids]
+            for r in stale:
+                self._alive[r] = False
+            old_rows.update(zip(sel_ids, range(n0, n0 + len(sel_ids))))
+            self._dirty = True
+            if self._worker is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmu-add")
+            self._pending = (self._worker.submit(self._gpu_half, tok, n0, len(sel_ids), stale), n0, len(sel_ids), undo, stale)
+        return True
 
     # ---- insert (RAGHelper.py:431, :525) ------------------------------------------------------------------
     def add_texts(self, texts: Iterable[str], metadatas: Optional[list[dict]] = None, ids: Optional[list[str]] = None,
@@ -352,9 +441,10 @@ class MI355XVectorStore(VectorStore):
         else:
             keep = sorted(last.values())
             sel_texts, sel_ids = [texts[i] for i in keep], [ids[i] for i in keep]
+        if self._add_pipelined(sel_texts, sel_ids, lambda: [dict(metadatas[i]) for i in keep]):
+            return list(ids)
         # The host records are prepared WHILE the GPU embeds (both the tokenizer and the encoder run in librmu.so with the GIL
-        # released): on the indexing path (1000-document calls, server/RAGHelper.py:423-434, or one big call) the Python
-        # bookkeeping would otherwise sit serially behind every embedding.
+        # released): on the indexing path (one big call) the Python bookkeeping would otherwise sit serially behind every embedding.
         if len(sel_texts) >= 4096:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=1) as pool:
@@ -365,6 +455,7 @@ class MI355XVectorStore(VectorStore):
             vecs = self._embed_docs_for_index(sel_texts)
             sel_metas = [dict(metadatas[i]) for i in keep]
         with self._lock:
+            self._drain()
             self._ensure_index(int(vecs.shape[1]))
             n0 = len(self._texts)
             # host records FIRST: a concurrent search may return a new row the moment index.add publishes it
@@ -410,6 +501,7 @@ class MI355XVectorStore(VectorStore):
         """Delete by pk list, by a Milvus-style `field == "value"` expression, or by a metadata dict.
         Returns an object with ``delete_count`` (what server.py:385 reads) that is also truthy/int-like."""
         with self._lock:
+            self._drain()
             rows: list[int] = []
             if ids:
                 rows += [self._pk_to_row[i] for i in ids if i in self._pk_to_row]
@@ -437,6 +529,8 @@ class MI355XVectorStore(VectorStore):
 
     # ---- search ---------------------------------------------------------------------------------------------
     def _search_vecs(self, qvecs: np.ndarray, k: int):
+        if self._pending is not None:
+            self.flush()
         if self._index is None or len(self._index) == 0:
             return np.full((qvecs.shape[0], 0), -np.inf, np.float32), np.full((qvecs.shape[0], 0), -1, np.int64)
         kk = max(1, min(int(k), N.MAX_K))
@@ -449,6 +543,8 @@ class MI355XVectorStore(VectorStore):
     def _fused_query(self, query: str, fetch_k: int, k: int, lambda_mult):
         """One query through `rmu_bert_search_mmr` (token ids in, rows out: forward, dense top-fetch_k and the selection in ONE library
         call with one synchronisation) when the Embeddings object and the index are the native ones; None otherwise."""
+        if self._pending is not None:
+            self.flush()
         emb, idx = self._embeddings, self._index
         if (idx is None or not hasattr(idx, "_h") or len(idx) == 0 or not hasattr(emb, "query_ids") or not (1 <= k <= fetch_k <= 64)
                 or idx.dim != 384):
@@ -481,6 +577,8 @@ class MI355XVectorStore(VectorStore):
     def max_marginal_relevance_search_by_vector(self, embedding, k: int = 4, fetch_k: int = 20,
                                                 lambda_mult: float = 0.5, **kw) -> list[Document]:
         q = np.asarray(embedding, dtype=np.float32)
+        if self._pending is not None:
+            self.flush()
         if (self._index is not None and hasattr(self._index, "search_mmr") and len(self._index) > 0
                 and 1 <= k <= int(fetch_k) <= 64):
             # dense top-fetch_k and the greedy selection in one library call (rmu_index_search_mmr, fetch_k <= 64): one host
@@ -533,6 +631,12 @@ class MI355XVectorStore(VectorStore):
         tags = list(kw.pop("tags", None) or []) + [type(self).__name__]
         return MI355XRetriever(vectorstore=self, search_type=search_type, search_kwargs=dict(search_kwargs or {}),
                                tags=tags, **kw)
+
+
+class _RowsOutOfStep(Exception):
+    def __init__(self, first: int):
+        super().__init__(first)
+        self.first = first
 
 
 class _DeleteResult(int):

@@ -108,8 +108,12 @@ def test_pooling_and_normalize_follow_the_checkpoint(tmp_path, pooling, normaliz
         assert np.abs(gn - 1).max() < 1e-5
     else:
         assert np.abs(gn / rn - 1).max() < 2e-2 and rn.std() > 0                              # the raw pooled norm is kept
+    # one query alone (the small-batch kernels, LayerNorms folded into their consumers) vs the same text inside the batch: two roundings of
+    # the same fp32 forward.  Measured on the 12-layer, 3x-scaled CLS case over all 96 texts: each within 3.2e-3 / 3.5e-3 (max abs) and
+    # 1.7e-2 / 1.9e-2 (rel. L2) of the fp32 reference, 3.2e-3 apart from each other (2.8e-3 before the LayerNorm fold).
     one = np.asarray(emb.embed_query(texts[5]), np.float32)
-    assert np.abs(one - got[5]).max() < 2e-3 * max(1.0, float(rn[5]))
+    assert np.abs(one - got[5]).max() < 4e-3 * max(1.0, float(rn[5]))
+    assert np.linalg.norm(one - ref[5]) / rn[5] <= 2.5e-2
 
 
 def test_cross_encoder_default_activation_is_sigmoid(tmp_path):

@@ -421,3 +421,53 @@ def test_store_queries_take_the_fused_call_and_equal_the_two_step_path(bi, tmp_p
     finally:
         bi[0].search_host = real
         store._index.close()
+
+
+def test_insert_calls_are_pipelined_across_calls_and_nothing_can_tell(bi, tmp_path):
+    """The reference's insert loop (server/RAGHelper.py:423-434, 1000-document calls): a call returns when its host half is done and its
+    GPU half overlaps the next call's tokenising.  Same store as one big call (rows, pks, search results); upserts across calls keep
+    one live row per pk; a GPU half that fails is raised by the next operation and its call's records are rolled back."""
+    from ragmeup_amd.documents import Document
+    from ragmeup_amd.embeddings import MI355XEmbeddings
+    from ragmeup_amd.tokenizer import WordPieceTokenizer
+    from ragmeup_amd.vectorstore import MI355XVectorStore
+    from tests.helpers import synth_texts, synth_vocab
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(synth_vocab()) + "\n", encoding="utf-8")
+    emb = MI355XEmbeddings(encoder=bi[0], tokenizer=WordPieceTokenizer(str(vp)), max_seq_length=128)
+    texts = synth_texts(2500, seed=31, wmin=10, wmax=40)
+    docs = [Document(t, {"source": f"s{i % 7}", "id": str(i)}) for i, t in enumerate(texts)]
+    pks = [str(i) for i in range(len(texts))]
+    one = MI355XVectorStore(embeddings=emb, collection_name="one", auto_persist=False)
+    one.add_documents(docs, ids=pks)
+    pip = MI355XVectorStore(embeddings=emb, collection_name="pip", auto_persist=False)
+    seen_pending = 0
+    for lo in range(0, len(docs), 500):
+        assert pip.add_documents(docs[lo:lo + 500], ids=pks[lo:lo + 500]) == pks[lo:lo + 500]
+        seen_pending += pip._pending is not None
+    assert seen_pending == 5                                    # every call of that size left its GPU half in flight
+    assert len(pip) == len(one) == 2500 and pip._pending is None
+    for q in texts[:3] + synth_texts(3, seed=32, wmin=5, wmax=12):
+        a = [(d.metadata["pk"], s) for d, s in one.similarity_search_with_score(q, k=8)]
+        b = [(d.metadata["pk"], s) for d, s in pip.similarity_search_with_score(q, k=8)]
+        assert a == b
+    # upsert across pipelined calls: the same 500 pks again with new texts -> still 2500 live rows, the old copies are gone
+    new_docs = [Document("replacement " + texts[i], {"source": "r", "id": str(i)}) for i in range(500)]
+    pip.add_documents(new_docs, ids=pks[:500])
+    pip.add_documents(docs[500:700], ids=pks[500:700])          # a second call right behind it (drains the first)
+    assert len(pip) == 2500
+    hit = pip.similarity_search("replacement " + texts[3], k=1)[0]
+    assert hit.metadata["pk"] == "3" and hit.page_content.startswith("replacement ")
+    assert pip.delete(expr='source == "r"').delete_count == 500 and len(pip) == 2000
+    # a failing GPU half: raised by the next operation, that call's records rolled back, the store still consistent and usable
+    real_add = pip._index.add
+    pip._index.add = lambda v: (_ for _ in ()).throw(RuntimeError("device lost"))
+    n_before = len(pip._texts)
+    pip.add_documents([Document("doomed " + t, {"source": "d", "id": "d" + str(i)}) for i, t in enumerate(texts[:300])], ids=["d" + str(i) for i in range(300)])
+    with pytest.raises(RuntimeError, match="device lost"):
+        pip.flush()
+    pip._index.add = real_add
+    assert len(pip._texts) == n_before and "d0" not in pip._pk_to_row and len(pip) == 2000
+    pip.add_documents(docs[:200], ids=["again" + p for p in pks[:200]])
+    assert len(pip) == 2200 and len(pip._index) == len(pip._texts)
+    one._index.close(); pip._index.close()

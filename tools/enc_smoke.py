@@ -9,8 +9,20 @@ from bench import bert_weights, synth_tokens
 from ragmeup_amd.bert import BertEncoder
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+pair = len(sys.argv) > 3 and sys.argv[3] == "pair"      # the rerank workload of bench.py's C5 leg: (query, passage) pairs through the cross-encoder
+if pair:
+    enc = BertEncoder(bert_weights(1, True), layers=6)
+    ids, tt, lens = synth_tokens(n, seed=9, lmin=100, lmax=190, mean=147, std=20, pair=True)
+    ids, tt, lens = (torch.as_tensor(a).cuda() for a in (ids, tt, lens))
+    out = enc.encode_ids(ids, lens, tt, mode=1)
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    print("OK", n, "pairs finite", bool(np.isfinite(o).all()), "checksum", float(o.sum()))
+    sys.exit(0)
 enc = BertEncoder(bert_weights(0, False), layers=6)
 ids, _, lens = synth_tokens(n, seed=7)
+if os.environ.get("ENC_DEVICE_IDS"):                     # ids resident on the device (what bench.py's embed leg times)
+    ids, lens = torch.as_tensor(ids).cuda(), torch.as_tensor(lens).cuda()
 out = enc.encode_ids(ids, lens, None, mode=0)
 torch.cuda.synchronize()
 o = out.cpu().numpy()

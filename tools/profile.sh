@@ -6,7 +6,7 @@
 # rocprofv3 (signal 6) and then hung in its finalisation until the box's limit -- 15 GPU-minutes lost.  The encoder is profiled
 # with --kernel-trace --stats only.
 set -u
-TAG=${1:-r03p}
+TAG=${1:-r04p}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check"
 keep() {  # keep only our kernels' rows of a CSV
   f=$(find $OUT/$1 -name "*$2" | head -1)
-  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|merge_select|merge_wg|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_cls_head" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
+  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|merge_select|merge_wg|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_cls_head|k_cu_seqlens" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
 }
 # 1) headline bench (10M x 384, B=1024) on the default path (fp16 hi/lo screening + exact re-score): stats + PMC passes
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan -o scan -- $B > $OUT/scan_bench.json 2> $OUT/scan.err
@@ -61,5 +61,14 @@ keep top100 kernel_stats.csv stats
 # 6) encoder PMC (the four dominant kernels only; a pass over every kernel hung rocprofv3 in round 1)
 timeout -k 5 150 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-include-regex "k_ffn3|k_gemm3|k_attn3|k_gemm" --output-format csv -d $OUT/enc_pmc -o a -- python $R/tools/enc_smoke.py 2048 > /dev/null 2>> $OUT/scan.err
 keep enc_pmc counter_collection.csv counters
-for d in top100 enc_pmc scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
+# 7) encoder HBM traffic (round 4): FETCH_SIZE and WRITE_SIZE, separate passes, over ONE forward of exactly the workloads bench.py's
+# embed (C3: 8192 chunks) and rerank (C5: 6400 pairs) legs time -- every encoder kernel of the forward (k_* only)
+ENCK="k_ffn3|k_gemm3|k_attn3|k_gemm|k_embed_ln|k_pool|k_layernorm|k_cls_head|k_cu_seqlens"
+for wl in "embed 8192" "rerank 6400"; do set -- $wl; name=$1; n=$2; extra=""; [ $name = rerank ] && extra="0 pair";
+  ENC_DEVICE_IDS=1 timeout -k 5 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$ENCK" --output-format csv -d $OUT/enc_${name}_f -o a -- python $R/tools/enc_smoke.py $n $extra > /dev/null 2>> $OUT/scan.err
+  keep enc_${name}_f counter_collection.csv counters
+  ENC_DEVICE_IDS=1 timeout -k 5 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$ENCK" --output-format csv -d $OUT/enc_${name}_w -o a -- python $R/tools/enc_smoke.py $n $extra > /dev/null 2>> $OUT/scan.err
+  keep enc_${name}_w counter_collection.csv counters
+done
+for d in enc_embed_f enc_embed_w enc_rerank_f enc_rerank_w top100 enc_pmc scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
 ls -la $OUT

@@ -12,8 +12,8 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03p"
-RP = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04p"
+RP = sys.argv[2] if len(sys.argv) > 2 else "r04"
 src = f"gpurun_out/{tag}"
 STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.py then repeats 10 searches with per-launch events (roofline pass)
 
@@ -155,6 +155,33 @@ if os.path.exists(f'{src}/enc_pmc_counters.csv'):
     out.append("| share of wave time with an instruction active | " + " | ".join(f"{m[k]['SQ_ACTIVE_INST_ANY'] / m[k]['SQ_WAVE_CYCLES']:.2f}" for k in ks) + " |")
     out.append("| resident waves per SIMD = WAVE_CYCLES x 4 / 1024 / cycles | " + " | ".join(f"{m[k]['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc[k]:.2f}" for k in ks) + " |")
     open(f'profiles/{RP}_encoder_pmc.md', 'w').write("\n".join(out) + "\n")
+# encoder HBM traffic (round 4): one forward of the embed / rerank workloads, every encoder kernel: 2 x FETCH_SIZE (gfx950 correction for
+# wide coalesced reads -- the LDS-DMA / 16-byte loads these kernels use) + WRITE_SIZE (uncalibrated: taken at face value), KiB -> bytes
+enc_entries, enc_lines = [], []
+for name, units in (("embed", 8192), ("rerank", 6400)):
+    ff, fw = f'{src}/enc_{name}_f_counters.csv', f'{src}/enc_{name}_w_counters.csv'
+    if not (os.path.exists(ff) and os.path.exists(fw)):
+        continue
+    per = collections.defaultdict(lambda: [0.0, 0.0, 0])
+    for path, col in ((ff, 0), (fw, 1)):
+        for r in csv.DictReader(open(path)):
+            if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                k = short(r['Kernel_Name'])
+                per[k][col] += float(r['Counter_Value'])
+                if col == 0:
+                    per[k][2] += 1
+    fetch = sum(v[0] for v in per.values()) * 2048
+    write = sum(v[1] for v in per.values()) * 1024
+    enc_entries.append({"path": name, "rows": units, "batch": 0, "bytes_per_step": fetch + write, "fetch_bytes": fetch, "write_bytes": write})
+    enc_lines.append(f"\n### {name}: one forward of {units} {'chunks' if name == 'embed' else 'pairs'} (`tools/enc_smoke.py`), all encoder kernels: "
+                     f"fetch {fetch / 1e9:.2f} GB (2 x FETCH_SIZE) + write {write / 1e9:.2f} GB = **{(fetch + write) / 1e9:.2f} GB**\n")
+    enc_lines += ["| kernel | launches | fetch GB | write GB |", "|---|---|---|---|"]
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1][0]):
+        enc_lines.append(f"| `{k}` | {v[2]} | {v[0] * 2048 / 1e9:.3f} | {v[1] * 1024 / 1e9:.3f} |")
+if enc_lines:
+    open(f'profiles/{RP}_encoder_traffic.md', 'w').write(
+        f"# Encoder HBM traffic (round {int(RP[1:])}): `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, tools/profile.sh step 7)\n"
+        + "\n".join(enc_lines) + "\n")
 # what bench.py reports as roofline.traffic: HBM bytes per bench step of exactly these configurations, from THIS round's passes
 json.dump({"source": f"tools/profile.sh {tag} -> tools/summarize_profiles.py: sum per bench step over the launches of (2 x FETCH_SIZE [gfx950 correction] "
                      f"+ WRITE_SIZE where collected) x 1024, profiles/{RP}_pmc_means.csv",
@@ -162,7 +189,7 @@ json.dump({"source": f"tools/profile.sh {tag} -> tools/summarize_profiles.py: su
                        {"path": "screen", "rows": 10_000_000, "batch": 32, "bytes_per_step": f('pmc_b32', SK, 'FETCH_SIZE') * 2048},
                        {"path": "screen", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('pmc_b1', SK, 'FETCH_SIZE') * 2048},
                        {"path": "exact", "rows": 10_000_000, "batch": 1024, "bytes_per_step": f('exact_pmc_b', EK, 'FETCH_SIZE') * 2048},
-                       {"path": "exact", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('exact_pmc_b1', B1, 'FETCH_SIZE') * 2048}]},
+                       {"path": "exact", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('exact_pmc_b1', B1, 'FETCH_SIZE') * 2048}] + enc_entries},
           open(f'profiles/{RP}_traffic.json', 'w'), indent=1)
 print("\n".join(txt[-4:]))
 print("SCREEN_TRAFFIC =", scr_fetch + scr_write, "B1 screen", f('pmc_b1',SK,'FETCH_SIZE')*2048, "B32 screen", f('pmc_b32',SK,'FETCH_SIZE')*2048, "exact", f('exact_pmc_b',EK,'FETCH_SIZE')*2048, "exact B1", f('exact_pmc_b1',B1,'FETCH_SIZE')*2048)
