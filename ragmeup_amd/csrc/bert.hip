@@ -496,7 +496,8 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
 // sit in registers as MFMA A fragments (K/64 of them), token fragments come straight from global memory (no LDS staging), the
 // four partial sums meet in LDS and all 256 threads run the epilogue (bias | + GELU | + residual).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int SMALL_M = 256;                           // tokens (upper bound batch * max_len) one graph-replayed host call may carry (rmu_bert_encode_host)
+constexpr int SMALL_M = 256;                           // tokens (upper bound batch * max_len) below which launch_gemm's callers take k_gemm_small
+constexpr int FOLD_TOKENS = 2560;                      // ... and up to which a whole forward runs on it with the LayerNorms folded (enqueue_forward)
 // Round 4: the token dimension is a grid dimension too -- workgroup (x, y) takes features [32 x, +32) of tokens [SMALL_TB y, +SMALL_TB)
 // -- so the same kernel serves a few THOUSAND tokens (the reference's rerank call: <= 14 (query, passage) pairs, ~1.5k tokens,
 // twice per /chat request): the tiled kernels run 6-36 workgroups there (10-17 us per launch), this one N/32 x M/128 short ones.
@@ -507,16 +508,20 @@ constexpr int SMALL_M = 256;                           // tokens (upper bound ba
 //     normalised value) -- and workgroup x = 0 leaves (mean, rstd) per token in `stats_out`;
 //   * LNR: a GEMM whose RESIDUAL is LN(y) rebuilds it in the epilogue from y and those statistics (the launch that wrote them is
 //     always an earlier one on the stream: FFN1 -> FFN2, next layer's QKV -> its out-proj).
-template <int EPI, int K, bool LNA = false, bool LNR = false>
-__global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
+// Token tiles are walked with the NEXT tile's fragments (and this tile's residual rows / statistics) already requested: a tile is
+// 6-12 MFMAs per wave, a global round trip is a microsecond -- unpipelined, a workgroup that walks 8 tiles spends 8 round trips
+// (round 4, first version: 8-22 us per launch at 1.5k tokens, no better than the tiled kernels).  K = 1536 is split over EIGHT waves
+// (NWV): 12 weight + 2 x 12 token fragments per wave instead of 24 + 2 x 24.
+template <int EPI, int K, bool LNA = false, bool LNR = false, int NWV = (K > 512 ? 8 : 4)>
+__global__ __launch_bounds__(64 * NWV) void k_gemm_small(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
                                                     const bf16* __restrict__ resid, bf16* __restrict__ out, const int* __restrict__ cu,
                                                     int batch, int N, int SMALL_TB /* tokens per workgroup along grid.y, a multiple of 32 */,
                                                     const float* __restrict__ lng = nullptr, const float* __restrict__ lnb = nullptr, float eps = 0.f,
                                                     float2* __restrict__ stats_out = nullptr, const float* __restrict__ rg = nullptr,
                                                     const float* __restrict__ rb = nullptr, const float2* __restrict__ rstats = nullptr) {
-    static_assert(!LNA || K == H, "the normalised operand is a hidden-state row");
-    constexpr int KW = K / 4, NF = KW / 16;
-    __shared__ float red[4][32][36];                   // [K quarter][token][feature (+4 pad)]
+    static_assert(!LNA || (K == H && NWV == 4), "the normalised operand is a hidden-state row, its statistics meet over four K quarters");
+    constexpr int KW = K / NWV, NF = KW / 16;
+    __shared__ float red[NWV][32][36];                 // [K slice][token][feature (+4 pad)]
     __shared__ float lnp[2][4][32];                    // LNA: [sum | squared deviations][K quarter][token]
     const int M = cu[batch];
     const int tb0 = blockIdx.y * SMALL_TB;
@@ -542,16 +547,33 @@ __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, 
             for (int e = 0; e < 4; ++e) { lg[f][e] = g0[e]; lg[f][4 + e] = g1[e]; lb[f][e] = b0[e]; lb[f][4 + e] = b1[e]; }
         }
     }
-    const int et = threadIdx.x >> 3, ef = (threadIdx.x & 7) * 4;       // epilogue: token et, features ef .. ef + 3
+    const bool epi_thread = threadIdx.x < 256;         // epilogue: token et, features ef .. ef + 3 (the first four waves)
+    const int et = (threadIdx.x & 255) >> 3, ef = (threadIdx.x & 7) * 4;
     const f32x4 bv = *(const f32x4*)(bias + n0 + ef);
     f32x4 rgv = {}, rbv = {};
     if constexpr (LNR) { rgv = *(const f32x4*)(rg + n0 + ef); rbv = *(const f32x4*)(rb + n0 + ef); }
-    for (int t0 = tb0; t0 < tb1; t0 += 32) {
+    auto load_x = [&](int t0, bf16x8 (&x)[NF]) {
         const int tok = min(t0 + r31, M - 1);
         const bf16* xr = A + (int64_t)tok * K + w * KW + hh * 8;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) x[f] = *(const bf16x8*)(xr + f * 16);
+    };
+    bf16x8 xn[NF];
+    load_x(tb0, xn);
+    for (int t0 = tb0; t0 < tb1; t0 += 32) {
         bf16x8 xf[NF];
 #pragma unroll
-        for (int f = 0; f < NF; ++f) xf[f] = *(const bf16x8*)(xr + f * 16);
+        for (int f = 0; f < NF; ++f) xf[f] = xn[f];
+        if (t0 + 32 < tb1) load_x(t0 + 32, xn);        // the next tile's fragments: in flight across this tile's MFMAs and epilogue
+        // this tile's residual rows and statistics: requested now, used behind the MFMAs
+        const int m = t0 + et;
+        const int64_t off = (int64_t)m * N + n0 + ef;
+        bf16x4 rv = {};
+        float2 st = {0.f, 1.f};
+        if (EPI == EPI_RESID && epi_thread && m < M) {
+            rv = *(const bf16x4*)(resid + off);
+            if constexpr (LNR) st = rstats[m];
+        }
         if constexpr (LNA) {
             float v[NF][8], sm = 0.f;
 #pragma unroll
@@ -582,25 +604,21 @@ __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, 
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f], xf[f], acc, 0, 0, 0);
-        // acc[4 q + e] = feature 8 q + 4 hh + e of token r31, summed over this wave's K quarter
+        // acc[4 q + e] = feature 8 q + 4 hh + e of token r31, summed over this wave's K slice
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *(f32x4*)&red[w][r31][q * 8 + hh * 4] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
         __syncthreads();
-        const int m = t0 + et;
-        if (m < M) {
+        if (epi_thread && m < M) {
             f32x4 v = bv;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) v += *(const f32x4*)&red[ww][et][ef];
+            for (int ww = 0; ww < NWV; ++ww) v += *(const f32x4*)&red[ww][et][ef];
             if (EPI == EPI_GELU) v = gelu_poly4(v);
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-            const int64_t off = (int64_t)m * N + n0 + ef;
             if (EPI == EPI_RESID) {
-                bf16x4 rv = *(const bf16x4*)(resid + off);
                 if constexpr (LNR) {                   // the residual is LN(resid row): (mean, rstd) from the launch that normalised it as ITS operand
-                    const float2 st = rstats[m];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rv[e] = (bf16)((bf2f(rv[e]) - st.x) * st.y * rgv[e] + rbv[e]);
                 }
@@ -611,6 +629,152 @@ __global__ __launch_bounds__(256) void k_gemm_small(const bf16* __restrict__ A, 
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_gemm_mid -- the same GEMM (and the same LayerNorm folds) for a few HUNDRED to a few THOUSAND tokens: the reference's rerank call
+// (<= 14 (query, passage) pairs, ~1.5k tokens, twice per /chat request).  k_gemm_small's K split costs four barriers and an LDS round
+// trip per 32-token tile -- ~2 us a tile whatever is prefetched (8-20 us per launch at 1.5k tokens), and the tiled kernels run 6-36
+// workgroups of 6-24 latency-bound stages there (11-15 us).  Here NOTHING is shared: a wave owns one 32-feature x 32-token output tile
+// for the whole K -- both operands straight from global memory / L2 as MFMA fragments, in k chunks of CK with the next chunk's
+// fragments requested before the current chunk's MFMAs (the weight rows are re-read per token tile: 56 MB of L2 reads for FFN2 at
+// 1.5k tokens, microseconds) -- no LDS, no barrier, the LayerNorm statistics of a token are this lane's and lane ^ 32's.  grid =
+// (N / 32) x ceil(tokens / 128); the four waves of a workgroup take four consecutive token tiles of one feature block.
+// ------------------------------------------------------------------------------------------------------------
+template <int EPI, int K, bool LNA = false, bool LNR = false>
+__global__ __launch_bounds__(256) void k_gemm_mid(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
+                                                  const bf16* __restrict__ resid, bf16* __restrict__ out, const int* __restrict__ cu,
+                                                  int batch, int N, const float* __restrict__ lng, const float* __restrict__ lnb, float eps,
+                                                  float2* __restrict__ stats_out, const float* __restrict__ rg, const float* __restrict__ rb,
+                                                  const float2* __restrict__ rstats) {
+    static_assert(!LNA || K == H, "the normalised operand is a hidden-state row");
+    constexpr int CK = LNA ? K : 192;                  // k per chunk (LNA: the whole row at once -- its statistics come first)
+    constexpr int NC = K / CK, NF = CK / 16;
+    const int M = cu[batch];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r31 = lane & 31, hh = lane >> 5;
+    __shared__ float sgb[LNA ? 2 * H : 2];             // LNA: gamma | beta (read per fragment from LDS: hoisted global loads of all 192 pairs
+    if constexpr (LNA) {                                // per lane cost 384 registers and spilled)
+        for (int i = threadIdx.x; i < H; i += 256) { sgb[i] = lng[i]; sgb[H + i] = lnb[i]; }
+        __syncthreads();
+    }
+    const int t0 = (blockIdx.y * 4 + w) * 32;
+    if (t0 >= M) return;
+    const int n0 = blockIdx.x * 32;
+    const int tok = min(t0 + r31, M - 1);
+    const bf16* wr = W + (int64_t)(n0 + r31) * K + hh * 8;       // A operand: feature n0 + r31, k = 16 f + 8 hh ..
+    const bf16* xr = A + (int64_t)tok * K + hh * 8;              // B operand: token, same k
+    bf16x8 wf[2][NF], xf[2][NF];
+    auto request = [&](int c, int buf) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            wf[buf][f] = *(const bf16x8*)(wr + c * CK + f * 16);
+            xf[buf][f] = *(const bf16x8*)(xr + c * CK + f * 16);
+        }
+    };
+    request(0, 0);
+    // epilogue operands, requested now: acc[4 q + e] = feature n0 + 8 q + 4 hh + e of token t0 + r31
+    const bool live = t0 + r31 < M;
+    f32x4 bq[4];
+    bf16x4 rv[4];
+    float2 st = {0.f, 1.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bq[q] = *(const f32x4*)(bias + n0 + 8 * q + 4 * hh);
+        rv[q] = bf16x4{};
+        if (EPI == EPI_RESID && live) rv[q] = *(const bf16x4*)(resid + (int64_t)(t0 + r31) * N + n0 + 8 * q + 4 * hh);
+    }
+    if constexpr (LNR) { if (live) st = rstats[t0 + r31]; }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) request(c + 1, (c + 1) & 1);
+        if constexpr (LNA) {
+            // LN(y) of this token on the way in: two-pass fp32 statistics over the 384 values = this lane's 192 and lane ^ 32's.  The
+            // fragments are handled as packed 32-bit PAIRS (a shift / a mask widens a bf16, one v_cvt_pk_bf16_f32 packs two results):
+            // element-wise bf16 arithmetic made hipcc keep every element in a register of its own (512 registers + 752 bytes of scratch)
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            auto lo_f = [](u32 u) { return __builtin_bit_cast(float, u << 16); };
+            auto hi_f = [](u32 u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+            float sm = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const u32x4 u = __builtin_bit_cast(u32x4, xf[0][f]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm += lo_f(u[j]) + hi_f(u[j]);
+            }
+            sm += __shfl_xor(sm, 32);
+            const float mu = sm * (1.0f / H);
+            float qv = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const u32x4 u = __builtin_bit_cast(u32x4, xf[0][f]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d0 = lo_f(u[j]) - mu, d1 = hi_f(u[j]) - mu; qv = fmaf(d0, d0, qv); qv = fmaf(d1, d1, qv); }
+            }
+            qv += __shfl_xor(qv, 32);
+            const float rs = rsqrtf(qv * (1.0f / H) + eps);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int k0 = f * 16 + hh * 8;
+                const u32x4 u = __builtin_bit_cast(u32x4, xf[0][f]);
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = (lo_f(u[j]) - mu) * rs * sgb[k0 + 2 * j] + sgb[H + k0 + 2 * j];
+                    const float b = (hi_f(u[j]) - mu) * rs * sgb[k0 + 2 * j + 1] + sgb[H + k0 + 2 * j + 1];
+                    u32 pk;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(a), "v"(b));
+                    o[j] = pk;
+                }
+                xf[0][f] = __builtin_bit_cast(bf16x8, o);
+                if (f % 4 == 3) asm volatile("" ::: "memory");     // at most four fragments' parameters in registers at a time
+            }
+            if (stats_out && blockIdx.x == 0 && hh == 0 && live) stats_out[t0 + r31] = float2{mu, rs};
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c & 1][f], xf[c & 1][f], acc, 0, 0, 0);
+    }
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[4 * q] + bq[q][0], acc[4 * q + 1] + bq[q][1], acc[4 * q + 2] + bq[q][2], acc[4 * q + 3] + bq[q][3]};
+        if (EPI == EPI_GELU) v = gelu_poly4(v);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+        if (EPI == EPI_RESID) {
+            bf16x4 r4 = rv[q];
+            if constexpr (LNR) {
+                const f32x4 gq = *(const f32x4*)(rg + n0 + 8 * q + 4 * hh), bb = *(const f32x4*)(rb + n0 + 8 * q + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r4[e] = (bf16)((bf2f(r4[e]) - st.x) * st.y * gq[e] + bb[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(bf2f(o[e]) + bf2f(r4[e]));
+        }
+        *(bf16x4*)(out + (int64_t)(t0 + r31) * N + n0 + 8 * q + 4 * hh) = o;
+    }
+}
+
+template <int EPI, int K, bool LNA = false, bool LNR = false>
+static void launch_mid(hipStream_t s, int64_t m_cap, const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
+                       int batch, int N, const float* lng = nullptr, const float* lnb = nullptr, float eps = 0.f, float2* stats_out = nullptr,
+                       const float* rg = nullptr, const float* rb = nullptr, const float2* rstats = nullptr) {
+    const dim3 grid((unsigned)(N / 32), (unsigned)((m_cap + 127) / 128));
+    hipLaunchKernelGGL((k_gemm_mid<EPI, K, LNA, LNR>), grid, dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N, lng, lnb, eps, stats_out, rg, rb, rstats);
+}
+
+// one k_gemm_small launch: grid = N / 32 feature blocks x token blocks of `tb`
+template <int EPI, int K, bool LNA = false, bool LNR = false>
+static void launch_small(hipStream_t s, int64_t m_cap, int tb, const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
+                         int batch, int N, const float* lng = nullptr, const float* lnb = nullptr, float eps = 0.f, float2* stats_out = nullptr,
+                         const float* rg = nullptr, const float* rb = nullptr, const float2* rstats = nullptr) {
+    constexpr int NWV = K > 512 ? 8 : 4;
+    const dim3 grid((unsigned)(N / 32), (unsigned)((m_cap + tb - 1) / tb));
+    hipLaunchKernelGGL((k_gemm_small<EPI, K, LNA, LNR, NWV>), grid, dim3(64 * NWV), 0, s, A, W, bias, resid, out, cu, batch, N, tb, lng, lnb, eps, stats_out, rg, rb, rstats);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3127,8 +3291,8 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
         if (hipMalloc((void**)&m->h, t * H * 2) != hipSuccess || hipMalloc((void**)&m->h1, t * H * 2) != hipSuccess ||
             hipMalloc((void**)&m->y, t * H * 2) != hipSuccess || hipMalloc((void**)&m->qkv, t * 3 * H * 2) != hipSuccess ||
             hipMalloc((void**)&m->ctx, t * H * 2) != hipSuccess || hipMalloc((void**)&m->mid, t * FF * 2) != hipSuccess ||
-            hipMalloc((void**)&m->st1, (size_t)std::min<int64_t>(t, SMALL_M + 64) * sizeof(float2)) != hipSuccess ||
-            hipMalloc((void**)&m->st2, (size_t)std::min<int64_t>(t, SMALL_M + 64) * sizeof(float2)) != hipSuccess)
+            hipMalloc((void**)&m->st1, (size_t)std::min<int64_t>(t, FOLD_TOKENS + 64) * sizeof(float2)) != hipSuccess ||
+            hipMalloc((void**)&m->st2, (size_t)std::min<int64_t>(t, FOLD_TOKENS + 64) * sizeof(float2)) != hipSuccess)
             return RMU_E_OOM;
         m->ws_tokens = t;
     }
@@ -3191,9 +3355,8 @@ static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const b
 #else
         const int tb = 128;
 #endif
-        const dim3 grid((unsigned)(N / 32), (unsigned)((m_cap + tb - 1) / tb));
-        if (K == H) hipLaunchKernelGGL((k_gemm_small<EPI, H>), grid, dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N, tb);
-        else hipLaunchKernelGGL((k_gemm_small<EPI, FF>), grid, dim3(256), 0, s, A, W, bias, resid, out, cu, batch, N, tb);
+        if (K == H) launch_small<EPI, H>(s, m_cap, tb, A, W, bias, resid, out, cu, batch, N);
+        else launch_small<EPI, FF>(s, m_cap, tb, A, W, bias, resid, out, cu, batch, N);
         return;
     }
     // few tiles (latency-bound: every workgroup walks K alone): 128 x 128 tiles in 64-k stages halve the stage count and double
@@ -3411,30 +3574,57 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     const dim3 at_grid(NH, (unsigned)batch);   // k_attention: one workgroup per (head, sequence); k_attn3: one per sequence
     size_t li = 0;
     bool h_in_tiled = false;                   // m->h as this layer reads it: row-major from k_embed_ln, tiled from a k_ffn3 that was told so
-    // ---- the interactive sizes (<= 256 tokens: one query, two short pairs): five launches per layer instead of seven -- both LayerNorms
-    // are folded into the k_gemm_small launches that consume them (see there): y1 = out-proj + residual lives in m->y, y2 = FFN2 +
-    // residual in m->h1, neither is ever normalised in memory; one k_layernorm after the last layer feeds the pooling heads.
+    // ---- the interactive sizes (one query; the <= 14 pairs of a rerank call, ~1.5k tokens; anything up to FOLD_TOKENS): five launches per
+    // layer instead of seven -- both LayerNorms are folded into the k_gemm_small launches that consume them (see there): y1 = out-proj +
+    // residual lives in m->y, y2 = FFN2 + residual in m->h1, neither is ever normalised in memory; one k_layernorm after the last layer
+    // feeds the pooling heads.  Token blocks per workgroup: enough of them to fill the chip, few enough to amortise the weight rows a
+    // workgroup keeps in registers (N / 32 feature blocks x cap / tb token blocks ~ 256-512 workgroups).
     static const bool small_ok_f = !(getenv("RMU_GEMM_SMALL") && atoi(getenv("RMU_GEMM_SMALL")) == 0);
     static const bool ln_fuse = !(getenv("RMU_LN_FUSE") && atoi(getenv("RMU_LN_FUSE")) == 0);
-    if (cap <= SMALL_M && small_ok_f && ln_fuse) {
-        const dim3 gq((unsigned)(3 * H / 32), (unsigned)((cap + 127) / 128)), gh((unsigned)(H / 32), (unsigned)((cap + 127) / 128)),
-            gf((unsigned)(FF / 32), (unsigned)((cap + 127) / 128));
+    // measured (tools/ce_probe.py, cross-encoder forward per call): 14 pairs / 1548 tokens 0.464-0.468 ms on the tiled kernels, 0.412-0.424 here;
+    // 30 pairs / 3360 tokens (cap 4800: above the threshold) 0.50-0.51 tiled vs 0.65 here -- the fold pays up to ~2.5k tokens
+    static const int64_t fold_tokens = getenv("RMU_FOLD_TOKENS") ? atoll(getenv("RMU_FOLD_TOKENS")) : FOLD_TOKENS;
+    if (cap <= fold_tokens && max_len <= 256 && small_ok_f && ln_fuse) {
+        auto tb_for = [&](int n_feature_blocks) {       // tokens per workgroup: ~384 workgroups in all, a multiple of 32, at least 32
+            const int64_t blocks = std::max<int64_t>(1, 384 / n_feature_blocks);
+            int64_t tb = (cap + blocks - 1) / blocks;
+            tb = (tb + 31) / 32 * 32;
+            return (int)std::min<int64_t>(std::max<int64_t>(tb, 32), 1024);
+        };
+        const int tq = tb_for(3 * H / 32), th = tb_for(H / 32), tf = tb_for(FF / 32);
         const int* cu = m->cu;
         bf16 *y1 = m->y, *y2 = m->h1;
         const BertLayer* prev = nullptr;
+        // k_gemm_mid (a wave per output tile, both operands as MFMA fragments straight from global memory, nothing shared): measured and NOT
+        // adopted -- 14 pairs / 1548 tokens: 0.58 ms per forward against 0.42 with k_gemm_small and 0.47 with the tiled kernels; per launch
+        // 8-28 us: a fragment-shaped load touches 32 cache lines for 1 KiB and the CU's address path is paid per line (debug builds: RMU_GEMM_MID=1)
+#ifdef RMU_DEBUG_KERNELS
+        static const bool mid_env = getenv("RMU_GEMM_MID") && atoi(getenv("RMU_GEMM_MID")) != 0;
+        const bool mid = cap > SMALL_M && mid_env;
+#endif
         for (const BertLayer& L : m->layers) {
-            if (!prev) hipLaunchKernelGGL((k_gemm_small<EPI_BIAS, H>), gq, dim3(256), 0, s, (const bf16*)m->h, L.wqkv, L.bqkv, (const bf16*)nullptr, m->qkv, cu, batch, 3 * H, 128);
-            else hipLaunchKernelGGL((k_gemm_small<EPI_BIAS, H, true>), gq, dim3(256), 0, s, (const bf16*)y2, L.wqkv, L.bqkv, (const bf16*)nullptr, m->qkv, cu, batch, 3 * H, 128,
-                                    (const float*)prev->ln2g, (const float*)prev->ln2b, eps, m->st2);
+#ifdef RMU_DEBUG_KERNELS
+            if (mid) {
+                if (!prev) launch_mid<EPI_BIAS, H>(s, cap, m->h, L.wqkv, L.bqkv, nullptr, m->qkv, cu, batch, 3 * H);
+                else launch_mid<EPI_BIAS, H, true>(s, cap, y2, L.wqkv, L.bqkv, nullptr, m->qkv, cu, batch, 3 * H, prev->ln2g, prev->ln2b, eps, m->st2);
+                if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
+                else launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
+                if (!prev) launch_mid<EPI_RESID, H>(s, cap, m->ctx, L.wo, L.bo, m->h, y1, cu, batch, H);
+                else launch_mid<EPI_RESID, H, false, true>(s, cap, m->ctx, L.wo, L.bo, y2, y1, cu, batch, H, nullptr, nullptr, eps, nullptr, prev->ln2g, prev->ln2b, m->st2);
+                launch_mid<EPI_GELU, H, true>(s, cap, y1, L.w1, L.b1, nullptr, m->mid, cu, batch, FF, L.ln1g, L.ln1b, eps, m->st1);
+                launch_mid<EPI_RESID, FF, false, true>(s, cap, m->mid, L.w2, L.b2, y1, y2, cu, batch, H, nullptr, nullptr, eps, nullptr, L.ln1g, L.ln1b, m->st1);
+                prev = &L;
+                continue;
+            }
+#endif
+            if (!prev) launch_small<EPI_BIAS, H>(s, cap, tq, m->h, L.wqkv, L.bqkv, nullptr, m->qkv, cu, batch, 3 * H);
+            else launch_small<EPI_BIAS, H, true>(s, cap, tq, y2, L.wqkv, L.bqkv, nullptr, m->qkv, cu, batch, 3 * H, prev->ln2g, prev->ln2b, eps, m->st2);
             if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
             else launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
-            if (!prev) hipLaunchKernelGGL((k_gemm_small<EPI_RESID, H>), gh, dim3(256), 0, s, (const bf16*)m->ctx, L.wo, L.bo, (const bf16*)m->h, y1, cu, batch, H, 128);
-            else hipLaunchKernelGGL((k_gemm_small<EPI_RESID, H, false, true>), gh, dim3(256), 0, s, (const bf16*)m->ctx, L.wo, L.bo, (const bf16*)y2, y1, cu, batch, H, 128,
-                                    (const float*)nullptr, (const float*)nullptr, eps, (float2*)nullptr, (const float*)prev->ln2g, (const float*)prev->ln2b, (const float2*)m->st2);
-            hipLaunchKernelGGL((k_gemm_small<EPI_GELU, H, true>), gf, dim3(256), 0, s, (const bf16*)y1, L.w1, L.b1, (const bf16*)nullptr, m->mid, cu, batch, FF, 128,
-                               (const float*)L.ln1g, (const float*)L.ln1b, eps, m->st1);
-            hipLaunchKernelGGL((k_gemm_small<EPI_RESID, FF, false, true>), gh, dim3(256), 0, s, (const bf16*)m->mid, L.w2, L.b2, (const bf16*)y1, y2, cu, batch, H, 128,
-                               (const float*)nullptr, (const float*)nullptr, eps, (float2*)nullptr, (const float*)L.ln1g, (const float*)L.ln1b, (const float2*)m->st1);
+            if (!prev) launch_small<EPI_RESID, H>(s, cap, th, m->ctx, L.wo, L.bo, m->h, y1, cu, batch, H);
+            else launch_small<EPI_RESID, H, false, true>(s, cap, th, m->ctx, L.wo, L.bo, y2, y1, cu, batch, H, nullptr, nullptr, eps, nullptr, prev->ln2g, prev->ln2b, m->st2);
+            launch_small<EPI_GELU, H, true>(s, cap, tf, y1, L.w1, L.b1, nullptr, m->mid, cu, batch, FF, L.ln1g, L.ln1b, eps, m->st1);
+            launch_small<EPI_RESID, FF, false, true>(s, cap, th, m->mid, L.w2, L.b2, y1, y2, cu, batch, H, nullptr, nullptr, eps, nullptr, L.ln1g, L.ln1b, m->st1);
             prev = &L;
         }
         if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);

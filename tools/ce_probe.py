@@ -14,9 +14,11 @@ for n in pairs:
     ids, tt, lens = synth_tokens(n, seed=9, lmin=60, lmax=160, mean=110, std=20, pair=True)
     a = [torch.as_tensor(t).cuda() for t in (ids, lens, tt)]
     for mid in mids:
-        # "MID[:TB[:CFG[:G3MIN]]]"
+        # "FOLD[:TB[:CFG[:G3MIN]]]": FOLD = RMU_FOLD_TOKENS (tokens up to which the LN-folded k_gemm_small forward runs; 0 = the tiled kernels);
+        # the other three are debug-build switches
         f = mid.split(":")
-        os.environ["RMU_MID_TOKENS"] = f[0]
+        os.environ["RMU_FOLD_TOKENS"] = f[0]
+        os.environ["RMU_MID_TOKENS"] = "256"
         os.environ["RMU_SMALL_TB"] = f[1] if len(f) > 1 else "128"   # (debug builds only)
         os.environ["RMU_GEMM_CFG"] = f[2] if len(f) > 2 else "0"
         os.environ["RMU_G3_MIN"] = f[3] if len(f) > 3 else "0"
@@ -24,4 +26,4 @@ for n in pairs:
         ms = timed(lambda: ce.encode_ids(a[0], a[1], a[2], mode=1), 100, 10)
         o = out.cpu().numpy()
         d = float(np.abs(o - ref.setdefault(n, o)).max())
-        print(f"pairs {n:4d} tokens {int(lens.sum()):6d} cap {ids.size:6d} MID:TB:CFG:G3MIN {mid:>18s}: {ms:.3f} ms per call   max|dlogit| vs first {d:.2e}", flush=True)
+        print(f"pairs {n:4d} tokens {int(lens.sum()):6d} cap {ids.size:6d} FOLD {mid:>8s}: {ms:.3f} ms per call   max|dlogit| vs first {d:.2e}", flush=True)
