@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
     // (one ballot per slot) and only slots with a passing lane pay for key + ds_add_rtn + store.  A position past the slot
     // means "full": the compaction this triggers frees room and the score is retried.
     u32 d_slow = 0, d_rounds = 0, d_comp = 0, d_app = 0;
-    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_all = DBG ? clock64() : 0;
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_vm = 0, d_clk_all = DBG ? clock64() : 0;
     auto slow_path = [&](const Acc* p, int64_t rbase, bool recompute) {
         unsigned long long c0 = 0;
         if (recompute) {      // the hot loop only kept a wave-wide "any lane passed" flag (scalar unit): per-lane bits are made here
@@ -373,6 +373,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
             unsigned long long cb = 0;
             if (DBG) cb = clock64();
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+            if (DBG) { const unsigned long long cv = clock64(); d_clk_vm += cv - cb; cb = cv; }      // own DMA pieces landed | everybody arrived
             __builtin_amdgcn_s_barrier();
             if (DBG) d_clk_bar += clock64() - cb;
             if (c == 0) {
@@ -406,6 +407,142 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
         }
     };
 
+    constexpr bool PP = (EXP & 16) != 0;
+    if constexpr (PP) {
+        // ---- PING-PONG form (round 4, 8 waves): the two waves of a SIMD never do the same thing at the same time.  Round 3's loop lets both
+        // interleave wait / MFMA / compare / ds_read / DMA step by step; the matrix pipe is per SIMD and an in-order wave cannot slip an MFMA
+        // into a gap shorter than 32 cycles (MI355X_MICROARCH.md, "Two waves per SIMD"): 0.59 MFMA busy.  Here a wave alternates a LOAD
+        // segment -- the 12 fragment reads of a chunk into 48 registers, the previous tile's 16 filter compares, its share of the ring's DMA --
+        // with a COMPUTE segment of 12 back-to-back MFMAs, and waves w and w + 4 (one SIMD) run half a period apart: group X = waves 0-3
+        // loads chunk c in phase 2c and computes it in phase 2c + 1, group Y = waves 4-7 one phase later.  One s_barrier per phase.
+        //   ring: chunk c is read by X in phase 2c and by Y in phase 2c + 1; its slot is refilled with chunk c + 6 - 1 + ... = c + 5's
+        //   successor: the pieces of chunk c + 5 go into the slot of chunk c - 1 (free since the barrier that ended phase 2c - 1), the X
+        //   half (pieces 0-5) issued in X's load of chunk c, the Y half (6-11) in Y's; a wave's pieces of chunk k have landed when at most
+        //   3 chunks' worth of its own pieces are still in flight: waited for at the end of EVERY load segment, i.e. one barrier before
+        //   anybody reads chunk k.
+        // MEASURED (debug counters, RMU_SCAN_EXP=7 + RMU_SCREEN_PP=1, largest range): a load segment = 12 ds_read_b128 + the wait = 481 cycles
+        // with four waves of a CU loading at once -- 8 cycles per KiB and CU, i.e. the LDS delivers 128 B/clk per CU = 32 B/clk to each SIMD, and
+        // ONE 1-KiB A fragment per 32-cycle MFMA is exactly that rate.  The interleaved form's 0.59 MFMA busy (1300 cycles per chunk for 768 of
+        // MFMA and 96 KiB of fragment reads = 74 B/clk) is the same wall from the other side: with one LDS fragment per MFMA the matrix pipe
+        // and the LDS return path both have to run at 100 % at the same time.  Ping-pong does not move it (8.3 ms vs 7.75): debug builds only.
+        // What would: every fragment feeding two MFMAs (64 queries per wave = 192 registers of query fragments: one wave per SIMD, the
+        // 4-wave form, which is issue-bound instead: 0.35).
+        static_assert(NW == 8 && G == 1, "ping-pong: 8 waves x 32 queries");
+        if (ntiles > 0) {
+            const bool grpY = w >= 4;
+            const int wi = w & 3;
+            const bool heavy = wi < 2;                           // two pieces per chunk (pieces wi and 4 + wi of the group's six), else one
+            const int p1 = (grpY ? 6 : 0) + wi, p2 = (grpY ? 6 : 0) + 4 + wi;
+            u32 poff1, poff2;
+            {
+                const int f1 = p1 * 64 + lane, f2 = p2 * 64 + lane;
+                const int i1 = f1 / S_U16, q1 = f1 % S_U16, i2 = f2 / S_U16, q2 = f2 % S_U16;
+                poff1 = (u32)(i1 * IMGB + (q1 ^ ((i1 >> 1) & 7)) * 16);
+                poff2 = (u32)(i2 * IMGB + (q2 ^ ((i2 >> 1) & 7)) * 16);
+            }
+            auto issue_pp = [&](int cc2) {
+                int ce = cc2 < nchunks ? cc2 : nchunks - 1;
+                const char* sbase = img + ((t0 + (ce >> 1)) * S_RT) * (int64_t)IMGB + (ce & 1) * S_CKB;
+                char* slot = ring + (cc2 % C::NR) * S_SLOT;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + poff1),
+                                                 (__attribute__((address_space(3))) void*)(slot + p1 * 1024), 16, 0, 0);
+                if (heavy)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + poff2),
+                                                     (__attribute__((address_space(3))) void*)(slot + p2 * 1024), 16, 0, 0);
+            };
+            // in flight when a load segment ends: this wave's pieces of the three youngest chunks (issued in its last three compute segments)
+            auto wait_own = [&]() {
+                if (heavy) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            };
+            refresh_gthr();
+#pragma unroll
+            for (int c0 = 0; c0 < C::NR - 1; ++c0) issue_pp(c0);
+            if (heavy) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // chunk 0
+            __builtin_amdgcn_s_barrier();
+            if (grpY) __builtin_amdgcn_s_barrier();              // Y runs one phase behind X
+            f16x8 fq[S_CS];
+            // two accumulation chains per tile (even / odd k steps: a 32-cycle MFMA never waits for the one before it), summed -- and
+            // filtered -- in the load segment that follows the tile
+            Acc acc[1], acc2[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[0].a[r] = -INFINITY; acc2[0].a[r] = 0.f; }
+            const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
+            for (int tl = 0; tl < ntiles; ++tl) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {                          // (unrolled: the chunk parity selects the query fragments at compile time)
+                const int cc2 = 2 * tl + c;
+                const int soff = (cc2 % C::NR) * S_SLOT;
+                unsigned long long ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0;
+                if (DBG) ck0 = clock64();
+                // ---- LOAD segment: the chunk's 12 fragments; behind a tile's second chunk also that tile's sum, its 16 compares, ONE branch
+#pragma unroll
+                for (int t = 0; t < S_CS; ++t) read_frag(fq[t], soff, t);
+                if (c == 0) {
+                    if (tl > 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[0].a[r] += acc2[0].a[r];
+                        if (!(a.share_thr & 2) && !(EXP & 8)) {
+                            u64 any_pass = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) any_pass |= __ballot(acc[0].a[r] > thr_s[0]);
+                            if (__builtin_expect(any_pass != 0, 0)) slow_path(acc, lane_r0 + (int64_t)(tl - 1) * S_RT, true);
+                        }
+                    }
+                    const u32 go = gt_lds[j];
+                    thr_g[0] = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
+                    set_thr();
+                    if (w == NW - 1 && pace_live) pace_step(tl);
+                }
+                wait_own();                                          // (the 12 fragment reads have landed as well)
+#pragma unroll
+                for (int t = 0; t < S_CS; ++t) asm volatile("" : "+v"(fq[t]));
+                if (DBG) ck1 = clock64();
+                __builtin_amdgcn_s_barrier();
+                if (DBG) ck2 = clock64();
+                // ---- COMPUTE segment: 12 MFMAs on two chains; this wave's DMA pieces of chunk cc2 + 5 and the threshold refresh in their shadow
+                if (c == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc[0].a[r] = 0.f; acc2[0].a[r] = 0.f; }
+                }
+#pragma unroll
+                for (int t = 0; t < S_CS; ++t) {
+                    if (t & 1) acc2[0].a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[t], qh[0][c * S_CS + t], acc2[0].a, 0, 0, 0);
+                    else acc[0].a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[t], qh[0][c * S_CS + t], acc[0].a, 0, 0, 0);
+                    if (t == 1 || (t == 6 && heavy)) {
+                        int ce = cc2 + C::NR - 1;
+                        const int cs = ce % C::NR;
+                        if (ce >= nchunks) ce = nchunks - 1;
+                        const char* sbase = img + ((t0 + (ce >> 1)) * S_RT) * (int64_t)IMGB + (ce & 1) * S_CKB;
+                        if (t == 1)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + poff1),
+                                                             (__attribute__((address_space(3))) void*)(ring + cs * S_SLOT + p1 * 1024), 16, 0, 0);
+                        else
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + poff2),
+                                                             (__attribute__((address_space(3))) void*)(ring + cs * S_SLOT + p2 * 1024), 16, 0, 0);
+                    }
+                    if (c == 1 && t == 9) refresh_gthr();
+                }
+                if (DBG) { asm volatile("" : "+v"(acc[0].a), "+v"(acc2[0].a)); ck3 = clock64(); }
+                if (!(grpY && cc2 + 1 == nchunks)) __builtin_amdgcn_s_barrier();
+                if (DBG) { d_clk_vm += ck1 - ck0; d_clk_bar += ck2 - ck1; d_clk_slow += ck3 - ck2; d_rounds += (u32)((clock64() - ck3) >> 4); }
+              }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            {
+                const int64_t rbl = lane_r0 + (int64_t)(ntiles - 1) * S_RT;
+                const int64_t row_end = a.row0 + a.n_rows;
+                pmask[0] = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[0].a[r] += acc2[0].a[r];
+                    const bool in_range = rbl + (r & 3) + 8 * (r >> 2) < row_end;
+                    pmask[0] |= (in_range && acc[0].a[r] > thr_s[0]) ? (1u << r) : 0u;
+                }
+                if (__any(pmask[0] != 0)) slow_path(acc, rbl, false);
+            }
+        }
+    } else
     if (ntiles > 0) {
         refresh_gthr();                                    // oldest VMEM op: seeded / already published thresholds
 #pragma unroll
@@ -463,6 +600,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
             atomicAdd((unsigned long long*)a.dbg + 4, (unsigned long long)d_rounds);
             atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
             atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
+            atomicAdd((unsigned long long*)a.dbg + 8, d_clk_vm);
             atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
         }
     }
@@ -624,7 +762,10 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
                               // python -m ragmeup_amd.build --debug-kernels; tools/ablate_screen.sh
     static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;
     static const int pre = getenv("RMU_SCREEN_SPRE") ? atoi(getenv("RMU_SCREEN_SPRE")) : 4;
-    if (p->wq == 8 && p->dbg) return screen_launch_cfg<1, 4, 4, 0, 0, 8>(p, s);
+    if (p->wq == 8 && p->dbg) {
+        static const int ppd = getenv("RMU_SCREEN_PP") ? atoi(getenv("RMU_SCREEN_PP")) : 0;
+        return ppd ? screen_launch_cfg<1, 20, 4, 0, 0, 8>(p, s) : screen_launch_cfg<1, 4, 4, 0, 0, 8>(p, s);
+    }
     if (p->dbg) {
         if (p->qg == 2 && ex == 8) return screen_launch_cfg<2, 12>(p, s);
         if (p->qg == 2 && ex == 9) return screen_launch_cfg<2, 13>(p, s);
@@ -647,7 +788,15 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
         if (pre == 3) return screen_launch_cfg<2, 0, 3>(p, s);
     }
 #endif
-    if (p->wq == 8) return screen_launch_cfg<1, 0, 4, 0, 0, 8>(p, s);                 // full query tiles: 8 waves x 32 queries
+    if (p->wq == 8) {                                                                 // full query tiles: 8 waves x 32 queries
+#ifdef RMU_DEBUG_KERNELS
+        // the PING-PONG form (EXP bit 4; see the kernel): measured 8.27-8.32 ms of scan kernels per 10M x 1024 batch against 7.69-7.81 for the
+        // interleaved form (compares in the compute segment; 9.3 with them in the load segment, 9.0-9.1 with the DMA there, 11.0 in the first cut)
+        static const int pp = getenv("RMU_SCREEN_PP") ? atoi(getenv("RMU_SCREEN_PP")) : 0;
+        if (pp) return screen_launch_cfg<1, 16, 4, 0, 0, 8>(p, s);
+#endif
+        return screen_launch_cfg<1, 0, 4, 0, 0, 8>(p, s);
+    }
     if (p->qg == 2) return screen_launch_cfg<2>(p, s);                                // RMU_SCREEN_W8=0 / RMU_SCREEN_G=2: 4 waves x 64 queries
     return p->nt ? screen_launch_cfg<1, 0, 4, 0, 1>(p, s) : screen_launch_cfg<1>(p, s);
 }

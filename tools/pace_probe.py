@@ -8,7 +8,8 @@ from bench import make_shard
 from ragmeup_amd import FlatIndex
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--pace", default="0,8,0,4,16,32,8")
+ap.add_argument("--pace", default="0,1,0,1")
+ap.add_argument("--env", default="RMU_SCREEN_PP", help="switch that is read per launch (RMU_SCREEN_PP while the ping-pong form is measured)")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--batch", type=int, default=1024)
@@ -24,7 +25,7 @@ q /= q.norm(dim=1, keepdim=True)
 del x
 ref = None
 for w in [int(v) for v in a.pace.split(",")]:
-    os.environ["RMU_SCREEN_PACE"] = str(w)   # NOTE: read once per process since the tuning ended: run one window per process
+    os.environ[a.env] = str(w)   # NOTE: read once per process since the tuning ended: run one window per process
     for _ in range(3):
         s, r = idx.search(q, 10)
     torch.cuda.synchronize()
@@ -41,4 +42,4 @@ for w in [int(v) for v in a.pace.split(",")]:
     if ref is None:
         ref = (s.clone(), r.clone())
     same = bool(torch.equal(s, ref[0]) and torch.equal(r, ref[1]))
-    print(f"PACE {w:3d}: step {ms:.3f} ms  scan kernels {sum(k)/len(k):.3f} ms  {a.batch/ms*1e3:.0f} qps  identical_to_first={same} screened={idx.last_screened()}", flush=True)
+    print(f"{a.env}={w:3d}: step {ms:.3f} ms  scan kernels {sum(k)/len(k):.3f} ms  {a.batch/ms*1e3:.0f} qps  identical_to_first={same} screened={idx.last_screened()}", flush=True)
