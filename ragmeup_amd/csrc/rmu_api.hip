@@ -81,7 +81,7 @@ struct Buf {
 struct Tls {
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm, fbq, fb_s, fb_r, fb_i, mm_q, mm_s, mm_r, mm_p;
+    Buf q, partial, out_s, out_r, in_s, in_r, qn, gthr, mscratch, qsplit, ckeys, flag, nrm, fbq, fb_s, fb_r, fb_i, mm_q, mm_s, mm_r, mm_p, gcand;
     std::vector<hipEvent_t> lev;   // per-launch events of the screening ladder
     int ensure_events(int n) {
         while ((int)lev.size() < n) {
@@ -875,8 +875,8 @@ static void dbg_dump(const char* what, int64_t rows, hipStream_t s) {
     u64 h[16];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[rmu dbg %s: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu clk_vmwait=%llu\n",
-            what, (long long)rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+    fprintf(stderr, "[rmu dbg %s: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu clk_vmwait=%llu seg=%llu/%llu/%llu\n",
+            what, (long long)rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
     (void)hipMemset(g_dbg, 0, 128);
 }
 
@@ -928,6 +928,10 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
     for (int l = 0; l < nl; ++l)
         if (lv[(size_t)l].pace) pwords += (size_t)lv[(size_t)l].s_chunks * 4;
     const size_t gbytes = (gwords + pwords) * sizeof(u32);    // one memset zeroes thresholds and progress words
+    size_t gcand_bytes = 0;                              // K-split launches: global candidate slots (reused by every launch of the ladder)
+    for (int l = 0; l < nl; ++l)
+        if (lv[(size_t)l].kv >= 1) gcand_bytes = std::max(gcand_bytes, (size_t)lv[(size_t)l].parts * (size_t)nb * RMU_KS_CAP * sizeof(u64));
+    if (gcand_bytes && t.gcand.ensure(gcand_bytes)) return fail(RMU_E_OOM, "rmu_index_search: screening candidate slots");
     if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
         t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.ensure_events(2 * nl))
         return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
@@ -947,6 +951,7 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
         if (S.pace) { S.prog = prog_next; prog_next += (size_t)S.s_chunks * 4; }
         S.partial = base + (size_t)cursor * part_keys;
         S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = g_dbg; S.q = (const float*)t.qsplit.p;
+        S.gcand = S.kv >= 1 ? (u64*)t.gcand.p : nullptr;
         if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l)], s));
         rc = rmu_screen_launch(&S, s);
         if (rc) return fail(rc, "rmu_index_search: screening launch");

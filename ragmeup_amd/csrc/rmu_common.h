@@ -124,7 +124,11 @@ struct ScanLaunch {
     // of each row chunk (zeroed per launch; nullptr = off), pace = how many tiles a workgroup may run ahead of its slowest sibling
     u32* prog;
     int pace;
+    // screening scan, K-split form only (kv == 1; scan_screen.hip): candidate slots in global memory, [parts][nq][RMU_KS_CAP] keys.  Needs no
+    // initialisation (the slot counts live in registers); contents are dead once the launch has written its partials
+    u64* gcand;
 };
+#define RMU_KS_CAP 40
 
 int rmu_scan_plan(ScanLaunch* p);                        // chooses geometry; returns 0 or RMU_E_INVALID
 int rmu_scan_launch(const ScanLaunch* p, hipStream_t s); // launches the fused scan

@@ -202,6 +202,13 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
 #pragma unroll
         for (int T = 0; T < S_TS; ++T) qh[g][T] = *(const f16x8*)(qrow + T * 32);
     }
+    // The loads must be COMPLETE, as far as the compiler's wait-count pass can tell, before the first LDS-DMA is issued: it cannot count
+    // through the ring's inline-asm waits, so a query fragment still "pending" at the loop head gets an s_waitcnt vmcnt(0) in front of its
+    // first MFMA -- inside the loop, draining the DMA ring once per trip (found in round 4: both tile-loop kernels had it).
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) asm volatile("" : "+v"(qh[g][T]));
 
     // ---- DMA source map: LDS unit f -> row f/24, physical unit f%24 holds logical unit p ^ ((row >> 1) & 7).  LDS rows are
     // 384 B = 96 banks apart, so rows alternate between two bank halves; the XOR spreads 8 row pairs over the 8 units of an
@@ -623,6 +630,873 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
     }
 }
 
+// ---- K-SPLIT form of the screening scan (round 4; full 256-query tiles) --------------------------------------------------------------
+// What bounds the 8-wave kernel above is the LDS return path, not the matrix pipe: 128 B/clk per CU = 32 B/clk per SIMD, and ONE 1-KiB A
+// fragment per 32-cycle MFMA is exactly that rate (measured with the ping-pong form: 8 cycles per KiB and CU): 0.59 MFMA busy.  Feeding
+// two MFMAs from every fragment needs 64 queries per wave -- 192 registers of query fragments, which only fits one wave per SIMD (the
+// 4-wave G = 2 form: issue-bound, 0.35).  Here the two waves of a SIMD pair (w, w + 4) hold the SAME 64 queries and split K instead: wave
+// half sh reads only the half-k chunk sh of every row tile (12 fragments, 12 KiB) and multiplies it with its k half of both 32-query groups
+// -- 96 registers of query fragments, 24 MFMAs per 12 fragment reads, two waves per SIMD.  The price is an exchange: each wave keeps the
+// partial sums of the group it OWNS (group sh of the pair) and hands the other group's 32 x 32 partials to its partner through 4 KiB of
+// LDS (16 KiB of LDS traffic per tile and wave in all instead of 24), one tile behind the MFMAs:
+//   tile t, behind ring barrier A : ds_write the send-partials of tile t - 1                     (the partner has finished reading t - 2's)
+//   step 5, behind barrier B      : ds_read the partner's partials of tile t - 1                 (waited for by the counted wait of step 9)
+//   steps 9-11                    : full score = own partial + partner's; 16 compares against the lane's threshold; ONE branch
+// fp32 addition of two 192-term fp32 sums instead of one 384-term chain: the same 408 * 2^-24 bound as in the header.
+// The 80 KiB of LDS candidate slots do not fit beside a ring deep enough for the faster tiles (4 tiles = 96 KiB) and the exchange area, so
+// candidates live in GLOBAL memory (a.gcand: [chunk][query][CAP] keys, L2 resident): both lanes (j, j + 32) of a query belong to the one
+// wave that filters it, so the slot count is a REGISTER (kept equal in both lanes through one shuffle per append) and an append is a
+// fire-and-forget global store -- no LDS atomic, no wait; compaction (a slot of 40 full: never in a seeded launch) and the final emit read
+// the slot back past the vector L1.
+struct KsCfg {
+    static constexpr int NW = 8, NR = 8, NDW = 6, NIW = 4;   // ring: 4 tiles x 2 half-k chunks; six waves carry the 24 DMA pieces of a tile
+    static constexpr int CAP = RMU_KS_CAP;
+    static constexpr int RING_BYTES = NR * S_SLOT;
+    static constexpr int XCH_OFF = RING_BYTES;               // 8 x 4 KiB: a wave's partial sums for its partner's queries
+    static constexpr int GT_OFF = XCH_OFF + NW * 4096;
+    static constexpr int LDS_BYTES = GT_OFF + NW * 256;
+};
+static_assert(KsCfg::LDS_BYTES <= 160 * 1024, "LDS");
+
+template <int EXP = 0>
+__global__ __launch_bounds__(512) void scan_screen_ks_kernel(const ScanLaunch a) {
+    using C = KsCfg;
+    constexpr bool DBG = (EXP & 4) != 0;
+    constexpr int PRE = 4;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int pr = w & 3, sh = w >> 2;                    // query pair of the workgroup's four; k half
+    int s_idx, qt;
+    {
+        const int b = blockIdx.x;
+        if ((a.s_chunks & 7) == 0) {
+            const int xcd = b & 7, m = b >> 3;
+            qt = m % a.nqt;
+            s_idx = (m / a.nqt) * 8 + xcd;
+        } else {
+            qt = b % a.nqt;
+            s_idx = b / a.nqt;
+        }
+    }
+    const int64_t tiles_total = (a.n_rows + S_RT - 1) / S_RT;
+    const int64_t t0 = (int64_t)s_idx * a.tiles_per_chunk;
+    int64_t t1 = t0 + a.tiles_per_chunk;
+    if (t1 > tiles_total) t1 = tiles_total;
+    const int ntiles = (int)(t1 > t0 ? t1 - t0 : 0);
+    const char* img = (const char*)a.x + a.row0 * (int64_t)IMGB;
+    char* ring = ssm;
+    const int q_own = qt * 256 + 64 * pr + 32 * sh;       // lanes j and j + 32 filter query q_own + j (group 0 of this wave's MFMAs) ...
+    const int q_oth = qt * 256 + 64 * pr + 32 * (1 - sh); // ... and group 1 are the partner's queries
+    const bool q_ok = q_own + j < a.nq;
+    float thr_loc = q_ok ? -INFINITY : INFINITY, thr_g = -INFINITY, thr_s = thr_loc;
+    u32* gthr_w = a.gthr + q_own;
+    const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
+    u32 cnt = 0;                                          // entries in this lane's query slot (equal in lanes j and j + 32)
+    u64* const gslot = a.gcand + ((size_t)s_idx * a.nq + (q_ok ? q_own + j : 0)) * C::CAP;
+    // sibling pacing: as in scan_screen_kernel (the last wave carries no corpus DMA)
+    const bool pace_on = a.prog != nullptr;
+    u32* prog_w = a.prog + (size_t)s_idx * 4;
+    bool pace_live = pace_on;
+    const u32* gsrc = gthr_w + j;
+    if (pace_on && lane >= 32 && lane < 36) gsrc = prog_w + (lane - 32);
+    auto refresh_gthr = [&]() {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
+    };
+    constexpr int PW = C::NW - 1;
+    auto pace_step = [&](int tile) {
+        if (lane == 0) __hip_atomic_store(prog_w + qt, ~(u32)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 m4 = max(max(gt_lds[32], gt_lds[33]), max(gt_lds[34], gt_lds[35]));
+        int lead = m4 ? tile - (int)~m4 : -1;
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(lead) > a.pace, 0)) {
+            int spins = 0;
+            do {
+                __builtin_amdgcn_s_sleep(24);
+                u32 v = 0;
+                if (lane < 4) v = __hip_atomic_load(prog_w + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = max(v, (u32)__shfl_xor((int)v, 1));
+                v = max(v, (u32)__shfl_xor((int)v, 2));
+                const u32 vm = (u32)__builtin_amdgcn_readfirstlane((int)v);
+                lead = vm ? tile - (int)~vm : -1;
+            } while (lead > a.pace && ++spins < 400);
+            if (spins >= 400) pace_live = false;
+        }
+    };
+
+    // ---- query fragments: this wave's k half (192 of 384) of both groups; step T covers k [192 sh + 16 T, + 16), lane half h owns 8 of them
+    f16x8 qh[2][S_CS];
+    {
+        const int qa = q_ok ? q_own + j : 0, qb = q_oth + j < a.nq ? q_oth + j : 0;
+        const char* ra = (const char*)a.q + (size_t)qa * IMGB + sh * S_CKB + h * 16;
+        const char* rb_ = (const char*)a.q + (size_t)qb * IMGB + sh * S_CKB + h * 16;
+#pragma unroll
+        for (int T = 0; T < S_CS; ++T) {
+            qh[0][T] = *(const f16x8*)(ra + T * 32);
+            qh[1][T] = *(const f16x8*)(rb_ + T * 32);
+        }
+#pragma unroll
+        for (int T = 0; T < S_CS; ++T) asm volatile("" : "+v"(qh[0][T]), "+v"(qh[1][T]));   // complete before any LDS-DMA (see scan_screen_kernel)
+    }
+    // ---- DMA map (six waves, four 1-KiB pieces of a tile each): piece id = n * 6 + w in 0..23 = 12 * chunk + piece of the chunk; the slot
+    // layout and its swizzle are the ones of scan_screen_kernel
+    u32 dma_off[C::NIW];
+    int dma_dst[C::NIW];
+#pragma unroll
+    for (int n = 0; n < C::NIW; ++n) {
+        const int id = n * C::NDW + (w < C::NDW ? w : 0);
+        const int half = id / 12, pid = id % 12;
+        const int f = pid * 64 + lane;
+        const int i = f / S_U16, p = f % S_U16;
+        dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16 + half * S_CKB);
+        dma_dst[n] = half * S_SLOT + pid * 1024;
+    }
+    auto issue_piece = [&](int tl, int n) {               // piece n of this wave, tile tl of the workgroup's chunk
+        if (EXP & 1) return;
+        if (w >= C::NDW) return;                          // (uniform)
+        const int te = tl < ntiles ? tl : ntiles - 1;     // past the end: a harmless reload keeps the vmcnt arithmetic uniform
+        const char* sbase = img + ((t0 + te) * S_RT) * (int64_t)IMGB;
+        char* dst = ring + ((2 * tl) & (C::NR - 1)) * S_SLOT + dma_dst[n];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    int abase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) abase[m] = j * S_CKB + (((2 * m + h) ^ ((j >> 1) & 7)) * 16);
+    f16x8 fr[PRE];
+#pragma unroll
+    for (int m = 0; m < PRE; ++m) fr[m] = f16x8{};
+    const u32 ring_addr = lds_addr(ring);
+    auto read_frag = [&](f16x8& dst, int slot_off, int t) {
+        if (EXP & 2) { asm volatile("" : "+v"(dst)); return; }
+        const u32 addr = ring_addr + (u32)(abase[t & 3] + slot_off);
+        if ((t >> 2) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+        else if ((t >> 2) == 1) asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(dst) : "v"(addr));
+        else asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dst) : "v"(addr));
+    };
+    const u32 xw_addr = lds_addr(ssm + C::XCH_OFF + w * 4096) + lane * 16u;            // mine to write
+    const u32 xr_addr = lds_addr(ssm + C::XCH_OFF + (w ^ 4) * 4096) + lane * 16u;      // my partner's to read
+    auto xch_write = [&](const f32x16& v) {
+        const f32x4 p0 = {v[0], v[1], v[2], v[3]}, p1 = {v[4], v[5], v[6], v[7]}, p2 = {v[8], v[9], v[10], v[11]}, p3 = {v[12], v[13], v[14], v[15]};
+        asm volatile("s_nop 7\n\ts_nop 7\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\tds_write_b128 %0, %3 offset:2048\n\t"
+                     "ds_write_b128 %0, %4 offset:3072\n\ts_nop 1" ::"v"(xw_addr), "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+    };
+    f32x4 xr[4];
+    auto xch_read = [&]() {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=v"(xr[0]), "=v"(xr[1]), "=v"(xr[2]), "=v"(xr[3]) : "v"(xr_addr));
+    };
+    auto set_thr = [&]() { thr_s = fmaxf(thr_loc, thr_g) * 4096.0f; };
+
+    u32 d_slow = 0, d_comp = 0, d_app = 0;
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_b2 = 0, d_clk_vm = 0, d_clk_all = DBG ? clock64() : 0;
+    // keep the best K' of query lane jj's slot (sorted), raise its threshold, publish it: the whole wave works on one slot
+    auto compact = [&](int jj) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's appends are in L2
+        const u32 n = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
+        u64* slot = (u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
+                           (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
+        u64 key[1];
+        u32 rank[1];
+        // (every VMEM operation of the slow path is inline asm: one the compiler can see puts an s_waitcnt vmcnt(0) in front of the tile loop's
+        // first MFMA -- the join of this path -- and drains the DMA ring once per tile)
+        key[0] = 0ull;
+        if ((u32)lane < n) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(key[0]) : "v"(slot + lane) : "memory");
+        rank_keys<1>(key, n, rank);
+        const bool keep = (u32)lane < n && rank[0] < (u32)a.k;
+        if (keep) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(slot + rank[0]), "v"(key[0]) : "memory");
+        const u64 kb = __ballot(keep && rank[0] == (u32)(a.k - 1));
+        if (kb) {
+            const int src = __builtin_ctzll(kb);
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(key[0] >> 32), src);
+            if (j == jj) thr_loc = rmu_ord2f(hi);
+            if (lane == 0) asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(gthr_w + jj), "v"(hi) : "memory");
+        }
+        if (j == jj) cnt = n < (u32)a.k ? n : (u32)a.k;
+        set_thr();
+        if (DBG) ++d_comp;
+    };
+    // append the passing scores of one tile: pf = 4096 * s~ of rows rbase + (r & 3) + 8 (r >> 2), `inmask` = slots inside the range
+    auto slow_path = [&](const float (&pf)[16], int64_t rbase, u32 inmask) {
+        unsigned long long c0 = 0;
+        u32 todo = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) todo |= (pf[r] > thr_s) ? (1u << r) : 0u;
+        todo &= inmask;
+        if (DBG) { ++d_slow; d_app += __builtin_popcount(todo); c0 = clock64(); }
+        u32 uni = 0;
+        for (u64 bl = __ballot(todo != 0); bl; bl &= bl - 1) uni |= (u32)__builtin_amdgcn_readlane((int)todo, __builtin_ctzll(bl));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((uni >> r) & 1u) {                                              // scalar test: most slots are skipped
+                bool has = ((todo >> r) & 1u) && pf[r] > thr_s;                 // (a compaction in this call may have raised the threshold)
+                u32 other = (u32)__shfl_xor((int)has, 32);
+                u64 full = __ballot(cnt + (u32)has + other > (u32)C::CAP);
+                if (__builtin_expect(full != 0, 0)) {
+                    for (u32 fm = (u32)full | (u32)(full >> 32); fm; fm &= fm - 1) compact(__builtin_ctz(fm));
+                    has = has && pf[r] > thr_s;
+                    other = (u32)__shfl_xor((int)has, 32);
+                }
+                const u32 pos = cnt + (h ? other : 0u);
+                if (has) {
+                    // (inline asm: a store the compiler can see gets an s_waitcnt vmcnt(0) in front of the next write of its data registers --
+                    // the first MFMA of the tile loop, where it drains the DMA ring once per trip; a 64-bit store has read its data when it issues)
+                    const u64 key = rmu_make_key(pf[r] * (1.0f / 4096.0f) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(gslot + pos), "v"(key) : "memory");
+                }
+                cnt += (u32)has + other;
+            }
+        }
+        if (DBG) d_clk_slow += clock64() - c0;
+    };
+
+    constexpr bool PP = (EXP & 16) != 0;
+    if constexpr (PP) {
+        // ---- PING-PONG over the K split: the two waves of a SIMD are also the two k halves, and they never do the same thing at the same time.
+        // X = waves 0-3 (k half 0), Y = waves 4-7 (k half 1).  A wave alternates a LOAD segment -- the 12 fragments of its half-k chunk into 48
+        // registers, the exchange (write its partner's partial sums of the tile it has just computed, read what the partner left), 16 sums +
+        // compares, thresholds -- with a COMPUTE segment of 24 back-to-back MFMAs with its DMA pieces in their shadow; X loads tile t in phase 2t
+        // and computes it in phase 2t + 1, Y one phase later; one s_barrier per phase.  The load segment moves 16 KiB through a SIMD's 32 B/clk
+        // LDS return path (~600 cycles) under the partner's 768 cycles of MFMA: the matrix pipe is the longer leg of every phase.
+        //   ring: chunk (t, half) is read by ONE group in ONE phase; its slot is refilled (tile t + 4) by the same waves in the compute segment
+        //   that follows -- no other wave ever touches it.
+        //   exchange: X writes its partial of tile t - 1 for Y's queries in load(t) (phase 2t), Y reads it in its load(t) (phase 2t + 1) and
+        //   filters tile t - 1 (own partial: the tile it computed last); Y writes in phase 2t + 1, X reads in load(t + 1) and filters tile t - 1
+        //   as well -- by then it has computed tile t on top, so its own partials alternate between two accumulators.
+        //   The loop runs two trips past the last tile (reads of a ring that is not refilled, results masked) so that every tile is filtered.
+        if (ntiles > 0) {
+            const int wi = w & 3;
+            u32 poff[3];
+            int pdst[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const int pid = n * 4 + wi;
+                const int f = pid * 64 + lane;
+                const int i = f / S_U16, p = f % S_U16;
+                poff[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16 + sh * S_CKB);
+                pdst[n] = sh * S_SLOT + pid * 1024;
+            }
+            auto issue_pp = [&](int tl, int n) {
+                const int te = tl < ntiles ? tl : ntiles - 1;
+                const char* sbase = img + ((t0 + te) * S_RT) * (int64_t)IMGB;
+                char* dst = ring + ((2 * tl) & (C::NR - 1)) * S_SLOT + pdst[n];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + poff[n]),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            };
+            // VMEM order of a wave: [PPP R] per tile (prologue: tiles 0-3, then tile it + 4 in compute(it)).  Behind compute(it) the pieces of tile
+            // it + 1 must have landed: 13 younger operations may still be in flight (R, PPP R, PPP R, PPP R); the same count holds for tile 0 here
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+#pragma unroll
+                for (int n = 0; n < 3; ++n) issue_pp(tl, n);
+                refresh_gthr();
+            }
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (sh) __builtin_amdgcn_s_barrier();          // Y runs one phase behind X
+            f16x8 fq[S_CS];
+            f32x16 oA, oB, c1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oA[r] = -INFINITY; oB[r] = -INFINITY; c1[r] = 0.f; }
+            const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
+            const int64_t row_end = a.row0 + a.n_rows;
+            u32 lastmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lastmask |= (lane_r0 + (int64_t)(ntiles - 1) * S_RT + (r & 3) + 8 * (r >> 2) < row_end) ? (1u << r) : 0u;
+            const int lag = sh ? 1 : 2;
+            // one trip: LOAD(it) | barrier | COMPUTE(it) | barrier.  cw = the own-partial accumulator this trip's MFMAs overwrite, co = the other
+            auto trip = [&](f32x16& cw, const f32x16& co, int it) {
+                unsigned long long ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0;
+                if (DBG) ck0 = clock64();
+                // ---- LOAD: exchange first (the partner's partials are what the filter waits for), then the 12 fragments with the 16 sums and ONE
+                // compare between them -- the LDS queue, not the issue port, paces this segment, so the VALU work rides in its stalls
+                xch_read();
+                xch_write(c1);
+                const int soff = (((2 * it) & (C::NR - 1)) + sh) * S_SLOT;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) read_frag(fq[t], soff, t);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
+                float pf[16];
+                if (sh) {                                  // Y: its own partials of tile it - 1 are the ones it computed last
+#pragma unroll
+                    for (int t = 4; t < S_CS; ++t) {
+                        read_frag(fq[t], soff, t);
+                        pf[2 * (t - 4)] = co[2 * (t - 4)] + xr[(t - 4) >> 1][(2 * (t - 4)) & 3];
+                        pf[2 * (t - 4) + 1] = co[2 * (t - 4) + 1] + xr[(t - 4) >> 1][(2 * (t - 4) + 1) & 3];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {                                   // X: of tile it - 2, in the accumulator it is about to overwrite
+#pragma unroll
+                    for (int t = 4; t < S_CS; ++t) {
+                        read_frag(fq[t], soff, t);
+                        pf[2 * (t - 4)] = cw[2 * (t - 4)] + xr[(t - 4) >> 1][(2 * (t - 4)) & 3];
+                        pf[2 * (t - 4) + 1] = cw[2 * (t - 4) + 1] + xr[(t - 4) >> 1][(2 * (t - 4) + 1) & 3];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                float mx = pf[0];                          // (v_max3: a NaN sum never wins, exactly as it never passes a compare)
+#pragma unroll
+                for (int r = 1; r < 15; r += 2) mx = fmaxf(mx, fmaxf(pf[r], pf[r + 1]));
+                mx = fmaxf(mx, pf[15]);
+                const int ft = it - lag;                   // the tile whose scores are complete now
+                if (!(a.share_thr & 2) && !(EXP & 8) && __builtin_expect(__ballot(mx > thr_s) != 0, 0)) {
+                    const u32 inmask = (ft < 0 || ft >= ntiles) ? 0u : (ft == ntiles - 1 ? lastmask : 0xffffu);
+                    if (inmask) slow_path(pf, lane_r0 + (int64_t)ft * S_RT, inmask);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int t = 0; t < S_CS; ++t) asm volatile("" : "+v"(fq[t]));
+                if (DBG) ck1 = clock64();
+                __builtin_amdgcn_sched_barrier(0);         // (no MFMA of the compute segment above the barrier)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (DBG) ck2 = clock64();
+                // ---- COMPUTE: 24 MFMAs, this wave's three DMA pieces of tile it + 4 and the threshold refresh in their shadow
+#pragma unroll
+                for (int t = 0; t < S_CS; ++t) {
+                    if (t == 0) {
+                        const f32x16 z = {};
+                        cw = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[t], qh[0][t], z, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[t], qh[1][t], z, 0, 0, 0);
+                    } else {
+                        cw = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[t], qh[0][t], cw, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq[t], qh[1][t], c1, 0, 0, 0);
+                    }
+                    if (t == 1 || t == 4 || t == 7) issue_pp(it + 4, (t - 1) / 3);
+                    if (t == 9) refresh_gthr();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {   // thresholds for the next load segment (the refresh of a trip ago has landed: counted wait below covers the NEXT one)
+                    const u32 go = gt_lds[j];
+                    thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
+                    set_thr();
+                    if (w == PW && pace_live && it + 1 < ntiles) pace_step(it + 1);
+                }
+                asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                if (DBG) { asm volatile("" : "+v"(cw), "+v"(c1)); ck3 = clock64(); }
+                __builtin_amdgcn_s_barrier();
+                if (DBG) { d_clk_vm += ck1 - ck0; d_clk_bar += ck2 - ck1; d_clk_b2 += ck3 - ck2; d_clk_slow += clock64() - ck3; }
+            };
+            const int nit = ntiles + 2;
+            for (int it = 0; it < nit; it += 2) {
+                trip(oA, oB, it);
+                if (it + 1 < nit) trip(oB, oA, it + 1);
+            }
+            if (!sh) __builtin_amdgcn_s_barrier();         // (X started one phase early)
+            if (pace_on && w == PW && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+    } else
+    if (ntiles > 0) {
+        refresh_gthr();                                    // oldest VMEM op: seeded / already published thresholds
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_piece(tl, n);
+        if (w < C::NDW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tiles 0 and 1
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int m = 0; m < PRE; ++m) read_frag(fr[m], sh * S_SLOT, m);
+        f32x16 accA0, accA1, accB0, accB1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accB0[r] = -INFINITY; accB1[r] = 0.f; accA0[r] = 0.f; accA1[r] = 0.f; }
+        const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
+        auto rb = [&](int t) { return lane_r0 + (int64_t)t * S_RT; };
+        // one tile: 12 steps of two MFMAs (own group into c0, the partner's into c1); p0 / p1 = the previous tile's own / send partials
+        auto tile_body = [&](f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, int tl) {
+            unsigned long long cb = 0;
+            if (DBG) cb = clock64();
+            // in flight at most: this wave's ops of the previous tile (4 pieces of tile tl + 2 and a threshold refresh | the refresh)
+            if (w < C::NDW) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (DBG) { const unsigned long long cv = clock64(); d_clk_vm += cv - cb; cb = cv; }
+            __builtin_amdgcn_s_barrier();                  // A: tile tl + 1 has landed; nobody reads tile tl - 1 or the exchange of tl - 2 any more
+            if (DBG) d_clk_bar += clock64() - cb;
+            {
+                const u32 go = gt_lds[j];
+                thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
+                set_thr();
+                if (w == PW && pace_live) pace_step(tl);
+            }
+            xch_write(p1);
+            const int cur_off = (((2 * tl) & (C::NR - 1)) + sh) * S_SLOT, nxt_off = (((2 * tl + 2) & (C::NR - 1)) + sh) * S_SLOT;
+            float pf[16];
+            u64 any_pass = 0;
+#pragma unroll
+            for (int t = 0; t < S_CS; ++t) {
+                if (t == 5) {
+                    unsigned long long cb2 = 0;
+                    if (DBG) cb2 = clock64();
+                    __builtin_amdgcn_s_barrier();          // B: the exchange writes of this tile (waited for at step 4) are visible
+                    if (DBG) d_clk_b2 += clock64() - cb2;
+                    xch_read();
+                }
+                if (!(EXP & 2)) {
+                    if (t == 9) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fr[t % PRE]), "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
+                    else if (t == 4 || t > 9) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fr[t % PRE]));
+                    else asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fr[t % PRE]));
+                }
+                if (t == 0) {
+                    const f32x16 z = {};
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t % PRE], qh[0][t], z, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t % PRE], qh[1][t], z, 0, 0, 0);
+                } else {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t % PRE], qh[0][t], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[t % PRE], qh[1][t], c1, 0, 0, 0);
+                }
+                if (t + PRE < S_CS) read_frag(fr[t % PRE], cur_off, t + PRE);
+                else read_frag(fr[t % PRE], nxt_off, t + PRE - S_CS);
+                if (t % 3 == 1) issue_piece(tl + 3, t / 3);                      // steps 1, 4, 7, 10
+                if (t == 3) refresh_gthr();
+                __builtin_amdgcn_sched_barrier(0);         // the scheduler otherwise bunches the counted waits of two or three steps in front of their MFMAs
+                if (t >= 9 && !(EXP & 8)) {                                     // 16 sums + compares over three steps
+                    constexpr int NPS = 6;
+#pragma unroll
+                    for (int r = (t - 9) * NPS; r < (t - 9) * NPS + NPS && r < 16; ++r) {
+                        pf[r] = p0[r] + xr[r >> 2][r & 3];
+                        any_pass |= __ballot(pf[r] > thr_s);
+                    }
+                }
+            }
+            if (!(a.share_thr & 2) && __builtin_expect(any_pass != 0, 0)) slow_path(pf, rb(tl - 1), 0xffffu);
+        };
+        for (int tl = 0; tl < ntiles; tl += 2) {           // two copies of the body: accumulator parity
+            tile_body(accA0, accA1, accB0, accB1, tl);        // (tile -1 = the -inf accumulators: nothing passes, whatever the exchange area holds)
+            if (tl + 1 < ntiles) tile_body(accB0, accB1, accA0, accA1, tl + 1);
+        }
+        if (pace_on && w == PW && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < PRE; ++m) asm volatile("" : "+v"(fr[m]));
+        {   // the last tile: exchange, sum, mask the rows past the range, filter
+            const bool last_in_a = ((ntiles - 1) & 1) == 0;
+            f32x16 own, snd;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { own[r] = last_in_a ? accA0[r] : accB0[r]; snd[r] = last_in_a ? accA1[r] : accB1[r]; }
+            __builtin_amdgcn_s_barrier();                  // everybody has read the exchange of the tile before
+            xch_write(snd);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            xch_read();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
+            const int64_t rbl = rb(ntiles - 1), row_end = a.row0 + a.n_rows;
+            float pf[16];
+            u32 inmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pf[r] = own[r] + xr[r >> 2][r & 3];
+                inmask |= (rbl + (r & 3) + 8 * (r >> 2) < row_end) ? (1u << r) : 0u;
+            }
+            if (!(a.share_thr & 2)) slow_path(pf, rbl, inmask);
+        }
+    }
+    if (DBG) {
+        u32 app = d_app;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) app += __shfl_xor(app, o);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)a.dbg + 0, (unsigned long long)d_slow);
+            atomicAdd((unsigned long long*)a.dbg + 1, (unsigned long long)d_comp);
+            atomicAdd((unsigned long long*)a.dbg + 2, (unsigned long long)app);
+            atomicAdd((unsigned long long*)a.dbg + 3, (unsigned long long)ntiles);
+            atomicAdd((unsigned long long*)a.dbg + 4, d_clk_b2);      // ("rounds" in the dump: cycles in barrier B)
+            atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
+            atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
+            atomicAdd((unsigned long long*)a.dbg + 8, d_clk_vm);
+            atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
+        }
+    }
+    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  Eight slots are read back per round trip.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int part = s_idx;
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+        if (q_own + j0 >= a.nq) break;
+        u64 key[8][1];
+        u32 nn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int jj = j0 + e;
+            nn[e] = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
+            const u64* slot = (const u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
+                                           (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
+            key[e][0] = (u32)lane < nn[e] ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int qq = q_own + j0 + e;
+            if (qq < a.nq) {
+                u32 rank[1];
+                rank_keys<1>(key[e], nn[e], rank);
+                u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+                if ((u32)lane < nn[e]) {
+                    if (rank[0] < (u32)a.k) dst[rank[0]] = key[e][0];
+                } else if (lane < a.k) {
+                    dst[lane] = 0ull;
+                }
+            }
+        }
+    }
+}
+
+// ---- 128 QUERIES PER WAVE (round 4; batches that fill 512-query tiles) -------------------------------------------------------------------
+// Both forms above are bound by what a 1-KiB A fragment costs to fetch from the LDS (~100 B/clk per CU, DMA writes included) against the one
+// or two 32-cycle MFMAs it feeds; the K-split pays for its second MFMA with an exchange and ends where it started.  The lever that is left
+// is register blocking: ONE wave per SIMD with the whole 512-register file (VGPRs + AGPRs), query fragments of FOUR 32-query groups in 384
+// of them, every fragment feeding four MFMAs (128 cycles of matrix work per ds_read_b128; 120 KiB of LDS traffic per 32 rows x 512 queries
+// instead of 2 x 216).  What made the 4-wave G = 2 form issue-bound -- ~10 other instructions per MFMA pair -- is ~5 per FOUR MFMAs here:
+//   - no second accumulator set: group g of the previous tile is filtered (v_max3 tree over its 16 scores, ONE compare) right before the
+//     first MFMA of the new tile overwrites it (zero C operand), in the shadow of group g - 1's MFMA;
+//   - candidates in global memory with the slot counts in registers, as in the K-split kernel (512 queries x 40 x 8 B do not fit the LDS).
+// 512 queries per workgroup: 1024 queries are 2 query tiles, so each image byte also crosses the L2 -> LDS path half as often.
+struct G4Cfg {
+    static constexpr int NW = 4, G = 4, QW = 128, NR = 5, NIW = 3;   // five 12-KiB half-k ring slots; three DMA pieces per wave and chunk
+    static constexpr int GR = 3;                             // groups whose query fragments live in registers (288); the fourth group's 24 KiB
+                                                             // per wave sit in the LDS and are streamed one step ahead like the row fragments:
+                                                             // 384 + 64 accumulator registers leave the allocator no room (72 spills into the loop)
+    static constexpr int CAP = RMU_KS_CAP;
+    static constexpr int RING_BYTES = NR * S_SLOT;
+    static constexpr int QL_OFF = RING_BYTES;                // [wave][step][lane] 16 B
+    static constexpr int QL_WAVE = S_TS * 1024;
+    static constexpr int GT_OFF = QL_OFF + NW * QL_WAVE;
+    static constexpr int LDS_BYTES = GT_OFF + NW * 512;
+};
+static_assert(G4Cfg::LDS_BYTES <= 160 * 1024, "LDS");
+
+struct G4Slow { u32 cnt; float thr_s; };
+// The append path of scan_screen_g4_kernel as a REAL call: inlined eight times into a kernel that keeps ~490 registers live it pushed the
+// allocator into spilling inside the tile loop; behind a call the saves and restores sit at the (rare) call site.
+// sc = 4096 * s~ of rows rbase + (r & 3) + 8 (r >> 2) for this lane's query; inmask = accumulator slots inside the row range; cn = entries in
+// the query's slot gs (equal in lanes j and j + 32), ts = 4096 * threshold.  Returns the new count and threshold.
+__device__ __attribute__((noinline)) G4Slow g4_slow(f32x16 sc, int64_t rbase, u32 inmask, u32 cn, float ts, u64* gs, u32* gthr_g, int k) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    u32 todo = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) todo |= (sc[r] > ts) ? (1u << r) : 0u;
+    todo &= inmask;
+    u32 uni = 0;
+    for (u64 bl = __ballot(todo != 0); bl; bl &= bl - 1) uni |= (u32)__builtin_amdgcn_readlane((int)todo, __builtin_ctzll(bl));
+    for (int r = 0; r < 16; ++r) {
+        if (!((uni >> r) & 1u)) continue;                                   // (uniform)
+        float v = sc[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) v = (r == e) ? sc[e] : v;              // (uniform select: no dynamic register index)
+        bool has = ((todo >> r) & 1u) && v > ts;
+        u32 other = (u32)__shfl_xor((int)has, 32);
+        const u64 full = __ballot(cn + (u32)has + other > (u32)G4Cfg::CAP);
+        if (__builtin_expect(full != 0, 0)) {
+            // keep the best K' of a full slot (sorted), raise its threshold, publish it: the whole wave works on one slot.  VMEM as inline asm
+            // with explicit waits (see scan_screen_ks_kernel)
+            for (u32 fm = (u32)full | (u32)(full >> 32); fm; fm &= fm - 1) {
+                const int jj = __builtin_ctz(fm);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const u32 n = (u32)__builtin_amdgcn_readlane((int)cn, jj);
+                u64* slot = (u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gs >> 32), jj) << 32) |
+                                   (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gs, jj));
+                u64 key[1];
+                u32 rank[1];
+                key[0] = 0ull;
+                if ((u32)lane < n) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(key[0]) : "v"(slot + lane) : "memory");
+                rank_keys<1>(key, n, rank);
+                const bool keep = (u32)lane < n && rank[0] < (u32)k;
+                if (keep) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(slot + rank[0]), "v"(key[0]) : "memory");
+                const u64 kb = __ballot(keep && rank[0] == (u32)(k - 1));
+                if (kb) {
+                    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(key[0] >> 32), __builtin_ctzll(kb));
+                    if (j == jj) ts = fmaxf(ts, rmu_ord2f(hi) * 4096.0f);
+                    if (lane == 0) asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(gthr_g + jj), "v"(hi) : "memory");
+                }
+                if (j == jj) cn = n < (u32)k ? n : (u32)k;
+            }
+            has = has && v > ts;
+            other = (u32)__shfl_xor((int)has, 32);
+        }
+        const u32 pos = cn + (h ? other : 0u);
+        if (has) {
+            const u64 key = rmu_make_key(v * (1.0f / 4096.0f) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+            asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(gs + pos), "v"(key) : "memory");
+        }
+        cn += (u32)has + other;
+    }
+    return G4Slow{cn, ts};
+}
+
+template <int EXP = 0>
+__global__ __launch_bounds__(256) void scan_screen_g4_kernel(const ScanLaunch a) {
+    using C = G4Cfg;
+    constexpr bool DBG = (EXP & 4) != 0;
+    constexpr int G = C::G, PRE = 3;                     // fragment buffers: this step's, the next one's (landed), the one after (in flight)
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    int s_idx, qt;
+    {
+        const int b = blockIdx.x;
+        if ((a.s_chunks & 7) == 0) {
+            const int xcd = b & 7, m = b >> 3;
+            qt = m % a.nqt;
+            s_idx = (m / a.nqt) * 8 + xcd;
+        } else {
+            qt = b % a.nqt;
+            s_idx = b / a.nqt;
+        }
+    }
+    const int64_t tiles_total = (a.n_rows + S_RT - 1) / S_RT;
+    const int64_t t0 = (int64_t)s_idx * a.tiles_per_chunk;
+    int64_t t1 = t0 + a.tiles_per_chunk;
+    if (t1 > tiles_total) t1 = tiles_total;
+    const int ntiles = (int)(t1 > t0 ? t1 - t0 : 0);
+    const char* img = (const char*)a.x + a.row0 * (int64_t)IMGB;
+    char* ring = ssm;
+    const int q_base = (qt * C::NW + w) * C::QW;          // group g, lanes j and j + 32: query q_base + 32 g + j
+    float thr_s[G];                                       // 4096 * max(own k-th best, shared threshold): only ever rises
+    u32 cnt[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        thr_s[g] = (q_base + 32 * g + j < a.nq) ? -INFINITY : INFINITY;
+        cnt[g] = 0;
+    }
+    u32* gthr_w = a.gthr + q_base;
+    const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 128;
+    // (queries past nq never append: their slot address is never used)
+    u64* const gslot0 = a.gcand + ((size_t)s_idx * a.nq + q_base + j) * C::CAP;
+    constexpr size_t GSTRIDE = (size_t)32 * C::CAP;       // keys between the slots of two groups
+    const u32* gsrc = gthr_w + lane;
+    auto refresh_gthr = [&]() {                           // two 4-byte LDS-DMAs: this wave's 128 shared thresholds
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 512), 4, 0, 16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + 64),
+                                         (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 512 + 256), 4, 0, 16);
+    };
+    f16x8 qh[C::GR][S_TS];
+    const u32 ql_addr = lds_addr(ssm + C::QL_OFF + w * C::QL_WAVE) + lane * 16u;
+    {   // the last group's fragments go to the LDS first (before any LDS-DMA is in flight: plain stores)
+        const int qi = q_base + 32 * C::GR + j;
+        const char* qrow = (const char*)a.q + (size_t)(qi < a.nq ? qi : 0) * IMGB + h * 16;
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) {
+            const f16x8 v = *(const f16x8*)(qrow + T * 32);
+            *(f16x8*)(ssm + C::QL_OFF + w * C::QL_WAVE + T * 1024 + lane * 16) = v;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < C::GR; ++g) {
+        const int qi = q_base + 32 * g + j;
+        const char* qrow = (const char*)a.q + (size_t)(qi < a.nq ? qi : 0) * IMGB + h * 16;
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) qh[g][T] = *(const f16x8*)(qrow + T * 32);
+    }
+#pragma unroll
+    for (int g = 0; g < C::GR; ++g)
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) asm volatile("" : "+v"(qh[g][T]));    // complete before any LDS-DMA (see scan_screen_kernel)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (each wave reads back only what it wrote)
+    u32 dma_off[C::NIW];
+#pragma unroll
+    for (int n = 0; n < C::NIW; ++n) {
+        const int f = (n * C::NW + w) * 64 + lane;
+        const int i = f / S_U16, p = f % S_U16;
+        dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16);
+    }
+    const int nchunks = 2 * ntiles;
+    auto issue_part = [&](int cc, int n) {
+        if (EXP & 1) return;
+        const int ce = cc < nchunks ? cc : nchunks - 1;
+        const char* sbase = img + ((t0 + (ce >> 1)) * S_RT) * (int64_t)IMGB + (ce & 1) * S_CKB;
+        char* slot = ring + (cc % C::NR) * S_SLOT;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + dma_off[n]),
+                                         (__attribute__((address_space(3))) void*)(slot + (n * C::NW + w) * 1024), 16, 0, 0);
+    };
+    int abase[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) abase[m] = j * S_CKB + (((2 * m + h) ^ ((j >> 1) & 7)) * 16);
+    f16x8 fr[PRE], qf[PRE];                              // row fragments and the LDS group's query fragments, PRE steps ahead
+#pragma unroll
+    for (int m = 0; m < PRE; ++m) { fr[m] = f16x8{}; qf[m] = f16x8{}; }
+    const u32 ring_addr = lds_addr(ring);
+    // step gs of the tile (0..23): its row fragment (chunk step t of the slot at slot_off) and the LDS group's query fragment
+    auto read_frag = [&](f16x8& dst, f16x8& qdst, int slot_off, int t, int gs) {
+        if (EXP & 2) { asm volatile("" : "+v"(dst), "+v"(qdst)); return; }
+        const u32 addr = ring_addr + (u32)(abase[t & 3] + slot_off);
+        if ((t >> 2) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+        else if ((t >> 2) == 1) asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(dst) : "v"(addr));
+        else asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dst) : "v"(addr));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qdst) : "v"(ql_addr), "n"(gs * 1024));
+    };
+    // A step first issues the reads of the step two ahead (into the buffer the PREVIOUS step's MFMAs have finished reading), then waits for its
+    // own pair: a single in-order wave per SIMD gets the full two steps = 256 cycles of MFMA issue between a read and its use (issued behind
+    // the step's MFMAs, ~100 cycles later, the same reads cost 3 ms of the 8.7-ms batch in exposed LDS latency)
+    auto frag_wait = [&](f16x8& f, f16x8& q) {           // two reads per step: the oldest pair has landed when 2 (PRE - 1) are in flight
+        if (EXP & 2) return;
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(q) : "n"(2 * (PRE - 1)));
+    };
+    u32 d_slow = 0, d_comp = 0, d_app = 0;
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_vm = 0, d_clk_all = DBG ? clock64() : 0;
+    constexpr int GRP = C::NIW;
+    constexpr int WAITN = GRP * (C::NR - 3);               // at a chunk's barrier only chunks >= cc + 2 may be in flight
+    if (ntiles > 0) {
+        refresh_gthr();
+#pragma unroll
+        for (int c0 = 0; c0 < C::NR - 1; ++c0)
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(c0, n);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP * (C::NR - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int m = 0; m < PRE - 1; ++m) read_frag(fr[m], qf[m], 0, m, m);
+        f32x16 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = -INFINITY;
+        const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
+        int cc = 0;
+        // The MFMAs are inline asm with register-class constraints: the accumulators (64) and the query fragments of group 0 and half of group 1 (144) sit
+        // in AGPRs and are read by the matrix core in place; left to itself the allocator treats AGPRs as a spill area for VGPR values (2.6
+        // v_accvgpr_read per MFMA, reloads behind s_waitcnt vmcnt(0) inside the tile loop).  Volatile asm keeps program order; an accumulator is
+        // read by VALU (filter) only three MFMAs = 96+ cycles after the last MFMA that wrote it.
+        auto mfma = [&](f32x16& c, const f16x8& fa, const f16x8& qb, int g, int gs) {
+            // (group 1: the allocator parks some of its fragments in the other register class and copies them over right in front of the
+            // MFMA -- v_accvgpr_write / _read -> MFMA source needs two wait states, which nobody inserts for inline asm: without the s_nop
+            // 20 of 1024 queries, all of group 1, lost a neighbour)
+            if (g == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(fa), "a"(qb));
+            else if (g == 1 && gs < S_CS) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(fa), "a"(qb));
+            else if (g == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(fa), "v"(qb));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(fa), "v"(qb));
+        };
+        auto mfma0 = [&](f32x16& c, const f16x8& fa, const f16x8& qb, int g) {
+            if (g < 2) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(fa), "a"(qb));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(fa), "v"(qb));
+        };
+        auto qfrag = [&](int g, int gs, const f16x8& streamed) -> const f16x8& { return g < C::GR ? qh[g < C::GR ? g : 0][gs] : streamed; };
+        // one half-k chunk: ring barrier, then 12 steps of four MFMAs; CI::value = chunk parity (compile time: it selects the query fragments)
+        auto chunk = [&](auto CI, int tl) {
+            constexpr int c = decltype(CI)::value;
+            unsigned long long cb = 0;
+            if (DBG) cb = clock64();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+            if (DBG) { const unsigned long long cv = clock64(); d_clk_vm += cv - cb; cb = cv; }
+            __builtin_amdgcn_s_barrier();
+            if (DBG) d_clk_bar += clock64() - cb;
+            if (c == 0) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const u32 go = gt_lds[32 * g + j];
+                    if (go && (a.share_thr & 1)) thr_s[g] = fmaxf(thr_s[g], rmu_ord2f(go - 1u) * 4096.0f);
+                }
+            } else {
+                refresh_gthr();
+            }
+            const int cur_off = (cc % C::NR) * S_SLOT, nxt_off = ((cc + 1) % C::NR) * S_SLOT;
+            if (c == 0) {
+                // step 0 (peeled: a full unroll of the step loop must not carry four copies of the slow path per step): each group's scores
+                // of the previous tile are filtered just before its accumulator starts over
+                read_frag(fr[(PRE - 1) % PRE], qf[(PRE - 1) % PRE], cur_off, PRE - 1, PRE - 1);
+                frag_wait(fr[0], qf[0]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (!(EXP & 8)) {
+                        float mx = acc[g][0];
+#pragma unroll
+                        for (int r = 1; r < 15; r += 2) mx = fmaxf(mx, fmaxf(acc[g][r], acc[g][r + 1]));
+                        mx = fmaxf(mx, acc[g][15]);
+                        if (!(a.share_thr & 2) && __builtin_expect(__ballot(mx > thr_s[g]) != 0, 0)) {
+                            const G4Slow u = g4_slow(acc[g], lane_r0 + (int64_t)(tl - 1) * S_RT, 0xffffu, cnt[g], thr_s[g], gslot0 + g * GSTRIDE,
+                                                     gthr_w + 32 * g, a.k);
+                            cnt[g] = u.cnt; thr_s[g] = u.thr_s;
+                            if (DBG) ++d_slow;
+                        }
+                    }
+                    mfma0(acc[g], fr[0], qfrag(g, 0, qf[0]), g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = (c == 0 ? 1 : 0); t < S_CS; ++t) {
+                constexpr int base = c * S_CS;
+                constexpr int AH = PRE - 1;                                  // steps ahead
+                if (t + AH < S_CS) read_frag(fr[(base + t + AH) % PRE], qf[(base + t + AH) % PRE], cur_off, t + AH, (base + t + AH) % S_TS);
+                else read_frag(fr[(base + t + AH) % PRE], qf[(base + t + AH) % PRE], nxt_off, t + AH - S_CS, (base + t + AH) % S_TS);
+                frag_wait(fr[(base + t) % PRE], qf[(base + t) % PRE]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) mfma(acc[g], fr[(base + t) % PRE], qfrag(g, base + t, qf[(base + t) % PRE]), g, base + t);
+                if (t % 4 == 1) issue_part(cc + C::NR - 1, t / 4);          // steps 1, 5, 9: this wave's DMA pieces of the chunk
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ++cc;
+        };
+        for (int tl = 0; tl < ntiles; ++tl) {
+            chunk(std::integral_constant<int, 0>{}, tl);
+            chunk(std::integral_constant<int, 1>{}, tl);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < PRE; ++m) asm volatile("" : "+v"(fr[m]), "+v"(qf[m]));
+        {   // the last tile: rows past the range are masked
+            const int64_t rbl = lane_r0 + (int64_t)(ntiles - 1) * S_RT, row_end = a.row0 + a.n_rows;
+            u32 inmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) inmask |= (rbl + (r & 3) + 8 * (r >> 2) < row_end) ? (1u << r) : 0u;
+            if (!(a.share_thr & 2)) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const G4Slow u = g4_slow(acc[g], rbl, inmask, cnt[g], thr_s[g], gslot0 + g * GSTRIDE, gthr_w + 32 * g, a.k);
+                    cnt[g] = u.cnt; thr_s[g] = u.thr_s;
+                }
+            }
+        }
+    }
+    if (DBG) {
+        u32 app = d_app;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) app += __shfl_xor(app, o);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)a.dbg + 0, (unsigned long long)d_slow);
+            atomicAdd((unsigned long long*)a.dbg + 1, (unsigned long long)d_comp);
+            atomicAdd((unsigned long long*)a.dbg + 2, (unsigned long long)app);
+            atomicAdd((unsigned long long*)a.dbg + 3, (unsigned long long)ntiles);
+            atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
+            atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
+            atomicAdd((unsigned long long*)a.dbg + 8, d_clk_vm);
+            atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
+        }
+    }
+    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  Eight slots are read back per round trip.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int part = s_idx;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const u64* gs = gslot0 + g * GSTRIDE;
+        for (int j0 = 0; j0 < 32; j0 += 8) {
+            if (q_base + 32 * g + j0 >= a.nq) break;
+            u64 key[8][1];
+            u32 nn[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int jj = j0 + e;
+                nn[e] = (u32)__builtin_amdgcn_readlane((int)cnt[g], jj);
+                const u64* slot = (const u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gs >> 32), jj) << 32) |
+                                               (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gs, jj));
+                key[e][0] = (u32)lane < nn[e] ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int qq = q_base + 32 * g + j0 + e;
+                if (qq < a.nq) {
+                    u32 rank[1];
+                    rank_keys<1>(key[e], nn[e], rank);
+                    u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+                    if ((u32)lane < nn[e]) {
+                        if (rank[0] < (u32)a.k) dst[rank[0]] = key[e][0];
+                    } else if (lane < a.k) {
+                        dst[lane] = 0ull;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // exact fp32 re-score of the K' candidates of each query, in the exact kernel's summation order:
 // for t in 0..47, c in 0..3: acc = fma(x[8t+c], q[8t+c], acc); acc = fma(x[8t+4+c], q[8t+4+c], acc)
 // (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain; lanes < 32 hold k = 8t+c, lanes >= 32 hold k = 8t+4+c).
@@ -715,10 +1589,21 @@ int rmu_screen_plan(ScanLaunch* p) {
     static const int force_g = getenv("RMU_SCREEN_G") ? atoi(getenv("RMU_SCREEN_G")) : 0;
     p->qg = force_g == 1 || force_g == 2 ? force_g : (p->nq > 128 ? 2 : 1);
     p->wq = 4; p->kv = 0;
+    // Round-4 experiments (debug builds only; all bit-identical to the product kernel, none faster -- DESIGN.md 4.5): RMU_SCREEN_G4=1 = one wave per
+    // SIMD, 128 queries per wave, four MFMAs per LDS fragment (scan_screen_g4_kernel, batches >= 512); RMU_SCREEN_KS=1 = K-split pairs
+    // (scan_screen_ks_kernel; RMU_SCREEN_KPP=0 for its interleaved form)
+#ifdef RMU_DEBUG_KERNELS
+    static const int g4 = getenv("RMU_SCREEN_G4") ? atoi(getenv("RMU_SCREEN_G4")) : 0;
+    static const int ks = getenv("RMU_SCREEN_KS") ? atoi(getenv("RMU_SCREEN_KS")) : 0;
+#else
+    constexpr int g4 = 0, ks = 0;
+#endif
+    const bool use_g4 = g4 && !force_g && p->nq >= 512;
     // full query tiles (> 128 queries): 8 waves x 32 queries (two waves per SIMD) instead of 4 x 64 -- RMU_SCREEN_W8=0 keeps the 4-wave form
     static const int w8 = getenv("RMU_SCREEN_W8") ? atoi(getenv("RMU_SCREEN_W8")) : 1;
     if (w8 && p->qg == 2 && !force_g) { p->qg = 1; p->wq = 8; }
-    const int qwg = p->wq == 8 ? 256 : 128 * p->qg;
+    if (use_g4) { p->qg = 4; p->wq = 4; }
+    const int qwg = use_g4 ? 512 : p->wq == 8 ? 256 : 128 * p->qg;
     p->nqt = (p->nq + qwg - 1) / qwg;
     const int64_t tiles_total = (p->n_rows + S_RT - 1) / S_RT;
     int best_s = 8;
@@ -740,7 +1625,8 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->parts = s;
     static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
-    p->lds_bytes = p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
+    p->kv = use_g4 ? 2 : (ks && p->wq == 8) ? 1 : 0;
+    p->lds_bytes = p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
     // sibling pacing (see the kernel): query tiles of a chunk on one XCD, 2..4 of them, the whole grid resident at once (these
     // kernels take > 80 KiB of LDS: one workgroup per CU), and enough tiles per workgroup for drift to matter
     // window in tiles (0 = off).  Measured (tools/pace_probe.py, 10M x 1024): 0 / 4 / 8 / 16 / 32 all 7.82-7.86 ms of scan kernels -- the pacing
@@ -757,7 +1643,49 @@ int rmu_screen_plan(ScanLaunch* p) {
     return RMU_OK;
 }
 
+#ifdef RMU_DEBUG_KERNELS
+template <int EXP>
+static int screen_launch_ks(const ScanLaunch* p, hipStream_t s) {
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_ks_kernel<EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          KsCfg::LDS_BYTES);
+    if (attr_rc != hipSuccess) return RMU_E_HIP;
+    if (!p->gcand) return RMU_E_INVALID;
+    hipLaunchKernelGGL((scan_screen_ks_kernel<EXP>), dim3(p->grid), dim3(512), KsCfg::LDS_BYTES, s, *p);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+
+template <int EXP>
+static int screen_launch_g4(const ScanLaunch* p, hipStream_t s) {
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_g4_kernel<EXP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          G4Cfg::LDS_BYTES);
+    if (attr_rc != hipSuccess) return RMU_E_HIP;
+    if (!p->gcand) return RMU_E_INVALID;
+    hipLaunchKernelGGL((scan_screen_g4_kernel<EXP>), dim3(p->grid), dim3(256), G4Cfg::LDS_BYTES, s, *p);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+#endif
+
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
+#ifdef RMU_DEBUG_KERNELS
+    if (p->kv == 2) {
+        if (p->dbg) return screen_launch_g4<4>(p, s);
+        static const int ex4 = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;   // timing ablations (wrong results)
+        if (ex4 == 1) return screen_launch_g4<1>(p, s);
+        if (ex4 == 2) return screen_launch_g4<2>(p, s);
+        if (ex4 == 3) return screen_launch_g4<3>(p, s);
+        if (ex4 == 8) return screen_launch_g4<8>(p, s);
+        if (ex4 == 11) return screen_launch_g4<11>(p, s);
+        return screen_launch_g4<0>(p, s);
+    }
+    if (p->kv == 1) {
+        if (p->dbg) return (getenv("RMU_SCREEN_KPP") && atoi(getenv("RMU_SCREEN_KPP")) == 0) ? screen_launch_ks<4>(p, s) : screen_launch_ks<20>(p, s);
+        static const int kpp = getenv("RMU_SCREEN_KPP") ? atoi(getenv("RMU_SCREEN_KPP")) : 1;
+        if (kpp) return screen_launch_ks<16>(p, s);
+        return screen_launch_ks<0>(p, s);
+    }
+#else
+    if (p->kv != 0) return RMU_E_INVALID;
+#endif
 #ifdef RMU_DEBUG_KERNELS      // timing ablations, ring / prefetch depth experiments, cycle counters (wrong results by design for EXP != 0):
                               // python -m ragmeup_amd.build --debug-kernels; tools/ablate_screen.sh
     static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;

@@ -13,6 +13,8 @@ ap.add_argument("--env", default="RMU_SCREEN_PP", help="switch that is read per 
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--save", default="", help="write the answers (scores, rows) of the last window here")
+ap.add_argument("--ref", default="", help="compare every window's answers with the ones saved here (another process / another kernel)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 idx = FlatIndex(384, capacity_hint=a.rows, device=0)
@@ -24,6 +26,8 @@ q = x[pick] + 0.1 * torch.randn((a.batch, 384), generator=g, dtype=torch.float32
 q /= q.norm(dim=1, keepdim=True)
 del x
 ref = None
+if a.ref:
+    ref = tuple(t.to(dev) for t in torch.load(a.ref, weights_only=True))
 for w in [int(v) for v in a.pace.split(",")]:
     os.environ[a.env] = str(w)   # NOTE: read once per process since the tuning ended: run one window per process
     for _ in range(3):
@@ -42,4 +46,6 @@ for w in [int(v) for v in a.pace.split(",")]:
     if ref is None:
         ref = (s.clone(), r.clone())
     same = bool(torch.equal(s, ref[0]) and torch.equal(r, ref[1]))
+    if a.save:
+        torch.save((s.cpu(), r.cpu()), a.save)
     print(f"{a.env}={w:3d}: step {ms:.3f} ms  scan kernels {sum(k)/len(k):.3f} ms  {a.batch/ms*1e3:.0f} qps  identical_to_first={same} screened={idx.last_screened()}", flush=True)
