@@ -630,6 +630,330 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
     }
 }
 
+// ---- the product kernel for full query tiles (8 waves x 32 queries), on an instruction diet (round 4) ------------------------------------
+// Same algorithm, layout, ring and filter semantics as scan_screen_kernel<1, .., NW = 8>; what changes is how many instructions a tile costs.
+// The counters of this round's experiments fit "32 cycles per MFMA + 6-11 per OTHER instruction of the wave" for every form tried, and
+// the round-3 kernel spends ~300 other instructions on 24 MFMAs -- half of them scalar arithmetic on the ring slot (cc % 6 by multiply-high,
+// 64-bit source pointers per DMA piece, clamps) and one v_add per fragment read.  Here the tile loop is unrolled over the ring's period
+// (6 chunks = 3 tiles, x 2 for the accumulator parity: six bodies) so that every ring slot is a compile-time constant:
+//   fragment reads   ds_read_b128 with the slot folded into the 16-bit offset field: no address arithmetic at all
+//   DMA pieces       LDS target = per-wave base + constant; source = ONE running 64-bit tile pointer (2 SALU per tile) + a per-lane 32-bit
+//                    offset that already contains the piece's look-ahead distance; no clamp -- the ring's look-ahead past the last tile
+//                    reads the image's slack rows (kSlackRows, zero-filled) or the next chunk's rows, and is never consumed
+//   filter           a running v_max3 over the previous tile's 16 scores (8 VALU) and ONE compare per tile instead of 16 v_cmp + 16 s_or
+struct LeanCfg : ScreenCfg<1, 0, 8> {};
+
+template <int EXP = 0>
+__global__ __launch_bounds__(512) void scan_screen_lean_kernel(const ScanLaunch a) {
+    using C = LeanCfg;
+    constexpr bool DBG = (EXP & 4) != 0;
+    constexpr int NW = 8, S_PRE = 4;
+    static_assert(C::NR == 6 && C::NDW == 6 && C::NIW == 2, "the unrolled ring below is written for 6 slots, 6 DMA waves x 2 pieces");
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    int s_idx, qt;
+    {
+        const int b = blockIdx.x;
+        if ((a.s_chunks & 7) == 0) {
+            const int xcd = b & 7, m = b >> 3;
+            qt = m % a.nqt;
+            s_idx = (m / a.nqt) * 8 + xcd;
+        } else {
+            qt = b % a.nqt;
+            s_idx = b / a.nqt;
+        }
+    }
+    const int64_t tiles_total = (a.n_rows + S_RT - 1) / S_RT;
+    const int64_t t0 = (int64_t)s_idx * a.tiles_per_chunk;
+    int64_t t1 = t0 + a.tiles_per_chunk;
+    if (t1 > tiles_total) t1 = tiles_total;
+    const int ntiles = (int)(t1 > t0 ? t1 - t0 : 0);
+    const char* img = (const char*)a.x + a.row0 * (int64_t)IMGB;
+    char* ring = ssm;
+    u64* cand_w = (u64*)(ssm + C::RING_BYTES) + (size_t)w * C::QW * C::CAP;
+    u32* cnt_w = (u32*)(ssm + C::CNT_OFF) + w * C::QW;
+    float* thr_w = (float*)(ssm + C::THR_OFF) + w * C::QW;
+    const int q_base = (qt * NW + w) * C::QW;
+    const bool q_ok = q_base + j < a.nq;
+    if (lane < C::QW) {
+        cnt_w[lane] = 0;
+        thr_w[lane] = (q_base + lane < a.nq) ? -INFINITY : INFINITY;
+    }
+    float thr_loc = q_ok ? -INFINITY : INFINITY, thr_g = -INFINITY, thr_s = thr_loc;
+    u32* gthr_w = a.gthr + q_base;
+    const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
+    const bool pace_on = a.prog != nullptr;               // sibling pacing: see scan_screen_kernel
+    u32* prog_w = a.prog + (size_t)s_idx * 4;
+    bool pace_live = pace_on;
+    const u32* gsrc = gthr_w + (lane & (C::QW - 1));
+    if (pace_on && lane >= 32 && lane < 36) gsrc = prog_w + (lane - 32);
+    auto refresh_gthr = [&]() {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
+    };
+    constexpr int PW = NW - 1;
+    auto pace_step = [&](int tile) {
+        if (lane == 0) __hip_atomic_store(prog_w + qt, ~(u32)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 m4 = max(max(gt_lds[32], gt_lds[33]), max(gt_lds[34], gt_lds[35]));
+        int lead = m4 ? tile - (int)~m4 : -1;
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(lead) > a.pace, 0)) {
+            int spins = 0;
+            do {
+                __builtin_amdgcn_s_sleep(24);
+                u32 v = 0;
+                if (lane < 4) v = __hip_atomic_load(prog_w + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = max(v, (u32)__shfl_xor((int)v, 1));
+                v = max(v, (u32)__shfl_xor((int)v, 2));
+                const u32 vm = (u32)__builtin_amdgcn_readfirstlane((int)v);
+                lead = vm ? tile - (int)~vm : -1;
+            } while (lead > a.pace && ++spins < 400);
+            if (spins >= 400) pace_live = false;
+        }
+    };
+    f16x8 qh[S_TS];
+    {
+        const char* qrow = (const char*)a.q + (size_t)(q_ok ? q_base + j : 0) * IMGB + h * 16;
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) qh[T] = *(const f16x8*)(qrow + T * 32);
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) asm volatile("" : "+v"(qh[T]));     // complete before any LDS-DMA (see scan_screen_kernel)
+    }
+    // DMA: wave w < 6 carries pieces w and 6 + w of every chunk.  A piece issued during chunk (tile t, half c) belongs to chunk 2t + c + 5:
+    // half c' = 1 - c of tile t + 2 + c, so its per-lane source offset from the CURRENT tile's base is a constant of (c, n)
+    u32 dma_off[2][C::NIW];
+#pragma unroll
+    for (int n = 0; n < C::NIW; ++n) {
+        const int f = (n * C::NDW + (w < C::NDW ? w : 0)) * 64 + lane;
+        const int i = f / S_U16, p = f % S_U16;
+        const u32 o = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16);
+        dma_off[0][n] = o + 2u * S_RT * IMGB + S_CKB;      // issued in a first half: second half of tile t + 2
+        dma_off[1][n] = o + 3u * S_RT * IMGB;              // issued in a second half: first half of tile t + 3
+    }
+    char* const lds_w = ring + (w < C::NDW ? w : 0) * 1024;                 // this wave's piece inside a slot (+ 6 KiB for its second piece)
+    const char* tp = img + (t0 * S_RT) * (int64_t)IMGB;                     // the current tile's rows (uniform)
+    // SLOT = ring slot the piece lands in (compile time)
+    auto issue_part = [&](auto SLOT, int c, int n) {
+        if (EXP & 1) return;
+        if (w >= C::NDW) return;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tp + dma_off[c][n]),
+                                         (__attribute__((address_space(3))) void*)(lds_w + decltype(SLOT)::value * S_SLOT + n * C::NDW * 1024), 16, 0, 0);
+    };
+    u32 ab[4];                                            // fragment (row j, step t) of slot s: ab[t & 3] + s * S_SLOT + (t >> 2) * 128
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ab[m] = lds_addr(ring) + (u32)(j * S_CKB + (((2 * m + h) ^ ((j >> 1) & 7)) * 16));
+    f16x8 fr[S_PRE];
+#pragma unroll
+    for (int m = 0; m < S_PRE; ++m) fr[m] = f16x8{};
+    auto read_frag = [&](f16x8& dst, auto OFF, int t) {
+        if (EXP & 2) { asm volatile("" : "+v"(dst)); return; }
+        const u32 ad = ab[t & 3];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(decltype(OFF)::value));
+    };
+    auto frag_wait = [&](f16x8& f) {
+        if (EXP & 2) return;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1));
+    };
+    const u32 cnt_addr = lds_addr(cnt_w + j), cand_addr = lds_addr(cand_w + j * C::CAP);
+    const u32 trash_addr = lds_addr(ssm + C::TRASH_OFF) + threadIdx.x * 8u;
+    auto set_thr = [&]() { thr_s = fmaxf(thr_loc, thr_g) * 4096.0f; };
+    auto check_compact = [&]() {
+        const u32 c = cnt_w[lane & (C::QW - 1)];
+        u64 mask = __ballot(c > (u32)(C::CAP - C::A));
+        mask = (u32)mask | (u32)(mask >> 32);
+        if (mask) {
+            while (mask) {
+                const int jj = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                compact_slot<C>(jj, cand_w, cnt_w, thr_w, a.k, lane, gthr_w);
+            }
+            thr_loc = thr_w[j];
+            set_thr();
+        }
+    };
+    constexpr int GRP = C::NIW;
+    constexpr int WAITN = GRP * (C::NR - 3);
+    u32 res_pos = 0;
+    u32 d_slow = 0, d_comp = 0, d_app = 0;
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_vm = 0, d_clk_all = DBG ? clock64() : 0;
+    // append the scores of one tile that pass (p = 4096 * s~; bits of `inmask` = accumulator slots inside the row range): as scan_screen_kernel
+    auto slow_path = [&](const f32x16& p, int64_t rbase, u32 inmask) {
+        unsigned long long c0 = 0;
+        u32 todo = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) todo |= (p[r] > thr_s) ? (1u << r) : 0u;
+        todo &= inmask;
+        if (DBG) { ++d_slow; d_app += __builtin_popcount(todo); c0 = clock64(); }
+        bool again;
+        do {
+            bool nearly_full = false;
+            u32 uni = 0;
+            for (u64 bl = __ballot(todo != 0); bl; bl &= bl - 1) uni |= (u32)__builtin_amdgcn_readlane((int)todo, __builtin_ctzll(bl));
+            u32 left = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((uni >> r) & 1u) {
+                    const bool has = (todo >> r) & 1u;
+                    const u64 key = rmu_make_key(p[r] * (1.0f / 4096.0f) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(res_pos) : "v"(cnt_addr), "v"(has ? 1u : 0u) : "memory");
+                    const bool fits = has && res_pos < (u32)C::CAP;
+                    lds_store_b64_nofence(fits ? cand_addr + res_pos * 8u : trash_addr, key);
+                    nearly_full |= has && res_pos >= (u32)(C::CAP - C::A);
+                    left |= (has && !fits) ? (1u << r) : 0u;
+                }
+            }
+            todo = left;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (__any(nearly_full)) {
+                check_compact();
+                if (DBG) ++d_comp;
+            }
+            again = todo != 0;
+        } while (__any(again));
+        if (DBG) d_clk_slow += clock64() - c0;
+    };
+    if (ntiles > 0) {
+        refresh_gthr();
+        {   // chunks 0..4 -> slots 0..4: the prologue's pieces sit at 0, 1 | 2 tile offsets that the per-lane constants do not cover
+            const char* tp0 = tp - (2 * S_RT * IMGB + S_CKB);          // so that dma_off[0] addresses (tile 0, half 0)
+            auto pro = [&](auto SLOT, const char* base, int c) {
+#pragma unroll
+                for (int n = 0; n < C::NIW; ++n) {
+                    if (w < C::NDW)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[c][n]),
+                                                         (__attribute__((address_space(3))) void*)(lds_w + decltype(SLOT)::value * S_SLOT + n * C::NDW * 1024), 16, 0, 0);
+                }
+            };
+            pro(std::integral_constant<int, 0>{}, tp0, 0);                                     // (tile 0, half 0)
+            pro(std::integral_constant<int, 1>{}, tp0 + S_CKB, 0);                             // (0, 1)
+            pro(std::integral_constant<int, 2>{}, tp0 + S_RT * IMGB, 0);                       // (1, 0)
+            pro(std::integral_constant<int, 3>{}, tp0 + S_RT * IMGB + S_CKB, 0);               // (1, 1)
+            pro(std::integral_constant<int, 4>{}, tp0 + 2 * S_RT * IMGB, 0);                   // (2, 0)
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP * (C::NR - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) {
+            if (!(EXP & 2)) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[m]) : "v"(ab[m]));
+        }
+        f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accB[r] = -INFINITY; accA[r] = 0.f; }
+        const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
+        // one tile; P = its position in the ring's three-tile period (compile time): its chunks sit in slots 2P and 2P + 1
+        auto tile_body = [&](auto PI, f32x16& acc, const f32x16& prev, int tl) {
+            constexpr int P = decltype(PI)::value;
+            float mx = -INFINITY;
+            auto half = [&](auto CI) {
+                constexpr int c = decltype(CI)::value;
+                unsigned long long cb = 0;
+                if (DBG) cb = clock64();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+                if (DBG) { const unsigned long long cv = clock64(); d_clk_vm += cv - cb; cb = cv; }
+                __builtin_amdgcn_s_barrier();
+                if (DBG) d_clk_bar += clock64() - cb;
+                if (c == 0) {
+                    const u32 go = gt_lds[j];
+                    thr_g = (go && (a.share_thr & 1)) ? rmu_ord2f(go - 1u) : -INFINITY;
+                    set_thr();
+                    if (w == PW && pace_live) pace_step(tl);
+                } else {
+                    refresh_gthr();
+                }
+                auto step = [&](auto TI) {
+                    constexpr int t = decltype(TI)::value % S_CS, cch = decltype(TI)::value / S_CS, gs = decltype(TI)::value;
+                    constexpr int cur = 2 * P + cch, nxt = (cur + 1) % C::NR, tgt = (cur + C::NR - 1) % C::NR;
+                    if (gs == 18 && !(a.share_thr & 2) && !(EXP & 8) && __builtin_expect(__ballot(mx > thr_s) != 0, 0))
+                        slow_path(prev, lane_r0 + (int64_t)(tl - 1) * S_RT, 0xffffu);
+                    frag_wait(fr[gs % S_PRE]);
+                    if (gs == 0) {
+                        const f32x16 z = {};
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], z, 0, 0, 0);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], acc, 0, 0, 0);
+                    }
+                    // (asm: fmaxf canonicalises both inputs first -- three instructions per pair; a NaN score loses v_max3 as it fails a compare)
+                    if (gs >= 1 && gs <= 8 && !(EXP & 8)) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(prev[2 * gs - 2]), "v"(prev[2 * gs - 1]));
+                    if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], std::integral_constant<int, cur * S_SLOT + ((t + S_PRE) >> 2) * 128>{}, t + S_PRE);
+                    else read_frag(fr[gs % S_PRE], std::integral_constant<int, nxt * S_SLOT + ((t + S_PRE - S_CS) >> 2) * 128>{}, t + S_PRE - S_CS);
+                    if (t % 4 == 1 && t / 4 < C::NIW) issue_part(std::integral_constant<int, tgt>{}, cch, t / 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                if (c == 0) {
+                    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+                    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+                    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+                    step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+                } else {
+                    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+                    step(std::integral_constant<int, 15>{}); step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
+                    step(std::integral_constant<int, 18>{}); step(std::integral_constant<int, 19>{}); step(std::integral_constant<int, 20>{});
+                    step(std::integral_constant<int, 21>{}); step(std::integral_constant<int, 22>{}); step(std::integral_constant<int, 23>{});
+                }
+            };
+            half(std::integral_constant<int, 0>{});
+            half(std::integral_constant<int, 1>{});
+            tp += S_RT * IMGB;
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        for (int tl = 0; tl < ntiles; tl += 6) {           // ring period (3 tiles) x accumulator parity (2): six bodies
+            tile_body(I0{}, accA, accB, tl);                 // (tile -1 = the -inf accumulators: nothing passes)
+            if (tl + 1 < ntiles) tile_body(I1{}, accB, accA, tl + 1);
+            if (tl + 2 < ntiles) tile_body(I2{}, accA, accB, tl + 2);
+            if (tl + 3 < ntiles) tile_body(I0{}, accB, accA, tl + 3);
+            if (tl + 4 < ntiles) tile_body(I1{}, accA, accB, tl + 4);
+            if (tl + 5 < ntiles) tile_body(I2{}, accB, accA, tl + 5);
+        }
+        if (pace_on && w == PW && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) asm volatile("" : "+v"(fr[m]));
+        {
+            const bool last_in_a = ((ntiles - 1) & 1) == 0;
+            f32x16 last;
+            const int64_t rbl = lane_r0 + (int64_t)(ntiles - 1) * S_RT, row_end = a.row0 + a.n_rows;
+            u32 inmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                last[r] = last_in_a ? accA[r] : accB[r];
+                inmask |= (rbl + (r & 3) + 8 * (r >> 2) < row_end) ? (1u << r) : 0u;
+            }
+            if (!(a.share_thr & 2)) slow_path(last, rbl, inmask);
+        }
+    }
+    if (DBG) {
+        u32 app = d_app;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) app += __shfl_xor(app, o);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)a.dbg + 0, (unsigned long long)d_slow);
+            atomicAdd((unsigned long long*)a.dbg + 1, (unsigned long long)d_comp);
+            atomicAdd((unsigned long long*)a.dbg + 2, (unsigned long long)app);
+            atomicAdd((unsigned long long*)a.dbg + 3, (unsigned long long)ntiles);
+            atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
+            atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
+            atomicAdd((unsigned long long*)a.dbg + 8, d_clk_vm);
+            atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
+        }
+    }
+    const int part = s_idx;
+    for (int jj = 0; jj < C::QW; ++jj) {
+        const int qq = q_base + jj;
+        if (qq >= a.nq) break;
+        const u32 n = cnt_w[jj];
+        u64 key[1];
+        u32 rank[1];
+        key[0] = ((u32)lane < n) ? cand_w[jj * C::CAP + lane] : 0ull;
+        rank_keys<1>(key, n, rank);
+        u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+        if ((u32)lane < n) {
+            if (rank[0] < (u32)a.k) dst[rank[0]] = key[0];
+        } else if (lane < a.k) {
+            dst[lane] = 0ull;
+        }
+    }
+}
+
 // ---- K-SPLIT form of the screening scan (round 4; full 256-query tiles) --------------------------------------------------------------
 // What bounds the 8-wave kernel above is the LDS return path, not the matrix pipe: 128 B/clk per CU = 32 B/clk per SIMD, and ONE 1-KiB A
 // fragment per 32-cycle MFMA is exactly that rate (measured with the ping-pong form: 8 cycles per KiB and CU): 0.59 MFMA busy.  Feeding
@@ -1717,6 +2041,23 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     }
 #endif
     if (p->wq == 8) {                                                                 // full query tiles: 8 waves x 32 queries
+        static const int lean = getenv("RMU_SCREEN_LEAN") ? atoi(getenv("RMU_SCREEN_LEAN")) : 1;   // 0: round 3's form of the same kernel
+        if (lean) {
+            static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                  LeanCfg::LDS_BYTES);
+            if (attr_rc != hipSuccess) return RMU_E_HIP;
+#ifdef RMU_DEBUG_KERNELS
+            if (p->dbg) {
+                static const hipError_t attr_d = hipFuncSetAttribute((const void*)scan_screen_lean_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                     LeanCfg::LDS_BYTES);
+                if (attr_d != hipSuccess) return RMU_E_HIP;
+                hipLaunchKernelGGL((scan_screen_lean_kernel<4>), dim3(p->grid), dim3(512), LeanCfg::LDS_BYTES, s, *p);
+                return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+            }
+#endif
+            hipLaunchKernelGGL((scan_screen_lean_kernel<0>), dim3(p->grid), dim3(512), LeanCfg::LDS_BYTES, s, *p);
+            return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+        }
 #ifdef RMU_DEBUG_KERNELS
         // the PING-PONG form (EXP bit 4; see the kernel): measured 8.27-8.32 ms of scan kernels per 10M x 1024 batch against 7.69-7.81 for the
         // interleaved form (compares in the compute segment; 9.3 with them in the load segment, 9.0-9.1 with the DMA there, 11.0 in the first cut)
