@@ -954,6 +954,642 @@ __global__ __launch_bounds__(512) void scan_screen_lean_kernel(const ScanLaunch 
     }
 }
 
+// ---- lean form, ONE barrier per tile (round 4) ----------------------------------------------------------------------------------------------
+// Debug counters of scan_screen_lean_kernel: 434 of a tile's ~2 400 cycles are spent waiting at its two ring barriers (six DMA waves, a pacing
+// wave and an idle one arrive at different times, twice per tile).  Half-k ring slots need a barrier per half because six slots hold only
+// three tiles; the 80 KiB of LDS candidate slots are what keeps the ring that small.  Here the candidates live in global memory as in the
+// K-split kernel (slot counts in registers, appends are fire-and-forget stores), the ring holds FOUR tiles (8 slots, 96 KiB) and is handed
+// over once per tile: at the barrier of tile t, tile t + 1 has landed (the fragment prefetch crosses into it), t + 2 is in flight, t + 3 is
+// issued during the tile into the slots of t - 1.  Four bodies (ring period 4 tiles, accumulator parity 2).
+struct Lean2Cfg {
+    static constexpr int NW = 8, QW = 32, NR = 8, NDW = 6, NIW = 4;
+    static constexpr int CAP = RMU_KS_CAP;
+    static constexpr int RING_BYTES = NR * S_SLOT;
+    static constexpr int GT_OFF = RING_BYTES;
+    static constexpr int LDS_BYTES = GT_OFF + NW * 256;
+};
+
+template <int EXP = 0>
+__global__ __launch_bounds__(512) void scan_screen_lean2_kernel(const ScanLaunch a) {
+    using C = Lean2Cfg;
+    constexpr bool DBG = (EXP & 4) != 0;
+    constexpr int NW = 8, S_PRE = 4;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    int s_idx, qt;
+    {
+        const int b = blockIdx.x;
+        if ((a.s_chunks & 7) == 0) {
+            const int xcd = b & 7, m = b >> 3;
+            qt = m % a.nqt;
+            s_idx = (m / a.nqt) * 8 + xcd;
+        } else {
+            qt = b % a.nqt;
+            s_idx = b / a.nqt;
+        }
+    }
+    const int64_t tiles_total = (a.n_rows + S_RT - 1) / S_RT;
+    const int64_t t0 = (int64_t)s_idx * a.tiles_per_chunk;
+    int64_t t1 = t0 + a.tiles_per_chunk;
+    if (t1 > tiles_total) t1 = tiles_total;
+    const int ntiles = (int)(t1 > t0 ? t1 - t0 : 0);
+    const char* img = (const char*)a.x + a.row0 * (int64_t)IMGB;
+    char* ring = ssm;
+    const int q_base = (qt * NW + w) * C::QW;
+    const bool q_ok = q_base + j < a.nq;
+    float thr_s = q_ok ? -INFINITY : INFINITY;            // 4096 * max(own k-th best, shared threshold): only ever rises
+    u32 cnt = 0;                                          // entries in this lane's query slot (equal in lanes j and j + 32)
+    u64* const gslot = a.gcand + ((size_t)s_idx * a.nq + (q_ok ? q_base + j : 0)) * C::CAP;
+    u32* gthr_w = a.gthr + q_base;
+    const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
+    const bool pace_on = a.prog != nullptr;               // sibling pacing: see scan_screen_kernel
+    u32* prog_w = a.prog + (size_t)s_idx * 4;
+    bool pace_live = pace_on;
+    const u32* gsrc = gthr_w + j;
+    if (pace_on && lane >= 32 && lane < 36) gsrc = prog_w + (lane - 32);
+    auto refresh_gthr = [&]() {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
+    };
+    constexpr int PW = NW - 1;
+    auto pace_step = [&](int tile) {
+        if (lane == 0) __hip_atomic_store(prog_w + qt, ~(u32)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 m4 = max(max(gt_lds[32], gt_lds[33]), max(gt_lds[34], gt_lds[35]));
+        int lead = m4 ? tile - (int)~m4 : -1;
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(lead) > a.pace, 0)) {
+            int spins = 0;
+            do {
+                __builtin_amdgcn_s_sleep(24);
+                u32 v = 0;
+                if (lane < 4) v = __hip_atomic_load(prog_w + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = max(v, (u32)__shfl_xor((int)v, 1));
+                v = max(v, (u32)__shfl_xor((int)v, 2));
+                const u32 vm = (u32)__builtin_amdgcn_readfirstlane((int)v);
+                lead = vm ? tile - (int)~vm : -1;
+            } while (lead > a.pace && ++spins < 400);
+            if (spins >= 400) pace_live = false;
+        }
+    };
+    f16x8 qh[S_TS];
+    {
+        const char* qrow = (const char*)a.q + (size_t)(q_ok ? q_base + j : 0) * IMGB + h * 16;
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) qh[T] = *(const f16x8*)(qrow + T * 32);
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) asm volatile("" : "+v"(qh[T]));     // complete before any LDS-DMA (see scan_screen_kernel)
+    }
+    // DMA: wave w < 6 carries pieces n * 6 + w (n = 0..3) of a tile's 24 = 12 * half + piece; issued during tile t they belong to tile t + 3
+    u32 dma_off[C::NIW];
+    int dma_dst[C::NIW];
+#pragma unroll
+    for (int n = 0; n < C::NIW; ++n) {
+        const int id = n * C::NDW + (w < C::NDW ? w : 0);
+        const int half = id / 12, pid = id % 12;
+        const int f = pid * 64 + lane;
+        const int i = f / S_U16, p = f % S_U16;
+        dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16 + half * S_CKB) + 3u * S_RT * IMGB;
+        dma_dst[n] = half * S_SLOT + pid * 1024;
+    }
+    const char* tp = img + (t0 * S_RT) * (int64_t)IMGB;   // the current tile's rows (uniform)
+    auto issue_part = [&](auto TS, const char* base, int n) {   // TS = ring position (0..3) of the tile the piece belongs to
+        if (EXP & 1) return;
+        if (w >= C::NDW) return;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[n]),
+                                         (__attribute__((address_space(3))) void*)(ring + decltype(TS)::value * 2 * S_SLOT + dma_dst[n]), 16, 0, 0);
+    };
+    u32 ab[4], ab_hi[4];                                  // (the offset field is 16 bits: slots 4..7 go through a second base)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        ab[m] = lds_addr(ring) + (u32)(j * S_CKB + (((2 * m + h) ^ ((j >> 1) & 7)) * 16));
+        ab_hi[m] = ab[m] + 4u * S_SLOT;
+    }
+    f16x8 fr[S_PRE];
+#pragma unroll
+    for (int m = 0; m < S_PRE; ++m) fr[m] = f16x8{};
+    auto read_frag = [&](f16x8& dst, auto OFF, int t) {
+        if (EXP & 2) { asm volatile("" : "+v"(dst)); return; }
+        constexpr int off = decltype(OFF)::value;
+        const u32 ad = off >= 4 * S_SLOT ? ab_hi[t & 3] : ab[t & 3];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(off >= 4 * S_SLOT ? off - 4 * S_SLOT : off));
+    };
+    auto frag_wait = [&](f16x8& f) {
+        if (EXP & 2) return;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1));
+    };
+    u32 d_slow = 0, d_comp = 0, d_app = 0;
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_vm = 0, d_clk_all = DBG ? clock64() : 0;
+    // keep the best K' of query lane jj's slot (sorted), raise its threshold, publish it (VMEM as inline asm: see scan_screen_ks_kernel)
+    auto compact = [&](int jj) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u32 n = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
+        u64* slot = (u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
+                           (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
+        u64 key[1];
+        u32 rank[1];
+        key[0] = 0ull;
+        if ((u32)lane < n) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(key[0]) : "v"(slot + lane) : "memory");
+        rank_keys<1>(key, n, rank);
+        const bool keep = (u32)lane < n && rank[0] < (u32)a.k;
+        if (keep) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(slot + rank[0]), "v"(key[0]) : "memory");
+        const u64 kb = __ballot(keep && rank[0] == (u32)(a.k - 1));
+        if (kb) {
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(key[0] >> 32), __builtin_ctzll(kb));
+            if (j == jj) thr_s = fmaxf(thr_s, rmu_ord2f(hi) * 4096.0f);
+            if (lane == 0) asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(gthr_w + jj), "v"(hi) : "memory");
+        }
+        if (j == jj) cnt = n < (u32)a.k ? n : (u32)a.k;
+        if (DBG) ++d_comp;
+    };
+    auto slow_path = [&](const f32x16& p, int64_t rbase, u32 inmask) {
+        unsigned long long c0 = 0;
+        u32 todo = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) todo |= (p[r] > thr_s) ? (1u << r) : 0u;
+        todo &= inmask;
+        if (DBG) { ++d_slow; d_app += __builtin_popcount(todo); c0 = clock64(); }
+        u32 uni = 0;
+        for (u64 bl = __ballot(todo != 0); bl; bl &= bl - 1) uni |= (u32)__builtin_amdgcn_readlane((int)todo, __builtin_ctzll(bl));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((uni >> r) & 1u) {
+                bool has = ((todo >> r) & 1u) && p[r] > thr_s;
+                u32 other = (u32)__shfl_xor((int)has, 32);
+                const u64 full = __ballot(cnt + (u32)has + other > (u32)C::CAP);
+                if (__builtin_expect(full != 0, 0)) {
+                    for (u32 fm = (u32)full | (u32)(full >> 32); fm; fm &= fm - 1) compact(__builtin_ctz(fm));
+                    has = has && p[r] > thr_s;
+                    other = (u32)__shfl_xor((int)has, 32);
+                }
+                const u32 pos = cnt + (h ? other : 0u);
+                if (has) {
+                    const u64 key = rmu_make_key(p[r] * (1.0f / 4096.0f) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(gslot + pos), "v"(key) : "memory");
+                }
+                cnt += (u32)has + other;
+            }
+        }
+        if (DBG) d_clk_slow += clock64() - c0;
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    if (ntiles > 0) {
+        refresh_gthr();
+        {
+            const char* b0 = tp - 3 * S_RT * IMGB;        // dma_off carries the in-loop look-ahead of three tiles
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(I0{}, b0, n);
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(I1{}, b0 + S_RT * IMGB, n);
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(I2{}, b0 + 2 * S_RT * IMGB, n);
+        }
+        if (w < C::NDW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tiles 0 and 1 (and the thresholds)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) {
+            if (!(EXP & 2)) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[m]) : "v"(ab[m]));
+        }
+        f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accB[r] = -INFINITY; accA[r] = 0.f; }
+        const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
+        // one tile; P = its position in the ring (compile time): its chunks sit in slots 2P and 2P + 1
+        auto tile_body = [&](auto PI, f32x16& acc, const f32x16& prev, int tl) {
+            constexpr int P = decltype(PI)::value;
+            unsigned long long cb = 0;
+            if (DBG) cb = clock64();
+            // in flight at most: this wave's operations of the previous tile (4 pieces of tile tl + 2 and a threshold refresh | the refresh)
+            if (w < C::NDW) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (DBG) { const unsigned long long cv = clock64(); d_clk_vm += cv - cb; cb = cv; }
+            __builtin_amdgcn_s_barrier();                  // tile tl + 1 has landed; nobody reads tile tl - 1 any more
+            if (DBG) d_clk_bar += clock64() - cb;
+            {
+                const u32 go = gt_lds[j];
+                if (go && (a.share_thr & 1)) thr_s = fmaxf(thr_s, rmu_ord2f(go - 1u) * 4096.0f);
+                if (w == PW && pace_live) pace_step(tl);
+            }
+            float mx = -INFINITY;
+            auto step = [&](auto TI) {
+                constexpr int gs = decltype(TI)::value, t = gs % S_CS, cch = gs / S_CS;
+                constexpr int cur = 2 * P + cch, nxt = (cur + 1) % C::NR;
+                if (gs == 18 && !(a.share_thr & 2) && !(EXP & 8) && __builtin_expect(__ballot(mx > thr_s) != 0, 0))
+                    slow_path(prev, lane_r0 + (int64_t)(tl - 1) * S_RT, 0xffffu);
+                frag_wait(fr[gs % S_PRE]);
+                if (gs == 0) {
+                    const f32x16 z = {};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], z, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], acc, 0, 0, 0);
+                }
+                if (gs >= 1 && gs <= 8 && !(EXP & 8)) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(prev[2 * gs - 2]), "v"(prev[2 * gs - 1]));
+                if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], std::integral_constant<int, cur * S_SLOT + ((t + S_PRE) >> 2) * 128>{}, t + S_PRE);
+                else read_frag(fr[gs % S_PRE], std::integral_constant<int, nxt * S_SLOT + ((t + S_PRE - S_CS) >> 2) * 128>{}, t + S_PRE - S_CS);
+                if (gs % 6 == 1) issue_part(std::integral_constant<int, (P + 3) & 3>{}, tp, gs / 6);      // steps 1, 7, 13, 19
+                if (gs == 4) refresh_gthr();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+            step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+            step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+            step(std::integral_constant<int, 15>{}); step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
+            step(std::integral_constant<int, 18>{}); step(std::integral_constant<int, 19>{}); step(std::integral_constant<int, 20>{});
+            step(std::integral_constant<int, 21>{}); step(std::integral_constant<int, 22>{}); step(std::integral_constant<int, 23>{});
+            tp += S_RT * IMGB;
+        };
+        for (int tl = 0; tl < ntiles; tl += 4) {           // ring period: four bodies (the accumulator parity alternates with it)
+            tile_body(I0{}, accA, accB, tl);                 // (tile -1 = the -inf accumulators: nothing passes)
+            if (tl + 1 < ntiles) tile_body(I1{}, accB, accA, tl + 1);
+            if (tl + 2 < ntiles) tile_body(I2{}, accA, accB, tl + 2);
+            if (tl + 3 < ntiles) tile_body(I3{}, accB, accA, tl + 3);
+        }
+        if (pace_on && w == PW && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) asm volatile("" : "+v"(fr[m]));
+        {
+            const bool last_in_a = ((ntiles - 1) & 1) == 0;
+            f32x16 last;
+            const int64_t rbl = lane_r0 + (int64_t)(ntiles - 1) * S_RT, row_end = a.row0 + a.n_rows;
+            u32 inmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                last[r] = last_in_a ? accA[r] : accB[r];
+                inmask |= (rbl + (r & 3) + 8 * (r >> 2) < row_end) ? (1u << r) : 0u;
+            }
+            if (!(a.share_thr & 2)) slow_path(last, rbl, inmask);
+        }
+    }
+    if (DBG) {
+        u32 app = d_app;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) app += __shfl_xor(app, o);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)a.dbg + 0, (unsigned long long)d_slow);
+            atomicAdd((unsigned long long*)a.dbg + 1, (unsigned long long)d_comp);
+            atomicAdd((unsigned long long*)a.dbg + 2, (unsigned long long)app);
+            atomicAdd((unsigned long long*)a.dbg + 3, (unsigned long long)ntiles);
+            atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
+            atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
+            atomicAdd((unsigned long long*)a.dbg + 8, d_clk_vm);
+            atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
+        }
+    }
+    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  Eight slots are read back per round trip.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int part = s_idx;
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+        if (q_base + j0 >= a.nq) break;
+        u64 key[8][1];
+        u32 nn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int jj = j0 + e;
+            nn[e] = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
+            const u64* slot = (const u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
+                                           (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
+            key[e][0] = (u32)lane < nn[e] ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int qq = q_base + j0 + e;
+            if (qq < a.nq) {
+                u32 rank[1];
+                rank_keys<1>(key[e], nn[e], rank);
+                u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+                if ((u32)lane < nn[e]) {
+                    if (rank[0] < (u32)a.k) dst[rank[0]] = key[e][0];
+                } else if (lane < a.k) {
+                    dst[lane] = 0ull;
+                }
+            }
+        }
+    }
+}
+
+// ---- lean form, one barrier per TWO tiles (round 4) ----------------------------------------------------------------------------------------------
+// scan_screen_lean2_kernel still waits 354 cycles per tile at its one barrier: eight waves with per-tile jitter, six of them carrying the DMA.
+// Here the ring holds SIX tiles (12 slots, 144 KiB -- the LDS has nothing else to hold), is handed over once per PAIR of tiles, and every wave
+// carries three of a tile's 24 DMA pieces (the pacing store of the last wave is a plain store issued a whole pair before the next counted
+// wait: it cannot hold the ring up).  At the barrier of pair p the tiles up to 2p + 2 have landed (the fragment prefetch crosses into the
+// next pair's first tile), 2p + 3 may be in flight, and pair p + 2 is issued during pair p into the slots of pair p - 1.  Six bodies.
+struct Lean3Cfg {
+    static constexpr int NW = 8, QW = 32, NR = 12, NDW = 8, NIW = 3;
+    static constexpr int CAP = RMU_KS_CAP;
+    static constexpr int RING_BYTES = NR * S_SLOT;
+    static constexpr int GT_OFF = RING_BYTES;
+    static constexpr int LDS_BYTES = GT_OFF + NW * 256;
+};
+
+template <int EXP = 0>
+__global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch a) {
+    using C = Lean3Cfg;
+    constexpr bool DBG = (EXP & 4) != 0;
+    constexpr int NW = 8, S_PRE = 4;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    int s_idx, qt;
+    {
+        const int b = blockIdx.x;
+        if ((a.s_chunks & 7) == 0) {
+            const int xcd = b & 7, m = b >> 3;
+            qt = m % a.nqt;
+            s_idx = (m / a.nqt) * 8 + xcd;
+        } else {
+            qt = b % a.nqt;
+            s_idx = b / a.nqt;
+        }
+    }
+    const int64_t tiles_total = (a.n_rows + S_RT - 1) / S_RT;
+    const int64_t t0 = (int64_t)s_idx * a.tiles_per_chunk;
+    int64_t t1 = t0 + a.tiles_per_chunk;
+    if (t1 > tiles_total) t1 = tiles_total;
+    const int ntiles = (int)(t1 > t0 ? t1 - t0 : 0);
+    const char* img = (const char*)a.x + a.row0 * (int64_t)IMGB;
+    char* ring = ssm;
+    const int q_base = (qt * NW + w) * C::QW;
+    const bool q_ok = q_base + j < a.nq;
+    float thr_s = q_ok ? -INFINITY : INFINITY;            // 4096 * max(own k-th best, shared threshold): only ever rises
+    u32 cnt = 0;                                          // entries in this lane's query slot (equal in lanes j and j + 32)
+    u64* const gslot = a.gcand + ((size_t)s_idx * a.nq + (q_ok ? q_base + j : 0)) * C::CAP;
+    u32* gthr_w = a.gthr + q_base;
+    const u32* gt_lds = (const u32*)(ssm + C::GT_OFF) + w * 64;
+    const bool pace_on = a.prog != nullptr;               // sibling pacing: see scan_screen_kernel
+    u32* prog_w = a.prog + (size_t)s_idx * 4;
+    bool pace_live = pace_on;
+    const u32* gsrc = gthr_w + j;
+    if (pace_on && lane >= 32 && lane < 36) gsrc = prog_w + (lane - 32);
+    auto refresh_gthr = [&]() {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                         (__attribute__((address_space(3))) void*)(ssm + C::GT_OFF + w * 256), 4, 0, 16);
+    };
+    constexpr int PW = NW - 1;
+    auto pace_step = [&](int tile) {
+        if (lane == 0) __hip_atomic_store(prog_w + qt, ~(u32)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 m4 = max(max(gt_lds[32], gt_lds[33]), max(gt_lds[34], gt_lds[35]));
+        int lead = m4 ? tile - (int)~m4 : -1;
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(lead) > a.pace, 0)) {
+            int spins = 0;
+            do {
+                __builtin_amdgcn_s_sleep(24);
+                u32 v = 0;
+                if (lane < 4) v = __hip_atomic_load(prog_w + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = max(v, (u32)__shfl_xor((int)v, 1));
+                v = max(v, (u32)__shfl_xor((int)v, 2));
+                const u32 vm = (u32)__builtin_amdgcn_readfirstlane((int)v);
+                lead = vm ? tile - (int)~vm : -1;
+            } while (lead > a.pace && ++spins < 400);
+            if (spins >= 400) pace_live = false;
+        }
+    };
+    f16x8 qh[S_TS];
+    {
+        const char* qrow = (const char*)a.q + (size_t)(q_ok ? q_base + j : 0) * IMGB + h * 16;
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) qh[T] = *(const f16x8*)(qrow + T * 32);
+#pragma unroll
+        for (int T = 0; T < S_TS; ++T) asm volatile("" : "+v"(qh[T]));     // complete before any LDS-DMA (see scan_screen_kernel)
+    }
+    // DMA: wave w carries pieces n * 8 + w (n = 0..2) of a tile's 24 = 12 * half + piece; issued during tile t they belong to tile t + 4
+    u32 dma_off[C::NIW];
+    int dma_dst[C::NIW];
+#pragma unroll
+    for (int n = 0; n < C::NIW; ++n) {
+        const int id = n * C::NDW + w;
+        const int half = id / 12, pid = id % 12;
+        const int f = pid * 64 + lane;
+        const int i = f / S_U16, p = f % S_U16;
+        dma_off[n] = (u32)(i * IMGB + (p ^ ((i >> 1) & 7)) * 16 + half * S_CKB) + 4u * S_RT * IMGB;
+        dma_dst[n] = half * S_SLOT + pid * 1024;
+    }
+    const char* tp = img + (t0 * S_RT) * (int64_t)IMGB;   // the current tile's rows (uniform)
+    auto issue_part = [&](auto TS, const char* base, int n) {   // TS = ring position (0..5) of the tile the piece belongs to
+        if (EXP & 1) return;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[n]),
+                                         (__attribute__((address_space(3))) void*)(ring + decltype(TS)::value * 2 * S_SLOT + dma_dst[n]), 16, 0, 0);
+    };
+    u32 ab[4], ab_hi[4], ab_h2[4];                        // (the offset field is 16 bits: slots 4..7 and 8..11 go through their own bases)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        ab[m] = lds_addr(ring) + (u32)(j * S_CKB + (((2 * m + h) ^ ((j >> 1) & 7)) * 16));
+        ab_hi[m] = ab[m] + 4u * S_SLOT;
+        ab_h2[m] = ab[m] + 8u * S_SLOT;
+    }
+    f16x8 fr[S_PRE];
+#pragma unroll
+    for (int m = 0; m < S_PRE; ++m) fr[m] = f16x8{};
+    auto read_frag = [&](f16x8& dst, auto OFF, int t) {
+        if (EXP & 2) { asm volatile("" : "+v"(dst)); return; }
+        constexpr int off = decltype(OFF)::value;
+        const u32 ad = off >= 8 * S_SLOT ? ab_h2[t & 3] : off >= 4 * S_SLOT ? ab_hi[t & 3] : ab[t & 3];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(off % (4 * S_SLOT)));
+    };
+    auto frag_wait = [&](f16x8& f) {
+        if (EXP & 2) return;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1));
+    };
+    u32 d_slow = 0, d_comp = 0, d_app = 0;
+    unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_vm = 0, d_clk_all = DBG ? clock64() : 0;
+    // keep the best K' of query lane jj's slot (sorted), raise its threshold, publish it (VMEM as inline asm: see scan_screen_ks_kernel)
+    auto compact = [&](int jj) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u32 n = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
+        u64* slot = (u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
+                           (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
+        u64 key[1];
+        u32 rank[1];
+        key[0] = 0ull;
+        if ((u32)lane < n) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(key[0]) : "v"(slot + lane) : "memory");
+        rank_keys<1>(key, n, rank);
+        const bool keep = (u32)lane < n && rank[0] < (u32)a.k;
+        if (keep) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(slot + rank[0]), "v"(key[0]) : "memory");
+        const u64 kb = __ballot(keep && rank[0] == (u32)(a.k - 1));
+        if (kb) {
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(key[0] >> 32), __builtin_ctzll(kb));
+            if (j == jj) thr_s = fmaxf(thr_s, rmu_ord2f(hi) * 4096.0f);
+            if (lane == 0) asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(gthr_w + jj), "v"(hi) : "memory");
+        }
+        if (j == jj) cnt = n < (u32)a.k ? n : (u32)a.k;
+        if (DBG) ++d_comp;
+    };
+    auto slow_path = [&](const f32x16& p, int64_t rbase, u32 inmask) {
+        unsigned long long c0 = 0;
+        u32 todo = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) todo |= (p[r] > thr_s) ? (1u << r) : 0u;
+        todo &= inmask;
+        if (DBG) { ++d_slow; d_app += __builtin_popcount(todo); c0 = clock64(); }
+        u32 uni = 0;
+        for (u64 bl = __ballot(todo != 0); bl; bl &= bl - 1) uni |= (u32)__builtin_amdgcn_readlane((int)todo, __builtin_ctzll(bl));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((uni >> r) & 1u) {
+                bool has = ((todo >> r) & 1u) && p[r] > thr_s;
+                u32 other = (u32)__shfl_xor((int)has, 32);
+                const u64 full = __ballot(cnt + (u32)has + other > (u32)C::CAP);
+                if (__builtin_expect(full != 0, 0)) {
+                    for (u32 fm = (u32)full | (u32)(full >> 32); fm; fm &= fm - 1) compact(__builtin_ctz(fm));
+                    has = has && p[r] > thr_s;
+                    other = (u32)__shfl_xor((int)has, 32);
+                }
+                const u32 pos = cnt + (h ? other : 0u);
+                if (has) {
+                    const u64 key = rmu_make_key(p[r] * (1.0f / 4096.0f) + 0.0f, (u32)(rbase + (r & 3) + 8 * (r >> 2)));
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(gslot + pos), "v"(key) : "memory");
+                }
+                cnt += (u32)has + other;
+            }
+        }
+        if (DBG) d_clk_slow += clock64() - c0;
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    if (ntiles > 0) {
+        refresh_gthr();
+        {
+            const char* b0 = tp - 4 * S_RT * IMGB;        // dma_off carries the in-loop look-ahead of four tiles
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(I0{}, b0, n);
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(I1{}, b0 + S_RT * IMGB, n);
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(I2{}, b0 + 2 * S_RT * IMGB, n);
+#pragma unroll
+            for (int n = 0; n < C::NIW; ++n) issue_part(I3{}, b0 + 3 * S_RT * IMGB, n);
+        }
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // tiles 0, 1, 2 (and the thresholds)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) {
+            if (!(EXP & 2)) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[m]) : "v"(ab[m]));
+        }
+        f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accB[r] = -INFINITY; accA[r] = 0.f; }
+        const int64_t lane_r0 = a.row0 + t0 * S_RT + 4 * h;
+        // one tile; P = its position in the six-tile ring (compile time): its chunks sit in slots 2P and 2P + 1
+        auto tile_body = [&](auto PI, f32x16& acc, const f32x16& prev, int tl) {
+            constexpr int P = decltype(PI)::value;
+            if (P % 2 == 0) {                              // a pair of tiles starts
+                unsigned long long cb = 0;
+                if (DBG) cb = clock64();
+                // in flight at most: the three pieces (tile tl + 3) this wave issued during the previous tile; the refresh is older
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                if (DBG) { const unsigned long long cv = clock64(); d_clk_vm += cv - cb; cb = cv; }
+                __builtin_amdgcn_s_barrier();              // tiles up to tl + 2 have landed; nobody reads the previous pair any more
+                if (DBG) d_clk_bar += clock64() - cb;
+                const u32 go = gt_lds[j];
+                if (go && (a.share_thr & 1)) thr_s = fmaxf(thr_s, rmu_ord2f(go - 1u) * 4096.0f);
+                if (w == PW && pace_live) pace_step(tl);
+            }
+            float mx = -INFINITY;
+            auto step = [&](auto TI) {
+                constexpr int gs = decltype(TI)::value, t = gs % S_CS, cch = gs / S_CS;
+                constexpr int cur = 2 * P + cch, nxt = (cur + 1) % C::NR;
+                if (gs == 18 && !(a.share_thr & 2) && !(EXP & 8) && __builtin_expect(__ballot(mx > thr_s) != 0, 0))
+                    slow_path(prev, lane_r0 + (int64_t)(tl - 1) * S_RT, 0xffffu);
+                frag_wait(fr[gs % S_PRE]);
+                if (gs == 0) {
+                    const f32x16 z = {};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], z, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], acc, 0, 0, 0);
+                }
+                if (gs >= 1 && gs <= 8 && !(EXP & 8)) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(prev[2 * gs - 2]), "v"(prev[2 * gs - 1]));
+                if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], std::integral_constant<int, cur * S_SLOT + ((t + S_PRE) >> 2) * 128>{}, t + S_PRE);
+                else read_frag(fr[gs % S_PRE], std::integral_constant<int, nxt * S_SLOT + ((t + S_PRE - S_CS) >> 2) * 128>{}, t + S_PRE - S_CS);
+                if (gs % 8 == 1) issue_part(std::integral_constant<int, (P + 4) % 6>{}, tp, gs / 8);      // steps 1, 9, 17
+                if (gs == 4 && P % 2 == 0) refresh_gthr();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+            step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+            step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+            step(std::integral_constant<int, 15>{}); step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
+            step(std::integral_constant<int, 18>{}); step(std::integral_constant<int, 19>{}); step(std::integral_constant<int, 20>{});
+            step(std::integral_constant<int, 21>{}); step(std::integral_constant<int, 22>{}); step(std::integral_constant<int, 23>{});
+            tp += S_RT * IMGB;
+        };
+        for (int tl = 0; tl < ntiles; tl += 6) {           // ring period: six bodies (the accumulator parity alternates with it)
+            tile_body(I0{}, accA, accB, tl);                 // (tile -1 = the -inf accumulators: nothing passes)
+            if (tl + 1 < ntiles) tile_body(I1{}, accB, accA, tl + 1);
+            if (tl + 2 < ntiles) tile_body(I2{}, accA, accB, tl + 2);
+            if (tl + 3 < ntiles) tile_body(I3{}, accB, accA, tl + 3);
+            if (tl + 4 < ntiles) tile_body(I4{}, accA, accB, tl + 4);
+            if (tl + 5 < ntiles) tile_body(I5{}, accB, accA, tl + 5);
+        }
+        if (pace_on && w == PW && lane == 0) __hip_atomic_store(prog_w + qt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < S_PRE; ++m) asm volatile("" : "+v"(fr[m]));
+        {
+            const bool last_in_a = ((ntiles - 1) & 1) == 0;
+            f32x16 last;
+            const int64_t rbl = lane_r0 + (int64_t)(ntiles - 1) * S_RT, row_end = a.row0 + a.n_rows;
+            u32 inmask = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                last[r] = last_in_a ? accA[r] : accB[r];
+                inmask |= (rbl + (r & 3) + 8 * (r >> 2) < row_end) ? (1u << r) : 0u;
+            }
+            if (!(a.share_thr & 2)) slow_path(last, rbl, inmask);
+        }
+    }
+    if (DBG) {
+        u32 app = d_app;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) app += __shfl_xor(app, o);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)a.dbg + 0, (unsigned long long)d_slow);
+            atomicAdd((unsigned long long*)a.dbg + 1, (unsigned long long)d_comp);
+            atomicAdd((unsigned long long*)a.dbg + 2, (unsigned long long)app);
+            atomicAdd((unsigned long long*)a.dbg + 3, (unsigned long long)ntiles);
+            atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
+            atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
+            atomicAdd((unsigned long long*)a.dbg + 8, d_clk_vm);
+            atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
+        }
+    }
+    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  Eight slots are read back per round trip.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int part = s_idx;
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+        if (q_base + j0 >= a.nq) break;
+        u64 key[8][1];
+        u32 nn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int jj = j0 + e;
+            nn[e] = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
+            const u64* slot = (const u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
+                                           (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
+            key[e][0] = (u32)lane < nn[e] ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int qq = q_base + j0 + e;
+            if (qq < a.nq) {
+                u32 rank[1];
+                rank_keys<1>(key[e], nn[e], rank);
+                u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+                if ((u32)lane < nn[e]) {
+                    if (rank[0] < (u32)a.k) dst[rank[0]] = key[e][0];
+                } else if (lane < a.k) {
+                    dst[lane] = 0ull;
+                }
+            }
+        }
+    }
+}
+
 // ---- K-SPLIT form of the screening scan (round 4; full 256-query tiles) --------------------------------------------------------------
 // What bounds the 8-wave kernel above is the LDS return path, not the matrix pipe: 128 B/clk per CU = 32 B/clk per SIMD, and ONE 1-KiB A
 // fragment per 32-cycle MFMA is exactly that rate (measured with the ping-pong form: 8 cycles per KiB and CU): 0.59 MFMA busy.  Feeding
@@ -1949,8 +2585,10 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->parts = s;
     static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
-    p->kv = use_g4 ? 2 : (ks && p->wq == 8) ? 1 : 0;
-    p->lds_bytes = p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
+    // lean form with one barrier per tile and candidates in global memory (scan_screen_lean2_kernel): RMU_SCREEN_LEAN=2
+    static const int lean_env = getenv("RMU_SCREEN_LEAN") ? atoi(getenv("RMU_SCREEN_LEAN")) : 3;
+    p->kv = use_g4 ? 2 : (ks && p->wq == 8) ? 1 : (lean_env == 3 && p->wq == 8) ? 4 : (lean_env == 2 && p->wq == 8) ? 3 : 0;
+    p->lds_bytes = p->kv == 4 ? Lean3Cfg::LDS_BYTES : p->kv == 3 ? Lean2Cfg::LDS_BYTES : p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
     // sibling pacing (see the kernel): query tiles of a chunk on one XCD, 2..4 of them, the whole grid resident at once (these
     // kernels take > 80 KiB of LDS: one workgroup per CU), and enough tiles per workgroup for drift to matter
     // window in tiles (0 = off).  Measured (tools/pace_probe.py, 10M x 1024): 0 / 4 / 8 / 16 / 32 all 7.82-7.86 ms of scan kernels -- the pacing
@@ -1990,6 +2628,40 @@ static int screen_launch_g4(const ScanLaunch* p, hipStream_t s) {
 #endif
 
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
+    if (p->kv == 4) {
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                              Lean3Cfg::LDS_BYTES);
+        if (attr_rc != hipSuccess) return RMU_E_HIP;
+        if (!p->gcand) return RMU_E_INVALID;
+#ifdef RMU_DEBUG_KERNELS
+        if (p->dbg) {
+            static const hipError_t attr_d = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 Lean3Cfg::LDS_BYTES);
+            if (attr_d != hipSuccess) return RMU_E_HIP;
+            hipLaunchKernelGGL((scan_screen_lean3_kernel<4>), dim3(p->grid), dim3(512), Lean3Cfg::LDS_BYTES, s, *p);
+            return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+        }
+#endif
+        hipLaunchKernelGGL((scan_screen_lean3_kernel<0>), dim3(p->grid), dim3(512), Lean3Cfg::LDS_BYTES, s, *p);
+        return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+    }
+    if (p->kv == 3) {
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                              Lean2Cfg::LDS_BYTES);
+        if (attr_rc != hipSuccess) return RMU_E_HIP;
+        if (!p->gcand) return RMU_E_INVALID;
+#ifdef RMU_DEBUG_KERNELS
+        if (p->dbg) {
+            static const hipError_t attr_d = hipFuncSetAttribute((const void*)scan_screen_lean2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 Lean2Cfg::LDS_BYTES);
+            if (attr_d != hipSuccess) return RMU_E_HIP;
+            hipLaunchKernelGGL((scan_screen_lean2_kernel<4>), dim3(p->grid), dim3(512), Lean2Cfg::LDS_BYTES, s, *p);
+            return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+        }
+#endif
+        hipLaunchKernelGGL((scan_screen_lean2_kernel<0>), dim3(p->grid), dim3(512), Lean2Cfg::LDS_BYTES, s, *p);
+        return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+    }
 #ifdef RMU_DEBUG_KERNELS
     if (p->kv == 2) {
         if (p->dbg) return screen_launch_g4<4>(p, s);
@@ -2008,7 +2680,7 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
         return screen_launch_ks<0>(p, s);
     }
 #else
-    if (p->kv != 0) return RMU_E_INVALID;
+    if (p->kv != 0) return RMU_E_INVALID;     // (3 and 4 were handled above)
 #endif
 #ifdef RMU_DEBUG_KERNELS      // timing ablations, ring / prefetch depth experiments, cycle counters (wrong results by design for EXP != 0):
                               // python -m ragmeup_amd.build --debug-kernels; tools/ablate_screen.sh
