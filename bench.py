@@ -104,8 +104,8 @@ def scan_roofline(index, run, n_rows: int, d: int, nq: int, k: int, steps: int) 
         path, peak_tf = "screen-f16+rescore-f32", PEAK_F16_MFMA_TFLOPS
         bytes_alg = n_rows * IMG_ROW_BYTES + nq * IMG_ROW_BYTES + nq * k * 12
         g2 = nq > 128
-        kname = ((f"scan_screen_kernel<G=1,NW=8> (D=384, 8 waves x 32 queries = 256 queries/WG, two waves per SIMD, 32-row tiles as two 12-KiB half-k chunks, "
-                  f"6-slot LDS-DMA ring)" if g2 else
+        kname = ((f"scan_screen_lean3_kernel (D=384, 8 waves x 32 queries = 256 queries/WG, two waves per SIMD, 32-row tiles as two 12-KiB half-k chunks, "
+                  f"12-slot = 6-tile LDS-DMA ring handed over once per two tiles, compile-time ring slots, candidates in global memory)" if g2 else
                   f"scan_screen_kernel<G=1> (D=384, 128 queries/WG, 32-row tiles as two 12-KiB half-k chunks, 8-slot LDS-DMA ring, nt stream)")
                  + ", one launch per row range of the threshold ladder")
     else:

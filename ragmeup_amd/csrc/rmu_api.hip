@@ -875,8 +875,8 @@ static void dbg_dump(const char* what, int64_t rows, hipStream_t s) {
     u64 h[16];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, g_dbg, 128, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[rmu dbg %s: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu clk_vmwait=%llu seg=%llu/%llu/%llu\n",
-            what, (long long)rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+    fprintf(stderr, "[rmu dbg %s: %lld rows] slow_tiles=%llu compactions=%llu appends=%llu wave_tiles=%llu rounds=%llu clk_slow=%llu clk_bar=%llu clk_all=%llu clk_vmwait=%llu seg=%llu/%llu/%llu/%llu/%llu/%llu/%llu\n",
+            what, (long long)rows, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
     (void)hipMemset(g_dbg, 0, 128);
 }
 

@@ -1488,6 +1488,9 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
                 if (go && (a.share_thr & 1)) thr_s = fmaxf(thr_s, rmu_ord2f(go - 1u) * 4096.0f);
                 if (w == PW && pace_live) pace_step(tl);
             }
+            // (Measured per wave: waves 0-3 wait ~600 cycles per tile at the pair barrier, waves 4-7 ~75 -- issue arbitration between the two waves
+            // of a SIMD is by age.  Giving the younger half s_setprio 1 for the first tile of every pair halves the total wait and changes
+            // the kernel's time by nothing: the SIMD's throughput, not the rendezvous, sets it.)
             float mx = -INFINITY;
             auto step = [&](auto TI) {
                 constexpr int gs = decltype(TI)::value, t = gs % S_CS, cch = gs / S_CS;
@@ -1501,6 +1504,7 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
                 } else {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], acc, 0, 0, 0);
                 }
+                // (the MFMAs as inline asm with the wait in the same statement -- no compiler s_nop padding -- measured no faster: 6.64-6.67 vs 6.54)
                 if (gs >= 1 && gs <= 8 && !(EXP & 8)) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(prev[2 * gs - 2]), "v"(prev[2 * gs - 1]));
                 if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], std::integral_constant<int, cur * S_SLOT + ((t + S_PRE) >> 2) * 128>{}, t + S_PRE);
                 else read_frag(fr[gs % S_PRE], std::integral_constant<int, nxt * S_SLOT + ((t + S_PRE - S_CS) >> 2) * 128>{}, t + S_PRE - S_CS);
@@ -1555,6 +1559,7 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
             atomicAdd((unsigned long long*)a.dbg + 5, d_clk_slow);
             atomicAdd((unsigned long long*)a.dbg + 6, d_clk_bar);
             atomicAdd((unsigned long long*)a.dbg + 8, d_clk_vm);
+            if (w < 7) atomicAdd((unsigned long long*)a.dbg + 9 + w, d_clk_bar);     // barrier wait of waves 0..6 ("seg" + following words in the dump)
             atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
         }
     }

@@ -19,7 +19,7 @@ STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.
 
 
 def short(n):
-    m = re.search(r'(scan_topk_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
+    m = re.search(r'(scan_topk_kernel|scan_screen_lean3_kernel|scan_screen_lean2_kernel|scan_screen_lean_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
                   r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm_small|k_gemm<\d, \d, \d+, \d(?:, \w+)?>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
     s = m.group(1) if m else n[:40]
     if s in ('scan_topk_kernel',):
@@ -79,7 +79,8 @@ def line(p, k):
             + ", ".join(f"{c}={v[1]:.4g}" for c, v in d.items() if not c.startswith('_')))
 
 
-SK = 'scan_screen_kernel'
+SK1 = 'scan_screen_kernel'              # one query tile (batch <= 128): the 4-wave nt form
+SK = 'scan_screen_lean3_kernel'         # full query tiles: the headline's kernel (round 4)
 
 
 def find(p, prefix):
@@ -110,7 +111,7 @@ txt = [
     stats('scan_b32', 'north-star regime: batch 32 over 10M rows, default path (fp16 image, nt stream, ladder ratio 8)'),
     stats('embed', 'encoder: 8192-chunk calls x ~128 tokens (BERT-6x384, bf16 MFMA; k_ffn3 / k_attn3 / k_gemm3 / k_gemm)'),
     "## PMC passes (separate runs, `--kernel-trace --pmc ...` only)\n",
-    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK), line('exact_pmc_b1', B1), line('pmc_b32', SK),
+    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK1), line('exact_pmc_b1', B1), line('pmc_b32', SK1),
     "\n## Derived (FETCH_SIZE is in KiB and under-reports by 2x on gfx950 per MI355X_MICROARCH.md -> bytes = FETCH_SIZE x 1024 x 2)\n",
     f"- screening launches, per batch: HBM fetch {scr_fetch/1e9:.2f} GB + write {scr_write/1e6:.1f} MB; the fp16 image is 7.68 GB and each of the 4 "
     f"query-tile workgroups of a row chunk streams it (L2 hit {hit:.3f}; ideal 0.75), i.e. x{scr_fetch/7.68e9:.2f} the image, x{scr_fetch/15.36e9:.2f} the "
@@ -119,8 +120,8 @@ txt = [
     f"{clk_s:.2f} GHz (GRBM_GUI_ACTIVE/8 / {k_ms} ms): the part down-clocks from 2.4 GHz under the combined MFMA + LDS + L2 load",
     f"- exact kernel: HBM fetch {f('exact_pmc_b',EK,'FETCH_SIZE')*2048/1e9:.2f} GB per launch vs 15.36 GB algorithmic (x{f('exact_pmc_b',EK,'FETCH_SIZE')*2048/15.36e9:.3f}); "
     f"MFMA busy {f('exact_pmc_a',EK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('exact_pmc_a',EK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles; mean clock {clk_e:.2f} GHz",
-    f"- batch 1, default path: HBM fetch {f('pmc_b1',SK,'FETCH_SIZE')*2048/1e9:.3f} GB per query over all launches vs the 7.680 GB image (x{f('pmc_b1',SK,'FETCH_SIZE')*2048/7.68e9:.4f})",
-    f"- batch 32, default path: HBM fetch {f('pmc_b32',SK,'FETCH_SIZE')*2048/1e9:.3f} GB per batch over all launches vs the 7.680 GB image (x{f('pmc_b32',SK,'FETCH_SIZE')*2048/7.68e9:.4f})",
+    f"- batch 1, default path: HBM fetch {f('pmc_b1',SK1,'FETCH_SIZE')*2048/1e9:.3f} GB per query over all launches vs the 7.680 GB image (x{f('pmc_b1',SK1,'FETCH_SIZE')*2048/7.68e9:.4f})",
+    f"- batch 32, default path: HBM fetch {f('pmc_b32',SK1,'FETCH_SIZE')*2048/1e9:.3f} GB per batch over all launches vs the 7.680 GB image (x{f('pmc_b32',SK1,'FETCH_SIZE')*2048/7.68e9:.4f})",
     f"- batch 1, exact scan: HBM fetch {f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
 ]
 open(f'profiles/{RP}_summary.md', 'w').write("\n".join(txt) + "\n")
@@ -186,10 +187,10 @@ if enc_lines:
 json.dump({"source": f"tools/profile.sh {tag} -> tools/summarize_profiles.py: sum per bench step over the launches of (2 x FETCH_SIZE [gfx950 correction] "
                      f"+ WRITE_SIZE where collected) x 1024, profiles/{RP}_pmc_means.csv",
            "entries": [{"path": "screen", "rows": 10_000_000, "batch": 1024, "bytes_per_step": scr_fetch + scr_write},
-                       {"path": "screen", "rows": 10_000_000, "batch": 32, "bytes_per_step": f('pmc_b32', SK, 'FETCH_SIZE') * 2048},
-                       {"path": "screen", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('pmc_b1', SK, 'FETCH_SIZE') * 2048},
+                       {"path": "screen", "rows": 10_000_000, "batch": 32, "bytes_per_step": f('pmc_b32', SK1, 'FETCH_SIZE') * 2048},
+                       {"path": "screen", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('pmc_b1', SK1, 'FETCH_SIZE') * 2048},
                        {"path": "exact", "rows": 10_000_000, "batch": 1024, "bytes_per_step": f('exact_pmc_b', EK, 'FETCH_SIZE') * 2048},
                        {"path": "exact", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('exact_pmc_b1', B1, 'FETCH_SIZE') * 2048}] + enc_entries},
           open(f'profiles/{RP}_traffic.json', 'w'), indent=1)
 print("\n".join(txt[-4:]))
-print("SCREEN_TRAFFIC =", scr_fetch + scr_write, "B1 screen", f('pmc_b1',SK,'FETCH_SIZE')*2048, "B32 screen", f('pmc_b32',SK,'FETCH_SIZE')*2048, "exact", f('exact_pmc_b',EK,'FETCH_SIZE')*2048, "exact B1", f('exact_pmc_b1',B1,'FETCH_SIZE')*2048)
+print("SCREEN_TRAFFIC =", scr_fetch + scr_write, "B1 screen", f('pmc_b1',SK1,'FETCH_SIZE')*2048, "B32 screen", f('pmc_b32',SK1,'FETCH_SIZE')*2048, "exact", f('exact_pmc_b',EK,'FETCH_SIZE')*2048, "exact B1", f('exact_pmc_b1',B1,'FETCH_SIZE')*2048)
