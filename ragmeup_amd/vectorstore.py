@@ -159,7 +159,10 @@ class MI355XVectorStore(VectorStore):
         self._pks: list[str] = []
         self._alive: list[bool] = []
         self._pk_to_row: dict[str, int] = {}
-        self._pending = None                 # the GPU half of the last add_texts call, still in flight (see _add_pipelined)
+        self._pending = []                   # GPU halves of add_texts calls still in flight, oldest first (see _add_pipelined)
+        self._pipe_failed = False            # set by the worker when a half fails: the halves queued behind it do nothing
+        self._work = []                      # GPU halves not yet taken by the worker (tok, n0, cnt, stale, future), oldest first
+        self._wlock = threading.Lock()
         self._worker = None
         if drop_old:
             self._remove_persisted()
@@ -332,7 +335,7 @@ class MI355XVectorStore(VectorStore):
         return float(s)
 
     def __len__(self) -> int:
-        if self._pending is not None:
+        if self._pending:
             self.flush()
         return sum(self._alive)
 
@@ -340,22 +343,44 @@ class MI355XVectorStore(VectorStore):
     # server/RAGHelper.py:423-434 inserts in 1000-document calls; each call is tokenise (host, ~1 ms) -> forward + append (GPU, ~3.4 ms)
     # -> Python bookkeeping, strictly in series: 0.81 of the rate of one big call (whose blocks overlap inside the call).  A call of
     # that size therefore returns once its HOST half is done -- ids fixed, records appended, the row numbers it will occupy known --
-    # and hands the GPU half to a worker thread; the next call's tokenising overlaps it.  Nothing can observe the difference: every
-    # entry point that reads or changes the index (search, delete, persist, the next GPU half, flush()) first waits for the pending
-    # half, and a failure in it rolls that call's records back and is raised there.
-    def _drain(self):
-        """(under self._lock) wait for the pending GPU half; on failure undo its call's host records and re-raise."""
-        pend, self._pending = self._pending, None
-        if pend is None:
-            return
-        fut, n0, cnt, undo, stale = pend
+    # and hands the GPU half to a worker thread; the next call's tokenising overlaps it.  Up to `pipeline_depth` halves are queued, and the
+    # worker runs EVERYTHING that is queued when it becomes free as ONE forward + ONE append: a 1000-chunk forward is ~14 % slower per chunk
+    # than an 8192-chunk one, which is what held the pattern at 0.86 of the one-call rate however the hand-over was arranged (depth 1 and 2
+    # measured alike); the host half of a call (~1.5 ms) is shorter than its GPU half (~3.4 ms), so the queue fills and the forwards grow.
+    # Nothing can observe the difference: every entry point that reads or changes the index (search, delete, persist, flush()) first
+    # waits for the pending halves, and a failure rolls back that call's records AND those of the calls queued with or behind it, and is
+    # raised there.
+    pipeline_depth = max(1, int(os.environ.get("RMU_ADD_DEPTH", "8")))   # insert calls whose GPU half may be pending (1 = no coalescing)
+
+    def _drain(self, keep: int = 0):
+        """(under self._lock) wait for pending GPU halves, oldest first, until at most `keep` are left; on failure undo and re-raise."""
+        while len(self._pending) > keep:
+            try:
+                self._pending[0][0].result()
+            except BaseException as exc:
+                ents, self._pending = self._pending, []
+                for ent in ents[1:]:                     # queued behind the failure: skipped by the worker
+                    try:
+                        ent[0].result()
+                    except BaseException:
+                        pass
+                self._pipe_failed = False
+                for (_f, n02, _c, undo2, stale2) in reversed(ents[1:]):   # newest first: a pk may appear in several calls
+                    del self._texts[n02:], self._metas[n02:], self._pks[n02:], self._alive[n02:]
+                    self._undo_pks(undo2, stale2)
+                self._rollback_failed_half(ents[0], exc)
+            else:
+                self._pending.pop(0)
+
+    def _rollback_failed_half(self, ent, exc):
+        _fut, n0, cnt, undo, stale = ent
         try:
-            fut.result()
+            raise exc
         except _RowsOutOfStep as e:
             # the rows ARE in the index (tombstoned by the worker): dead placeholder records keep row numbers and records in step
             for r in range(min(n0, e.first), len(self._alive)):
                 self._alive[r] = False
-            while len(self._texts) < e.first + cnt:
+            while len(self._texts) < e.first + e.total:
                 self._texts.append(""); self._metas.append({}); self._pks.append(""); self._alive.append(False)
             self._undo_pks(undo, stale)
             raise RuntimeError(f"index rows ({e.first}) and host records ({n0}) out of step: the batch was rolled back") from None
@@ -378,17 +403,48 @@ class MI355XVectorStore(VectorStore):
         with self._lock:
             self._drain()
 
-    def _gpu_half(self, tok, n0: int, cnt: int, stale: list):
+    def _gpu_pump(self):
+        """(worker thread) run every queued GPU half as one forward + one append; resolve their futures."""
+        import numpy as np
         import torch
+        with self._wlock:
+            items, self._work = self._work, []
+        if not items:
+            return                                       # an earlier pump took this call's item along
+        if self._pipe_failed:
+            for it in items:
+                it[4].set_exception(RuntimeError("skipped: an earlier insert call of the pipeline failed"))
+            return
         emb = self._embeddings
-        with torch.cuda.device(emb.encoder.device):
-            vecs = emb.embed_token_arrays_device(*tok)
-            first = self._index.add(vecs)
-            if first != n0:
-                self._index.remove_rows(list(range(min(n0, first), first + cnt)))
-                raise _RowsOutOfStep(first)
-            if stale:
-                self._index.remove_rows(stale)
+        try:
+            if len(items) == 1:
+                ids, lens = items[0][0]
+            else:
+                width = max(it[0][0].shape[1] for it in items)
+                ids = np.zeros((sum(it[0][0].shape[0] for it in items), width), dtype=items[0][0][0].dtype)
+                lo = 0
+                for it in items:
+                    a = it[0][0]
+                    ids[lo:lo + a.shape[0], :a.shape[1]] = a
+                    lo += a.shape[0]
+                lens = np.concatenate([it[0][1] for it in items])
+            n0, total = items[0][1], sum(it[2] for it in items)
+            with torch.cuda.device(emb.encoder.device):
+                vecs = emb.embed_token_arrays_device(ids, lens)
+                first = self._index.add(vecs)
+                if first != n0:
+                    self._index.remove_rows(list(range(min(n0, first), first + total)))
+                    raise _RowsOutOfStep(first, total)
+                stale = [r for it in items for r in it[3]]
+                if stale:
+                    self._index.remove_rows(stale)
+        except BaseException as e:
+            self._pipe_failed = True
+            for it in items:
+                it[4].set_exception(e)
+            return
+        for it in items:
+            it[4].set_result(None)
 
     def _add_pipelined(self, sel_texts, sel_ids, sel_metas_fn) -> bool:
         emb = self._embeddings
@@ -400,7 +456,7 @@ class MI355XVectorStore(VectorStore):
             return False
         sel_metas = sel_metas_fn()
         with self._lock:
-            self._drain()
+            self._drain(keep=self.pipeline_depth - 1)    # the newest half may still be running while this call's records are written
             self._ensure_index(int(emb.encoder.HIDDEN))
             n0 = len(self._texts)
             self._texts.extend(sel_texts)
@@ -414,10 +470,14 @@ class MI355XVectorStore(VectorStore):
                 self._alive[r] = False
             old_rows.update(zip(sel_ids, range(n0, n0 + len(sel_ids))))
             self._dirty = True
+            from concurrent.futures import Future, ThreadPoolExecutor
             if self._worker is None:
-                from concurrent.futures import ThreadPoolExecutor
                 self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmu-add")
-            self._pending = (self._worker.submit(self._gpu_half, tok, n0, len(sel_ids), stale), n0, len(sel_ids), undo, stale)
+            fut = Future()
+            with self._wlock:
+                self._work.append((tok, n0, len(sel_ids), stale, fut))
+            self._pending.append((fut, n0, len(sel_ids), undo, stale))
+            self._worker.submit(self._gpu_pump)
         return True
 
     # ---- insert (RAGHelper.py:431, :525) ------------------------------------------------------------------
@@ -529,7 +589,7 @@ class MI355XVectorStore(VectorStore):
 
     # ---- search ---------------------------------------------------------------------------------------------
     def _search_vecs(self, qvecs: np.ndarray, k: int):
-        if self._pending is not None:
+        if self._pending:
             self.flush()
         if self._index is None or len(self._index) == 0:
             return np.full((qvecs.shape[0], 0), -np.inf, np.float32), np.full((qvecs.shape[0], 0), -1, np.int64)
@@ -543,7 +603,7 @@ class MI355XVectorStore(VectorStore):
     def _fused_query(self, query: str, fetch_k: int, k: int, lambda_mult):
         """One query through `rmu_bert_search_mmr` (token ids in, rows out: forward, dense top-fetch_k and the selection in ONE library
         call with one synchronisation) when the Embeddings object and the index are the native ones; None otherwise."""
-        if self._pending is not None:
+        if self._pending:
             self.flush()
         emb, idx = self._embeddings, self._index
         if (idx is None or not hasattr(idx, "_h") or len(idx) == 0 or not hasattr(emb, "query_ids") or not (1 <= k <= fetch_k <= 64)
@@ -577,7 +637,7 @@ class MI355XVectorStore(VectorStore):
     def max_marginal_relevance_search_by_vector(self, embedding, k: int = 4, fetch_k: int = 20,
                                                 lambda_mult: float = 0.5, **kw) -> list[Document]:
         q = np.asarray(embedding, dtype=np.float32)
-        if self._pending is not None:
+        if self._pending:
             self.flush()
         if (self._index is not None and hasattr(self._index, "search_mmr") and len(self._index) > 0
                 and 1 <= k <= int(fetch_k) <= 64):
@@ -634,9 +694,10 @@ class MI355XVectorStore(VectorStore):
 
 
 class _RowsOutOfStep(Exception):
-    def __init__(self, first: int):
-        super().__init__(first)
-        self.first = first
+    def __init__(self, first: int, total: int):
+        super().__init__(first, total)
+        self.first = first          # the row the index gave the batch
+        self.total = total          # rows the batch added there (tombstoned by the worker)
 
 
 class _DeleteResult(int):

@@ -444,9 +444,10 @@ def test_insert_calls_are_pipelined_across_calls_and_nothing_can_tell(bi, tmp_pa
     seen_pending = 0
     for lo in range(0, len(docs), 500):
         assert pip.add_documents(docs[lo:lo + 500], ids=pks[lo:lo + 500]) == pks[lo:lo + 500]
-        seen_pending += pip._pending is not None
+        seen_pending += len(pip._pending) >= 1
+        assert len(pip._pending) <= pip.pipeline_depth          # bounded queue of GPU halves
     assert seen_pending == 5                                    # every call of that size left its GPU half in flight
-    assert len(pip) == len(one) == 2500 and pip._pending is None
+    assert len(pip) == len(one) == 2500 and not pip._pending
     for q in texts[:3] + synth_texts(3, seed=32, wmin=5, wmax=12):
         a = [(d.metadata["pk"], s) for d, s in one.similarity_search_with_score(q, k=8)]
         b = [(d.metadata["pk"], s) for d, s in pip.similarity_search_with_score(q, k=8)]
@@ -470,4 +471,28 @@ def test_insert_calls_are_pipelined_across_calls_and_nothing_can_tell(bi, tmp_pa
     assert len(pip._texts) == n_before and "d0" not in pip._pk_to_row and len(pip) == 2000
     pip.add_documents(docs[:200], ids=["again" + p for p in pks[:200]])
     assert len(pip) == 2200 and len(pip._index) == len(pip._texts)
+    # two halves in flight, the FIRST fails: the second is skipped by the worker, both calls are rolled back (newest first: "shared"
+    # is upserted by both), the error of the first is the one raised, and the store carries on
+    n_before = len(pip._texts)
+    pip.add_documents([Document("keep me", {"source": "k", "id": "shared"})], ids=["shared"])
+    assert pip._pk_to_row["shared"] == n_before and len(pip) == 2201
+    n_before += 1
+    calls = []
+    def flaky_add(v):
+        calls.append(len(v))
+        raise RuntimeError("device lost again")
+    pip._index.add = flaky_add
+    a_docs = [Document("first " + t, {"source": "f", "id": "f" + str(i)}) for i, t in enumerate(texts[:300])] + [Document("first shared", {"source": "f", "id": "shared"})]
+    b_docs = [Document("second " + t, {"source": "g", "id": "g" + str(i)}) for i, t in enumerate(texts[:300])] + [Document("second shared", {"source": "g", "id": "shared"})]
+    pip.add_documents(a_docs, ids=["f" + str(i) for i in range(300)] + ["shared"])
+    pip.add_documents(b_docs, ids=["g" + str(i) for i in range(300)] + ["shared"])
+    with pytest.raises(RuntimeError, match="device lost again"):
+        pip.flush()
+    pip._index.add = real_add
+    assert calls in ([301], [602])                              # the second half never touched the index on its own (skipped, or coalesced with the first)
+    assert len(pip._texts) == n_before and "f0" not in pip._pk_to_row and "g0" not in pip._pk_to_row
+    assert pip._pk_to_row["shared"] == n_before - 1 and pip._alive[n_before - 1] and len(pip) == 2201
+    assert pip.similarity_search("keep me", k=1)[0].metadata["pk"] == "shared"
+    pip.add_documents(docs[200:400], ids=["again" + p for p in pks[200:400]])
+    assert len(pip) == 2401 and len(pip._index) == len(pip._texts)
     one._index.close(); pip._index.close()
