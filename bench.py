@@ -106,7 +106,8 @@ def scan_roofline(index, run, n_rows: int, d: int, nq: int, k: int, steps: int) 
         g2 = nq > 128
         kname = ((f"scan_screen_lean3_kernel (D=384, 8 waves x 32 queries = 256 queries/WG, two waves per SIMD, 32-row tiles as two 12-KiB half-k chunks, "
                   f"12-slot = 6-tile LDS-DMA ring handed over once per two tiles, compile-time ring slots, candidates in global memory)" if g2 else
-                  f"scan_screen_kernel<G=1> (D=384, 128 queries/WG, 32-row tiles as two 12-KiB half-k chunks, 8-slot LDS-DMA ring, nt stream)")
+                  f"scan_screen_lean3_kernel<NW=4> (D=384, 4 waves x 32 queries = 128 queries/WG, 32-row tiles as two 12-KiB half-k chunks, 12-slot = 6-tile LDS-DMA ring "
+                  f"handed over once per two tiles, nt stream, candidates in global memory)")
                  + ", one launch per row range of the threshold ladder")
     else:
         path, peak_tf = "exact-f32", PEAK_F32_MFMA_TFLOPS

@@ -1277,19 +1277,23 @@ __global__ __launch_bounds__(512) void scan_screen_lean2_kernel(const ScanLaunch
 // carries three of a tile's 24 DMA pieces (the pacing store of the last wave is a plain store issued a whole pair before the next counted
 // wait: it cannot hold the ring up).  At the barrier of pair p the tiles up to 2p + 2 have landed (the fragment prefetch crosses into the
 // next pair's first tile), 2p + 3 may be in flight, and pair p + 2 is issued during pair p into the slots of pair p - 1.  Six bodies.
+// NWV = 8: full query tiles (256 queries per workgroup, two waves per SIMD).  NWV = 4: ONE query tile (batches <= 128 queries: every image byte
+// is read by exactly one workgroup -- NT streams it past the L2 with non-temporal loads; the HBM-bound regime, where the round-3 form's ~300
+// instructions per tile and wave cost bandwidth: one wave per SIMD cannot issue them and keep 24 KiB per microsecond in flight).
+template <int NWV>
 struct Lean3Cfg {
-    static constexpr int NW = 8, QW = 32, NR = 12, NDW = 8, NIW = 3;
+    static constexpr int NW = NWV, QW = 32, NR = 12, NDW = NWV, NIW = 24 / NWV;
     static constexpr int CAP = RMU_KS_CAP;
     static constexpr int RING_BYTES = NR * S_SLOT;
     static constexpr int GT_OFF = RING_BYTES;
     static constexpr int LDS_BYTES = GT_OFF + NW * 256;
 };
 
-template <int EXP = 0>
-__global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch a) {
-    using C = Lean3Cfg;
+template <int EXP = 0, int NWV = 8, int NT = 0>
+__global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanLaunch a) {
+    using C = Lean3Cfg<NWV>;
     constexpr bool DBG = (EXP & 4) != 0;
-    constexpr int NW = 8, S_PRE = 4;
+    constexpr int NW = NWV, S_PRE = 4;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, j = lane & 31;
@@ -1355,7 +1359,7 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
 #pragma unroll
         for (int T = 0; T < S_TS; ++T) asm volatile("" : "+v"(qh[T]));     // complete before any LDS-DMA (see scan_screen_kernel)
     }
-    // DMA: wave w carries pieces n * 8 + w (n = 0..2) of a tile's 24 = 12 * half + piece; issued during tile t they belong to tile t + 4
+    // DMA: wave w carries pieces n * NW + w (n = 0..NIW-1) of a tile's 24 = 12 * half + piece; issued during tile t they belong to tile t + 4
     u32 dma_off[C::NIW];
     int dma_dst[C::NIW];
 #pragma unroll
@@ -1370,8 +1374,12 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
     const char* tp = img + (t0 * S_RT) * (int64_t)IMGB;   // the current tile's rows (uniform)
     auto issue_part = [&](auto TS, const char* base, int n) {   // TS = ring position (0..5) of the tile the piece belongs to
         if (EXP & 1) return;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[n]),
-                                         (__attribute__((address_space(3))) void*)(ring + decltype(TS)::value * 2 * S_SLOT + dma_dst[n]), 16, 0, 0);
+        if (NT)        // literal aux operands only
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[n]),
+                                             (__attribute__((address_space(3))) void*)(ring + decltype(TS)::value * 2 * S_SLOT + dma_dst[n]), 16, 0, 2);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + dma_off[n]),
+                                             (__attribute__((address_space(3))) void*)(ring + decltype(TS)::value * 2 * S_SLOT + dma_dst[n]), 16, 0, 0);
     };
     u32 ab[4], ab_hi[4], ab_h2[4];                        // (the offset field is 16 bits: slots 4..7 and 8..11 go through their own bases)
 #pragma unroll
@@ -1463,7 +1471,7 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
 #pragma unroll
             for (int n = 0; n < C::NIW; ++n) issue_part(I3{}, b0 + 3 * S_RT * IMGB, n);
         }
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // tiles 0, 1, 2 (and the thresholds)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NIW) : "memory");   // tiles 0, 1, 2 (and the thresholds)
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int m = 0; m < S_PRE; ++m) {
@@ -1479,8 +1487,8 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
             if (P % 2 == 0) {                              // a pair of tiles starts
                 unsigned long long cb = 0;
                 if (DBG) cb = clock64();
-                // in flight at most: the three pieces (tile tl + 3) this wave issued during the previous tile; the refresh is older
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                // in flight at most: the NIW pieces (tile tl + 3) this wave issued during the previous tile; the refresh is older
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NIW) : "memory");
                 if (DBG) { const unsigned long long cv = clock64(); d_clk_vm += cv - cb; cb = cv; }
                 __builtin_amdgcn_s_barrier();              // tiles up to tl + 2 have landed; nobody reads the previous pair any more
                 if (DBG) d_clk_bar += clock64() - cb;
@@ -1508,7 +1516,7 @@ __global__ __launch_bounds__(512) void scan_screen_lean3_kernel(const ScanLaunch
                 if (gs >= 1 && gs <= 8 && !(EXP & 8)) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(prev[2 * gs - 2]), "v"(prev[2 * gs - 1]));
                 if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], std::integral_constant<int, cur * S_SLOT + ((t + S_PRE) >> 2) * 128>{}, t + S_PRE);
                 else read_frag(fr[gs % S_PRE], std::integral_constant<int, nxt * S_SLOT + ((t + S_PRE - S_CS) >> 2) * 128>{}, t + S_PRE - S_CS);
-                if (gs % 8 == 1) issue_part(std::integral_constant<int, (P + 4) % 6>{}, tp, gs / 8);      // steps 1, 9, 17
+                if (gs % (S_TS / C::NIW) == 1) issue_part(std::integral_constant<int, (P + 4) % 6>{}, tp, gs / (S_TS / C::NIW));   // steps 1, 9, 17 | 1, 5, .., 21
                 if (gs == 4 && P % 2 == 0) refresh_gthr();
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -2592,8 +2600,10 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
     // lean form with one barrier per tile and candidates in global memory (scan_screen_lean2_kernel): RMU_SCREEN_LEAN=2
     static const int lean_env = getenv("RMU_SCREEN_LEAN") ? atoi(getenv("RMU_SCREEN_LEAN")) : 3;
-    p->kv = use_g4 ? 2 : (ks && p->wq == 8) ? 1 : (lean_env == 3 && p->wq == 8) ? 4 : (lean_env == 2 && p->wq == 8) ? 3 : 0;
-    p->lds_bytes = p->kv == 4 ? Lean3Cfg::LDS_BYTES : p->kv == 3 ? Lean2Cfg::LDS_BYTES : p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
+    static const int lean4 = getenv("RMU_SCREEN_LEAN4") ? atoi(getenv("RMU_SCREEN_LEAN4")) : 1;     // 0: round 3's kernel for one query tile
+    const bool one_tile = p->wq == 4 && p->qg == 1 && p->nqt == 1;
+    p->kv = use_g4 ? 2 : (ks && p->wq == 8) ? 1 : (lean_env == 3 && (p->wq == 8 || (lean4 && one_tile))) ? 4 : (lean_env == 2 && p->wq == 8) ? 3 : 0;
+    p->lds_bytes = p->kv == 4 ? (p->wq == 8 ? Lean3Cfg<8>::LDS_BYTES : Lean3Cfg<4>::LDS_BYTES) : p->kv == 3 ? Lean2Cfg::LDS_BYTES : p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
     // sibling pacing (see the kernel): query tiles of a chunk on one XCD, 2..4 of them, the whole grid resident at once (these
     // kernels take > 80 KiB of LDS: one workgroup per CU), and enough tiles per workgroup for drift to matter
     // window in tiles (0 = off).  Measured (tools/pace_probe.py, 10M x 1024): 0 / 4 / 8 / 16 / 32 all 7.82-7.86 ms of scan kernels -- the pacing
@@ -2634,20 +2644,34 @@ static int screen_launch_g4(const ScanLaunch* p, hipStream_t s) {
 
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     if (p->kv == 4) {
-        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                              Lean3Cfg::LDS_BYTES);
-        if (attr_rc != hipSuccess) return RMU_E_HIP;
         if (!p->gcand) return RMU_E_INVALID;
+        if (p->wq == 4) {                                 // one query tile
+            if (p->nt) {
+                static const hipError_t rc4 = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                  Lean3Cfg<4>::LDS_BYTES);
+                if (rc4 != hipSuccess) return RMU_E_HIP;
+                hipLaunchKernelGGL((scan_screen_lean3_kernel<0, 4, 1>), dim3(p->grid), dim3(256), Lean3Cfg<4>::LDS_BYTES, s, *p);
+            } else {
+                static const hipError_t rc4 = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                  Lean3Cfg<4>::LDS_BYTES);
+                if (rc4 != hipSuccess) return RMU_E_HIP;
+                hipLaunchKernelGGL((scan_screen_lean3_kernel<0, 4, 0>), dim3(p->grid), dim3(256), Lean3Cfg<4>::LDS_BYTES, s, *p);
+            }
+            return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+        }
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                              Lean3Cfg<8>::LDS_BYTES);
+        if (attr_rc != hipSuccess) return RMU_E_HIP;
 #ifdef RMU_DEBUG_KERNELS
         if (p->dbg) {
             static const hipError_t attr_d = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                 Lean3Cfg::LDS_BYTES);
+                                                                 Lean3Cfg<8>::LDS_BYTES);
             if (attr_d != hipSuccess) return RMU_E_HIP;
-            hipLaunchKernelGGL((scan_screen_lean3_kernel<4>), dim3(p->grid), dim3(512), Lean3Cfg::LDS_BYTES, s, *p);
+            hipLaunchKernelGGL((scan_screen_lean3_kernel<4>), dim3(p->grid), dim3(512), Lean3Cfg<8>::LDS_BYTES, s, *p);
             return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
         }
 #endif
-        hipLaunchKernelGGL((scan_screen_lean3_kernel<0>), dim3(p->grid), dim3(512), Lean3Cfg::LDS_BYTES, s, *p);
+        hipLaunchKernelGGL((scan_screen_lean3_kernel<0>), dim3(p->grid), dim3(512), Lean3Cfg<8>::LDS_BYTES, s, *p);
         return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
     }
     if (p->kv == 3) {

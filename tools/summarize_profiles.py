@@ -79,7 +79,7 @@ def line(p, k):
             + ", ".join(f"{c}={v[1]:.4g}" for c, v in d.items() if not c.startswith('_')))
 
 
-SK1 = 'scan_screen_kernel'              # one query tile (batch <= 128): the 4-wave nt form
+SK1 = 'scan_screen_lean3_kernel'        # one query tile (batch <= 128): the 4-wave nt instantiation of the same kernel
 SK = 'scan_screen_lean3_kernel'         # full query tiles: the headline's kernel (round 4)
 
 
