@@ -1318,6 +1318,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
     char* ring = ssm;
     const int q_base = (qt * NW + w) * C::QW;
     const bool q_ok = q_base + j < a.nq;
+    const bool wave_live = q_base < a.nq;                 // (uniform)
     float thr_s = q_ok ? -INFINITY : INFINITY;            // 4096 * max(own k-th best, shared threshold): only ever rises
     u32 cnt = 0;                                          // entries in this lane's query slot (equal in lanes j and j + 32)
     u64* const gslot = a.gcand + ((size_t)s_idx * a.nq + (q_ok ? q_base + j : 0)) * C::CAP;
@@ -1503,6 +1504,8 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
             auto step = [&](auto TI) {
                 constexpr int gs = decltype(TI)::value, t = gs % S_CS, cch = gs / S_CS;
                 constexpr int cur = 2 * P + cch, nxt = (cur + 1) % C::NR;
+                // (a wave none of whose 32 queries exist -- batches below 97 queries in the one-tile form -- only carries its DMA pieces)
+                if (NWV == 8 || wave_live) {
                 if (gs == 18 && !(a.share_thr & 2) && !(EXP & 8) && __builtin_expect(__ballot(mx > thr_s) != 0, 0))
                     slow_path(prev, lane_r0 + (int64_t)(tl - 1) * S_RT, 0xffffu);
                 frag_wait(fr[gs % S_PRE]);
@@ -1516,6 +1519,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
                 if (gs >= 1 && gs <= 8 && !(EXP & 8)) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(prev[2 * gs - 2]), "v"(prev[2 * gs - 1]));
                 if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], std::integral_constant<int, cur * S_SLOT + ((t + S_PRE) >> 2) * 128>{}, t + S_PRE);
                 else read_frag(fr[gs % S_PRE], std::integral_constant<int, nxt * S_SLOT + ((t + S_PRE - S_CS) >> 2) * 128>{}, t + S_PRE - S_CS);
+                }
                 if (gs % (S_TS / C::NIW) == 1) issue_part(std::integral_constant<int, (P + 4) % 6>{}, tp, gs / (S_TS / C::NIW));   // steps 1, 9, 17 | 1, 5, .., 21
                 if (gs == 4 && P % 2 == 0) refresh_gthr();
                 __builtin_amdgcn_sched_barrier(0);
