@@ -892,3 +892,25 @@ def test_deep_k_ladder_with_clustered_duplicates_tombstones_and_l2(rmu, corpus30
     scale = float((xl ** 2).sum(1).max())
     assert_topk_parity(-d, r, os_, or_, score_tol=2e-6 * scale + 1e-4, tie_tol=1e-6 * scale)
     il2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"RMU_SCREEN_LEAN": "0"}, {"RMU_SCREEN_LEAN": "1"}, {"RMU_SCREEN_LEAN": "2"}, {"RMU_SCREEN_LEAN4": "0"},
+                                 {"RMU_SCREEN_W8": "0"}, {"RMU_SCREEN_PACE": "0"}],
+                         ids=["default_lean3", "round3_8wave", "lean_compile_time_slots", "lean2_one_barrier_per_tile", "round3_one_tile_4wave",
+                              "four_waves_x_64_queries", "no_sibling_pacing"])
+def test_every_switchable_screening_kernel_returns_the_exact_answers(env):
+    """Every form of the screening kernel the PRODUCT library can be switched to (environment, read once per process) answers the same
+    batches -- full query tiles, a ragged tile, one query tile, a lone wave -- and every answer must be the exact fp32 scan's, bit for
+    bit, through the screening path.  (The K-split and 128-queries-per-wave forms exist in debug builds only: profiles/r04_ab_screen_forms.txt.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "screen_variant_driver.py")], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for nq, r in res.items():
+        assert r["screened"] == 1 and r["same"], (env, nq, r)
