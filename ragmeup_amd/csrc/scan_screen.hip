@@ -1575,15 +1575,15 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
             atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
         }
     }
-    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  Eight slots are read back per round trip.
+    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  All 32 slots are read back in ONE round trip (the query fragments are dead: registers are free).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int part = s_idx;
-    for (int j0 = 0; j0 < 32; j0 += 8) {
+    for (int j0 = 0; j0 < 32; j0 += 32) {
         if (q_base + j0 >= a.nq) break;
-        u64 key[8][1];
-        u32 nn[8];
+        u64 key[32][1];
+        u32 nn[32];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 32; ++e) {
             const int jj = j0 + e;
             nn[e] = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
             const u64* slot = (const u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
             key[e][0] = (u32)lane < nn[e] ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 32; ++e) {
             const int qq = q_base + j0 + e;
             if (qq < a.nq) {
                 u32 rank[1];
