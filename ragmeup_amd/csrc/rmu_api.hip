@@ -412,8 +412,11 @@ struct rmu_index {
     std::shared_mutex mu;
 };
 
-// the scan's LDS-DMA reads whole 128-row tiles: keep that many allocated rows past the last one
-static const int64_t kSlackRows = 128;
+// The scans' LDS-DMA rings run past the last row: the exact scan reads whole 128-row tiles; the screening scan (scan_screen_lean3_kernel)
+// looks four 32-row tiles ahead of the tile it computes and does not clamp, i.e. it touches up to (ceil(n / 32) + 4) * 32 - n <= 159 rows
+// past row n of the image.  Keep this many allocated (zero-filled) rows past the capacity of both matrices.
+static const int64_t kSlackRows = 256;
+static_assert(kSlackRows >= 160, "scan_screen_lean3_kernel's unclamped look-ahead");
 static int pad_dim(int d) { return d <= 192 ? 192 : (d <= 384 ? 384 : (d <= 768 ? 768 : -1)); }
 // L2SQ rows carry -|x|^2 in one extra column (see k_l2_aug_rows)
 static int pad_dim_metric(int d, int metric) { return pad_dim(metric == RMU_METRIC_L2SQ ? d + 1 : d); }

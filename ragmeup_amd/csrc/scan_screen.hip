@@ -639,7 +639,7 @@ __global__ __launch_bounds__(64 * NW) void scan_screen_kernel(const ScanLaunch a
 //   fragment reads   ds_read_b128 with the slot folded into the 16-bit offset field: no address arithmetic at all
 //   DMA pieces       LDS target = per-wave base + constant; source = ONE running 64-bit tile pointer (2 SALU per tile) + a per-lane 32-bit
 //                    offset that already contains the piece's look-ahead distance; no clamp -- the ring's look-ahead past the last tile
-//                    reads the image's slack rows (kSlackRows, zero-filled) or the next chunk's rows, and is never consumed
+//                    reads the image's slack rows (rmu_api.hip: kSlackRows, zero-filled) or the next chunk's rows, and is never consumed
 //   filter           a running v_max3 over the previous tile's 16 scores (8 VALU) and ONE compare per tile instead of 16 v_cmp + 16 s_or
 struct LeanCfg : ScreenCfg<1, 0, 8> {};
 
