@@ -891,7 +891,10 @@ static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb) {
     // save and pay for every launch gap and merge, so they climb faster
     const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
     std::vector<int64_t> bounds{n};
-    if (lvl_ratio > 1 && n >= 262144) {
+    // (round 4: from 4 096 rows up -- was 262 144.  A single COLD launch over 200k rows x 1024 queries takes 1.74 ms, twice what the ladder
+    // needs for 1M rows: every score that beats a still-empty threshold is appended.  With the ladder: 200k 0.45 ms, 20k 0.27, 8k 0.29.)
+    static const int64_t ladder_min = getenv("RMU_SCREEN_LADDER_MIN") ? atoll(getenv("RMU_SCREEN_LADDER_MIN")) : 4096;
+    if (lvl_ratio > 1 && n >= ladder_min) {
         int64_t c = n / lvl_ratio / 32 * 32;
         for (; c >= 65536 && bounds.size() < 24; c = c / lvl_ratio / 32 * 32) bounds.insert(bounds.begin(), c);
         // below 64k rows a range is a handful of tiles per workgroup and its appends cost next to nothing: ratio 8, down
