@@ -27,12 +27,17 @@ for d in big:
 PY
   rm -rf $OUT/$name
 }
-FORMS=${2:-"old ks kpp g4"}
+# forms: round3 | lean | lean2 | lean3 (product default) -- product library; ks | kpp | g4 -- debug builds only (python -m ragmeup_amd.build --debug-kernels)
+FORMS=${2:-"round3 lean lean2 lean3"}
 for f in $FORMS; do
   case $f in
-    old) run old RMU_SCREEN_G4=0 RMU_SCREEN_KS=0;;
-    ks)  run ks RMU_SCREEN_G4=0 RMU_SCREEN_KPP=0;;
-    kpp) run kpp RMU_SCREEN_G4=0 RMU_SCREEN_KPP=1;;
+    round3|old) run round3 RMU_SCREEN_LEAN=0;;
+    lean)  run lean RMU_SCREEN_LEAN=1;;
+    lean2) run lean2 RMU_SCREEN_LEAN=2;;
+    lean3) run lean3 RMU_SCREEN_LEAN=3;;
+    ks)  run ks RMU_SCREEN_KS=1 RMU_SCREEN_KPP=0;;
+    kpp) run kpp RMU_SCREEN_KS=1 RMU_SCREEN_KPP=1;;
     g4)  run g4 RMU_SCREEN_G4=1;;
+    *) echo "unknown form $f";;
   esac
 done
