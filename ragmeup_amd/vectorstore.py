@@ -403,10 +403,14 @@ class MI355XVectorStore(VectorStore):
         with self._lock:
             self._drain()
 
+    def _can_pipeline(self) -> bool:
+        """The GPU halves call the index from a worker thread: only the native index (and the stock factory methods) are known to allow it."""
+        return not ((self._index is not None and not hasattr(self._index, "_h")) or type(self)._new_index is not MI355XVectorStore._new_index)
+
     def _gpu_pump(self):
         """(worker thread) run every queued GPU half as one forward + one append; resolve their futures."""
+        import contextlib
         import numpy as np
-        import torch
         with self._wlock:
             items, self._work = self._work, []
         if not items:
@@ -429,7 +433,10 @@ class MI355XVectorStore(VectorStore):
                     lo += a.shape[0]
                 lens = np.concatenate([it[0][1] for it in items])
             n0, total = items[0][1], sum(it[2] for it in items)
-            with torch.cuda.device(emb.encoder.device):
+            dev = getattr(emb.encoder, "device", None)
+            if dev is not None:
+                import torch
+            with (torch.cuda.device(dev) if dev is not None else contextlib.nullcontext()):
                 vecs = emb.embed_token_arrays_device(ids, lens)
                 first = self._index.add(vecs)
                 if first != n0:
@@ -449,7 +456,7 @@ class MI355XVectorStore(VectorStore):
     def _add_pipelined(self, sel_texts, sel_ids, sel_metas_fn) -> bool:
         emb = self._embeddings
         if (self.auto_persist is True or not hasattr(emb, "tokenize_for_index") or not (128 <= len(sel_texts) <= getattr(emb, "pipeline_block", 0))
-                or (self._index is not None and not hasattr(self._index, "_h")) or type(self)._new_index is not MI355XVectorStore._new_index):
+                or not self._can_pipeline()):
             return False
         tok = emb.tokenize_for_index(sel_texts)          # the previous call's GPU half may still be running: this is the overlap
         if tok is None:

@@ -3,6 +3,7 @@ overrides the two index constructors with an oracle-backed fake; the product cla
 import hashlib
 import json
 import os
+import threading
 
 import numpy as np
 import pytest
@@ -441,3 +442,115 @@ def test_switch_interval_is_refcounted():
     assert abs(sys.getswitchinterval() - 2e-4) < 1e-9          # the second pipeline is still running
     b.__exit__(None, None, None)
     assert sys.getswitchinterval() == old
+
+
+# ---- the insert pipeline (vectorstore._add_pipelined / _gpu_pump / _drain) on the CPU: a two-halves Embeddings fake and the oracle-backed index ----
+class TokenEmbeddings(HashEmbeddings):
+    """HashEmbeddings with the two-halves interface of MI355XEmbeddings: the "token arrays" of a text are its md5 seed."""
+    pipeline_block = 8192
+
+    class _Enc:
+        HIDDEN, device = 384, None
+
+    encoder = _Enc()
+
+    def __init__(self):
+        self.forwards, self.fail_on = [], None
+        self.gate, self.entered = threading.Event(), threading.Event()
+        self.gate.set()
+
+    def tokenize_for_index(self, texts):
+        seeds = [int(hashlib.md5(t.replace("\n", " ").encode()).hexdigest()[:8], 16) for t in texts]
+        return np.asarray(seeds, np.int64).reshape(-1, 1), np.ones(len(texts), np.int32)
+
+    def embed_token_arrays_device(self, ids, lens):
+        self.entered.set()
+        assert self.gate.wait(20)
+        self.forwards.append(len(ids))
+        if self.fail_on is not None and len(self.forwards) == self.fail_on:
+            raise RuntimeError("device lost")
+        v = np.stack([np.random.default_rng(int(s)).standard_normal(384) for s in ids[:, 0]])
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+class PipeStore(FakeStore):
+    def _can_pipeline(self):
+        return True
+
+
+def _docs(lo, hi, tag=""):
+    return [Document(f"{tag}text number {i} " + "w " * (i % 7), {"source": f"s{i % 3}", "id": str(i)}) for i in range(lo, hi)]
+
+
+def test_insert_calls_queue_and_run_as_one_forward_and_nothing_can_tell():
+    """The reference's insert loop (server/RAGHelper.py:423-434) against the pipelined store: calls return with their GPU half queued, the
+    worker runs everything that is queued as ONE forward, and the store ends up exactly as after one big call."""
+    emb = TokenEmbeddings()
+    one = FakeStore(embeddings=emb, collection_name="one", auto_persist=False)
+    docs = _docs(0, 1000)
+    pks = [str(i) for i in range(1000)]
+    one.add_documents(docs, ids=pks)
+    emb.forwards.clear()
+    pip = PipeStore(embeddings=emb, collection_name="pip", auto_persist=False)
+    emb.gate.clear(); emb.entered.clear()
+    assert pip.add_documents(docs[:200], ids=pks[:200]) == pks[:200]
+    assert emb.entered.wait(20)                                  # the worker is inside the first forward ...
+    for lo in range(200, 1000, 200):                             # ... while four more calls return with their halves queued
+        assert pip.add_documents(docs[lo:lo + 200], ids=pks[lo:lo + 200]) == pks[lo:lo + 200]
+    assert len(pip._pending) == 5 and len(pip._texts) == 1000 and len(pip._index) == 0
+    emb.gate.set()
+    assert len(pip) == 1000 and not pip._pending                 # len() waits for the halves
+    assert emb.forwards == [200, 800]                            # the four queued calls ran as one forward
+    assert pip._pks == one._pks and np.array_equal(pip._index.x, one._index.x)
+    for q in ("text number 17 w w w ", "something else"):
+        a = [(d.metadata["pk"], s) for d, s in one.similarity_search_with_score(q, k=5)]
+        b = [(d.metadata["pk"], s) for d, s in pip.similarity_search_with_score(q, k=5)]
+        assert a == b
+    # an upsert spread over queued calls: one live row per pk at the end
+    emb.gate.clear(); emb.entered.clear()
+    pip.add_documents(_docs(0, 150, "new "), ids=pks[:150])
+    assert emb.entered.wait(20)
+    pip.add_documents(_docs(100, 300, "newer "), ids=pks[100:300])
+    emb.gate.set()
+    assert len(pip) == 1000 and len(pip._index) == len(pip._texts) == 1350
+    assert pip.similarity_search("newer text number 120 w ", k=1)[0].page_content.startswith("newer ")
+
+
+def test_a_failing_gpu_half_rolls_back_its_call_and_every_call_queued_behind_it():
+    emb = TokenEmbeddings()
+    pip = PipeStore(embeddings=emb, collection_name="pip", auto_persist=False)
+    pip.add_documents(_docs(0, 300), ids=[str(i) for i in range(300)])
+    pip.add_documents([Document("keep me", {"source": "k", "id": "shared"})], ids=["shared"])      # (a single document: synchronous path)
+    assert len(pip) == 301 and pip._pk_to_row["shared"] == 300
+    emb.forwards.clear(); emb.fail_on = 1
+    emb.gate.clear(); emb.entered.clear()
+    pip.add_documents(_docs(1000, 1200, "a ") + [Document("first shared", {"source": "f", "id": "shared"})], ids=["a" + str(i) for i in range(200)] + ["shared"])
+    assert emb.entered.wait(20)
+    pip.add_documents(_docs(2000, 2200, "b ") + [Document("second shared", {"source": "g", "id": "shared"})], ids=["b" + str(i) for i in range(200)] + ["shared"])
+    pip.add_documents(_docs(3000, 3150, "c "), ids=["c" + str(i) for i in range(150)])
+    assert len(pip._texts) == 301 + 201 + 201 + 150 and pip._pk_to_row["shared"] == 301 + 201 + 200
+    emb.gate.set()
+    with pytest.raises(RuntimeError, match="device lost"):
+        pip.flush()
+    emb.fail_on = None
+    assert emb.forwards == [201]                                 # the calls behind the failure never reached the encoder
+    assert len(pip._texts) == len(pip._alive) == 301 and len(pip._index) == 301 and len(pip) == 301
+    assert pip._pk_to_row["shared"] == 300 and pip._alive[300] and "a0" not in pip._pk_to_row and "c0" not in pip._pk_to_row
+    assert pip.similarity_search("keep me", k=1)[0].metadata["pk"] == "shared"
+    pip.add_documents(_docs(4000, 4200), ids=["d" + str(i) for i in range(200)])                   # the pipeline carries on
+    assert len(pip) == 501 and len(pip._index) == len(pip._texts) == 501
+
+
+def test_rows_that_land_out_of_step_are_tombstoned_and_the_records_stay_aligned():
+    emb = TokenEmbeddings()
+    pip = PipeStore(embeddings=emb, collection_name="pip", auto_persist=False)
+    pip.add_documents(_docs(0, 200), ids=[str(i) for i in range(200)])
+    pip.flush()
+    pip._index.add(np.zeros((3, 384), np.float32))               # somebody appended behind the store's back
+    pip.add_documents(_docs(200, 400), ids=[str(i) for i in range(200, 400)])
+    with pytest.raises(RuntimeError, match="out of step"):
+        pip.flush()
+    assert len(pip._index) == len(pip._texts) == 403 and len(pip) == 200      # the 200 rows are in the index, dead; records are placeholders
+    assert "200" not in pip._pk_to_row
+    pip.add_documents(_docs(200, 400), ids=[str(i) for i in range(200, 400)])
+    assert len(pip) == 400 and len(pip._index) == len(pip._texts) == 603
