@@ -3318,7 +3318,7 @@ static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, con
     const int64_t mt = ((m_cap + BM - 1) / BM + 7) / 8 * 8;     // token tiles, padded to a multiple of 8 (XCD map)
     const dim3 grid((unsigned)(mt * (N / BN)));
 #ifdef RMU_DEBUG_KERNELS
-    static const int dbg = getenv("RMU_GEMM_DBG") ? atoi(getenv("RMU_GEMM_DBG")) : 0;   // timing ablations: 1 no stores, 2 no main loop
+    static const int dbg = rmu_env("RMU_GEMM_DBG") ? atoi(rmu_env("RMU_GEMM_DBG")) : 0;   // timing ablations: 1 no stores, 2 no main loop
 #else
     const int dbg = 0;
 #endif
@@ -3331,7 +3331,7 @@ static void launch_gemm_cfg(const bf16* A, const bf16* W, const float* bias, con
 // Debug builds keep the switches: RMU_MID_TOKENS, RMU_SMALL_TB, RMU_GEMM_CFG (+ RMU_GEMM_CFG_MAX), RMU_G3_MIN.
 static int64_t mid_tokens() {
 #ifdef RMU_DEBUG_KERNELS
-    const int64_t v = getenv("RMU_MID_TOKENS") ? atoll(getenv("RMU_MID_TOKENS")) : SMALL_M;
+    const int64_t v = rmu_env("RMU_MID_TOKENS") ? atoll(rmu_env("RMU_MID_TOKENS")) : SMALL_M;
     return v < SMALL_M ? SMALL_M : v;
 #else
     return SMALL_M;
@@ -3339,7 +3339,7 @@ static int64_t mid_tokens() {
 }
 static int64_t g3_min_tokens() {
 #ifdef RMU_DEBUG_KERNELS
-    const int64_t v = getenv("RMU_G3_MIN") ? atoll(getenv("RMU_G3_MIN")) : 0;
+    const int64_t v = rmu_env("RMU_G3_MIN") ? atoll(rmu_env("RMU_G3_MIN")) : 0;
     return v > mid_tokens() ? v : mid_tokens();
 #else
     return SMALL_M;
@@ -3348,10 +3348,10 @@ static int64_t g3_min_tokens() {
 template <int EPI>
 static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const bf16* resid, bf16* out, const int* cu,
                         int batch, int64_t m_cap, int N, int K, hipStream_t s) {
-    static const bool small_ok = !(getenv("RMU_GEMM_SMALL") && atoi(getenv("RMU_GEMM_SMALL")) == 0);
+    static const bool small_ok = !(rmu_env("RMU_GEMM_SMALL") && atoi(rmu_env("RMU_GEMM_SMALL")) == 0);
     if (small_ok && m_cap <= mid_tokens() && (K == H || K == FF)) {
 #ifdef RMU_DEBUG_KERNELS
-        const int tb = getenv("RMU_SMALL_TB") ? atoi(getenv("RMU_SMALL_TB")) / 32 * 32 : 128;
+        const int tb = rmu_env("RMU_SMALL_TB") ? atoi(rmu_env("RMU_SMALL_TB")) / 32 * 32 : 128;
 #else
         const int tb = 128;
 #endif
@@ -3364,8 +3364,8 @@ static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const b
     // (best of the seven tile / stage / ring combinations measured in round 2)
 #ifdef RMU_DEBUG_KERNELS
     {   // (A/B of the mid-size shapes, measured and not adopted: RMU_GEMM_CFG = 1: 128x128 / 3 stages, 2: 128x128 / 4, 3: 64x128 / 4, 4: 64x128 / 6)
-        const int cfgv = getenv("RMU_GEMM_CFG") ? atoi(getenv("RMU_GEMM_CFG")) : 0;
-        const int64_t lim = getenv("RMU_GEMM_CFG_MAX") ? atoll(getenv("RMU_GEMM_CFG_MAX")) : 8192;
+        const int cfgv = rmu_env("RMU_GEMM_CFG") ? atoi(rmu_env("RMU_GEMM_CFG")) : 0;
+        const int64_t lim = rmu_env("RMU_GEMM_CFG_MAX") ? atoll(rmu_env("RMU_GEMM_CFG_MAX")) : 8192;
         if (cfgv && m_cap <= lim) {
             if (cfgv == 1) return launch_gemm_cfg<EPI, 2, 64, 3>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
             if (cfgv == 2) return launch_gemm_cfg<EPI, 2, 64, 4>(A, W, bias, resid, out, cu, batch, m_cap, N, K, s);
@@ -3385,13 +3385,13 @@ static void launch_gemm(const bf16* A, const bf16* W, const float* bias, const b
 static void launch_ffn_fused(const bf16* h1, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
     const dim3 grid((unsigned)((m_cap + ffn::TOK - 1) / ffn::TOK));
 #ifdef RMU_DEBUG_KERNELS
-    static const bool want_dbg = getenv("RMU_FFN_DBG") != nullptr;
+    static const bool want_dbg = rmu_env("RMU_FFN_DBG") != nullptr;
     if (want_dbg) {
         static const hipError_t attr_dbg = hipFuncSetAttribute((const void*)k_ffn_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn::LDS_BYTES);
         (void)attr_dbg;
         static unsigned long long* dbg = nullptr;
         if (!dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
-        static const unsigned long long fl = getenv("RMU_FFN_FLAGS") ? strtoull(getenv("RMU_FFN_FLAGS"), nullptr, 10) : 0ull;
+        static const unsigned long long fl = rmu_env("RMU_FFN_FLAGS") ? strtoull(rmu_env("RMU_FFN_FLAGS"), nullptr, 10) : 0ull;
         (void)hipMemcpyAsync(dbg + 7, &fl, 8, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL(k_ffn_fused<true>, grid, dim3(256), ffn::LDS_BYTES, s, h1, L.w1, L.b1, L.w2p, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch, dbg);
         unsigned long long h[5];
@@ -3422,8 +3422,8 @@ static void launch_ffn2_t(const bf16* x, const BertLayer& L, float eps, bf16* ou
 }
 // x = h1 (ln_in false) or the pre-LN out-proj sum y (ln_in true: LN1 happens in the kernel's prologue)
 static void launch_ffn2(const bf16* x, bool ln_in, const BertLayer& L, float eps, bf16* out, const int* cu, int batch, int64_t m_cap, hipStream_t s) {
-    static const int gv = getenv("RMU_FFN_GELU") ? atoi(getenv("RMU_FFN_GELU")) : 0;   // 1: scalar v_fma_f32 polynomial (A/B measurement)
-    static const int pf = getenv("RMU_FFN_PF") ? atoi(getenv("RMU_FFN_PF")) : 4;       // 8: eight weight fragments read ahead (A/B measurement)
+    static const int gv = rmu_env("RMU_FFN_GELU") ? atoi(rmu_env("RMU_FFN_GELU")) : 0;   // 1: scalar v_fma_f32 polynomial (A/B measurement)
+    static const int pf = rmu_env("RMU_FFN_PF") ? atoi(rmu_env("RMU_FFN_PF")) : 4;       // 8: eight weight fragments read ahead (A/B measurement)
     if (pf == 8 && ln_in && !gv) return launch_ffn2_t<true, 0, 8>(x, L, eps, out, cu, batch, m_cap, s);
     if (ln_in) { if (gv) launch_ffn2_t<true, 1, 4>(x, L, eps, out, cu, batch, m_cap, s); else launch_ffn2_t<true, 0, 4>(x, L, eps, out, cu, batch, m_cap, s); }
     else { if (gv) launch_ffn2_t<false, 1, 4>(x, L, eps, out, cu, batch, m_cap, s); else launch_ffn2_t<false, 0, 4>(x, L, eps, out, cu, batch, m_cap, s); }
@@ -3435,7 +3435,7 @@ static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* ou
     const bf16* w1 = (VAR & 2) ? L.w1s : L.w1;
     const bf16* w2 = (VAR & 2) ? L.w2s : L.w2p;
 #ifdef RMU_DEBUG_KERNELS
-    static const int dflags = getenv("RMU_FFN3_DBG") ? atoi(getenv("RMU_FFN3_DBG")) : 0;
+    static const int dflags = rmu_env("RMU_FFN3_DBG") ? atoi(rmu_env("RMU_FFN3_DBG")) : 0;
     if (dflags) {
         static const hipError_t attr_d = hipFuncSetAttribute((const void*)k_ffn3<LN_IN, PF, true, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
         (void)attr_d;
@@ -3467,7 +3467,7 @@ static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps
 #ifdef RMU_DEBUG_KERNELS
     // A/B forms (measured, 8192 chunks, per launch: VAR 0 3227 us, 1 3404, 2 3245, 3 3370 -- the packed-f32 activation is SLOWER than
     // hipcc's mostly scalar one although the loop shrinks from 431 to 357 instructions, and the stream form of the weights changes nothing)
-    static const int var = getenv("RMU_FFN3_VAR") ? atoi(getenv("RMU_FFN3_VAR")) : 0;
+    static const int var = rmu_env("RMU_FFN3_VAR") ? atoi(rmu_env("RMU_FFN3_VAR")) : 0;
 #define RMU_FFN3_CASE(V) case V: if (ln_in) launch_ffn3_t<true, 4, V>(x, L, eps, out, cu, batch, m_cap, s, out_tiled); else launch_ffn3_t<false, 4, V>(x, L, eps, out, cu, batch, m_cap, s, out_tiled); return;
     switch (var & 3) { RMU_FFN3_CASE(1) RMU_FFN3_CASE(2) RMU_FFN3_CASE(3) default: break; }
 #undef RMU_FFN3_CASE
@@ -3477,7 +3477,7 @@ static void launch_ffn3(const bf16* x, bool ln_in, const BertLayer& L, float eps
     // per 8192-chunk forward without it, 34.58-34.70 with it (three interleaved runs each, one box), k_ffn3 3346.7 vs 3351.7 us per launch
     // under rocprofv3, MFMA busy 0.393 vs 0.378: the LDS round trip behind each of a chunk's five barriers is NOT what the kernel waits
     // for (the second wave of the SIMD and the 3-slab DMA lead already cover it).  Debug builds: RMU_FFN3_LA=1.
-    static const int la = getenv("RMU_FFN3_LA") ? atoi(getenv("RMU_FFN3_LA")) : 0;
+    static const int la = rmu_env("RMU_FFN3_LA") ? atoi(rmu_env("RMU_FFN3_LA")) : 0;
     if (la) {
         if (ln_in) launch_ffn3_t<true, 4, 4>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
         else launch_ffn3_t<false, 4, 4>(x, L, eps, out, cu, batch, m_cap, s, out_tiled);
@@ -3493,13 +3493,13 @@ static void launch_gemm3(const bf16* A, const bf16* W, const float* bias, const 
                          int N, int K, hipStream_t s, bool a_tiled = false, int64_t hm_stride = 0) {
     static const int n_wg = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus / 8 * 8; }();
 #ifdef RMU_DEBUG_KERNELS
-    static const bool want_dbg = getenv("RMU_G3_DBG") != nullptr;
+    static const bool want_dbg = rmu_env("RMU_G3_DBG") != nullptr;
     if (want_dbg) {
         static const hipError_t attr_dbg = hipFuncSetAttribute((const void*)k_gemm3<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g3::LDS_BYTES);
         (void)attr_dbg;
         static unsigned long long* dbg = nullptr;
         if (!dbg) { (void)hipMalloc((void**)&dbg, 64); (void)hipMemset(dbg, 0, 64); }
-        static const int dflags = getenv("RMU_G3_FLAGS") ? atoi(getenv("RMU_G3_FLAGS")) : 0;   // 1: no DMA in the loop, 2: no fragment reads, 4: no epilogue (timing only)
+        static const int dflags = rmu_env("RMU_G3_FLAGS") ? atoi(rmu_env("RMU_G3_FLAGS")) : 0;   // 1: no DMA in the loop, 2: no fragment reads, 4: no epilogue (timing only)
         hipLaunchKernelGGL((k_gemm3<EPI, true>), dim3(n_wg), dim3(512), g3::LDS_BYTES, s, A, W, bias, resid, out, cu, batch, N, K, dbg, dflags | (a_tiled ? 256 : 0), (long)hm_stride);
         unsigned long long h[6];
         (void)hipStreamSynchronize(s);
@@ -3579,11 +3579,11 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     // residual lives in m->y, y2 = FFN2 + residual in m->h1, neither is ever normalised in memory; one k_layernorm after the last layer
     // feeds the pooling heads.  Token blocks per workgroup: enough of them to fill the chip, few enough to amortise the weight rows a
     // workgroup keeps in registers (N / 32 feature blocks x cap / tb token blocks ~ 256-512 workgroups).
-    static const bool small_ok_f = !(getenv("RMU_GEMM_SMALL") && atoi(getenv("RMU_GEMM_SMALL")) == 0);
-    static const bool ln_fuse = !(getenv("RMU_LN_FUSE") && atoi(getenv("RMU_LN_FUSE")) == 0);
+    static const bool small_ok_f = !(rmu_env("RMU_GEMM_SMALL") && atoi(rmu_env("RMU_GEMM_SMALL")) == 0);
+    static const bool ln_fuse = !(rmu_env("RMU_LN_FUSE") && atoi(rmu_env("RMU_LN_FUSE")) == 0);
     // measured (tools/ce_probe.py, cross-encoder forward per call): 14 pairs / 1548 tokens 0.464-0.468 ms on the tiled kernels, 0.412-0.424 here;
     // 30 pairs / 3360 tokens (cap 4800: above the threshold) 0.50-0.51 tiled vs 0.65 here -- the fold pays up to ~2.5k tokens
-    static const int64_t fold_tokens = getenv("RMU_FOLD_TOKENS") ? atoll(getenv("RMU_FOLD_TOKENS")) : FOLD_TOKENS;
+    static const int64_t fold_tokens = rmu_env("RMU_FOLD_TOKENS") ? atoll(rmu_env("RMU_FOLD_TOKENS")) : FOLD_TOKENS;
     if (cap <= fold_tokens && max_len <= 256 && small_ok_f && ln_fuse) {
         auto tb_for = [&](int n_feature_blocks) {       // tokens per workgroup: ~384 workgroups in all, a multiple of 32, at least 32
             const int64_t blocks = std::max<int64_t>(1, 384 / n_feature_blocks);
@@ -3599,7 +3599,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // adopted -- 14 pairs / 1548 tokens: 0.58 ms per forward against 0.42 with k_gemm_small and 0.47 with the tiled kernels; per launch
         // 8-28 us: a fragment-shaped load touches 32 cache lines for 1 KiB and the CU's address path is paid per line (debug builds: RMU_GEMM_MID=1)
 #ifdef RMU_DEBUG_KERNELS
-        static const bool mid_env = getenv("RMU_GEMM_MID") && atoi(getenv("RMU_GEMM_MID")) != 0;
+        static const bool mid_env = rmu_env("RMU_GEMM_MID") && atoi(rmu_env("RMU_GEMM_MID")) != 0;
         const bool mid = cap > SMALL_M && mid_env;
 #endif
         for (const BertLayer& L : m->layers) {
@@ -3631,22 +3631,22 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     } else
     for (const BertLayer& L : m->layers) {
         ++li;
-        static const int g3_mask = getenv("RMU_GEMM3") ? atoi(getenv("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
+        static const int g3_mask = rmu_env("RMU_GEMM3") ? atoi(rmu_env("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
         // The round-1/2 kernels k_attention and k_ffn_fused are instantiated in debug builds only (RMU_ATTN_V=1, RMU_FFN_V=1: the A/B
         // numbers of DESIGN.md); the product library carries the kernels it takes by default plus k_ffn2 (RMU_FFN_V=2).
 #ifdef RMU_DEBUG_KERNELS
-        static const int attn_v = getenv("RMU_ATTN_V") ? atoi(getenv("RMU_ATTN_V")) : 3;
+        static const int attn_v = rmu_env("RMU_ATTN_V") ? atoi(rmu_env("RMU_ATTN_V")) : 3;
 #else
         constexpr int attn_v = 3;
 #endif
         // QKV head-major when k_gemm3 writes it and k_attn3 reads it (RMU_QKV_HM=0: row-major); the stride between (part, head) planes is the
         // workspace's token capacity
-        static const bool hm_env = !(getenv("RMU_QKV_HM") && atoi(getenv("RMU_QKV_HM")) == 0);
+        static const bool hm_env = !(rmu_env("RMU_QKV_HM") && atoi(rmu_env("RMU_QKV_HM")) == 0);
         const int64_t hm_stride = (hm_env && (g3_mask & 1) && cap > g3_min_tokens() && attn_v == 3) ? m->ws_tokens : 0;
         if ((g3_mask & 1) && cap > g3_min_tokens()) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled, hm_stride);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
-        static const bool tiled_env = !(getenv("RMU_CTX_TILED") && atoi(getenv("RMU_CTX_TILED")) == 0);
+        static const bool tiled_env = !(rmu_env("RMU_CTX_TILED") && atoi(rmu_env("RMU_CTX_TILED")) == 0);
         const bool ctx_tiled = tiled_env && attn_v == 3 && !(g3_mask & 2) && cap > 32768;
 #ifdef RMU_DEBUG_KERNELS
         // k_attn4, the PERSISTENT form (round 4): measured SLOWER in every variant -- 8192 chunks, per layer under rocprofv3: k_attn3 837-851 us;
@@ -3654,9 +3654,9 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // and k_attn3's occupancy 1244 us; bench.py's embed leg 33.8-34.0 ms vs 35.7-36.2.  The hardware dispatcher already overlaps one
         // workgroup's cold start with three others' arithmetic AND balances the 16..256-token items dynamically; a static item list
         // loses both.  Debug builds: RMU_ATTN4=1, RMU_ATTN4_OCC=2|3|4.
-        static const int attn4 = getenv("RMU_ATTN4") ? atoi(getenv("RMU_ATTN4")) : 0;
+        static const int attn4 = rmu_env("RMU_ATTN4") ? atoi(rmu_env("RMU_ATTN4")) : 0;
         if (attn_v == 3 && attn4 && batch * NH > 4096 && max_len <= 256) {
-            static const int occ = getenv("RMU_ATTN4_OCC") ? atoi(getenv("RMU_ATTN4_OCC")) : 3;
+            static const int occ = rmu_env("RMU_ATTN4_OCC") ? atoi(rmu_env("RMU_ATTN4_OCC")) : 3;
             if (max_len <= 128) {
                 if (occ == 2) launch_attn4<4, 2>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
                 else if (occ == 4) launch_attn4<4, 4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
@@ -3677,12 +3677,12 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
 #endif
 #ifdef RMU_DEBUG_KERNELS
         // RMU_FFN_OUTPROJ=1: the out-proj GEMM runs inside k_ffn3's prologue (no launch, no pre-LN sum in memory)
-        static const bool op_env = getenv("RMU_FFN_OUTPROJ") && atoi(getenv("RMU_FFN_OUTPROJ")) != 0;
-        static const int fused_env0 = getenv("RMU_FUSED_FFN") ? atoi(getenv("RMU_FUSED_FFN")) : -1;
-        static const bool lnin0 = !(getenv("RMU_FFN_LNIN") && atoi(getenv("RMU_FFN_LNIN")) == 0);
-        static const bool v3 = !(getenv("RMU_FFN_V") && atoi(getenv("RMU_FFN_V")) != 3);
+        static const bool op_env = rmu_env("RMU_FFN_OUTPROJ") && atoi(rmu_env("RMU_FFN_OUTPROJ")) != 0;
+        static const int fused_env0 = rmu_env("RMU_FUSED_FFN") ? atoi(rmu_env("RMU_FUSED_FFN")) : -1;
+        static const bool lnin0 = !(rmu_env("RMU_FFN_LNIN") && atoi(rmu_env("RMU_FFN_LNIN")) == 0);
+        static const bool v3 = !(rmu_env("RMU_FFN_V") && atoi(rmu_env("RMU_FFN_V")) != 3);
         if (op_env && v3 && lnin0 && !(g3_mask & 6) && attn_v == 3 && (fused_env0 < 0 ? cap > 16384 : fused_env0 != 0)) {
-            static const bool h_env0 = !(getenv("RMU_H_TILED") && atoi(getenv("RMU_H_TILED")) == 0);
+            static const bool h_env0 = !(rmu_env("RMU_H_TILED") && atoi(rmu_env("RMU_H_TILED")) == 0);
             const bool h_out_tiled = h_env0 && ctx_tiled && (g3_mask & 1) && li < m->layers.size();
             launch_ffn3_outproj(m->ctx, ctx_tiled, m->h, h_in_tiled, L, eps, m->h1, m->cu, batch, cap, s, h_out_tiled);
             std::swap(m->h, m->h1);                // the kernel reads the residual h while other workgroups write the layer output: two buffers
@@ -3697,21 +3697,21 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // CU (~100 us per layer whatever the batch): below ~128 tiles most CUs would idle and the GEMM pair, whose feature tiles
         // spread over the chip, is faster (measured: 8k tokens 0.82 vs 0.95 ms per forward, one 16-token query 0.44 vs 0.63 ms;
         // 32k tokens 1.70 vs 1.45).  RMU_FUSED_FFN=0 / 1 forces either path.
-        static const int fused_env = getenv("RMU_FUSED_FFN") ? atoi(getenv("RMU_FUSED_FFN")) : -1;
+        static const int fused_env = rmu_env("RMU_FUSED_FFN") ? atoi(rmu_env("RMU_FUSED_FFN")) : -1;
         const bool fused_ffn = !(g3_mask & 4) && (fused_env < 0 ? cap > 16384 : fused_env != 0);
         // k_ffn3 (default; two waves per SIMD) and k_ffn2 (RMU_FFN_V=2; one) also take LayerNorm 1 into their prologue: the out-proj sum y
         // goes straight in (RMU_FFN_LNIN=0: separate k_layernorm launch; RMU_FFN_V=1: the round-2 kernel k_ffn_fused -- both kept
         // this round for the A/B numbers in DESIGN.md)
 #ifdef RMU_DEBUG_KERNELS
-        static const int ffn_v = getenv("RMU_FFN_V") ? atoi(getenv("RMU_FFN_V")) : 3;
+        static const int ffn_v = rmu_env("RMU_FFN_V") ? atoi(rmu_env("RMU_FFN_V")) : 3;
 #else
-        static const int ffn_v = getenv("RMU_FFN_V") && atoi(getenv("RMU_FFN_V")) == 2 ? 2 : 3;
+        static const int ffn_v = rmu_env("RMU_FFN_V") && atoi(rmu_env("RMU_FFN_V")) == 2 ? 2 : 3;
 #endif
-        static const bool ln_in = !(getenv("RMU_FFN_LNIN") && atoi(getenv("RMU_FFN_LNIN")) == 0);
+        static const bool ln_in = !(rmu_env("RMU_FFN_LNIN") && atoi(rmu_env("RMU_FFN_LNIN")) == 0);
         if (fused_ffn && ffn_v >= 2 && ln_in) {
             // Between layers h travels TILED (1-KiB blocks of 16 tokens x 32 features: the next QKV GEMM's A pieces and the next out-proj's
             // residual pieces become whole contiguous KiB); the last layer writes row-major for the pooling heads.  RMU_H_TILED=0: never.
-            static const bool h_env = !(getenv("RMU_H_TILED") && atoi(getenv("RMU_H_TILED")) == 0);
+            static const bool h_env = !(rmu_env("RMU_H_TILED") && atoi(rmu_env("RMU_H_TILED")) == 0);
             const bool h_out_tiled = h_env && ffn_v == 3 && ctx_tiled && (g3_mask & 1) && li < m->layers.size();
             if (ffn_v == 3) launch_ffn3(m->y, true, L, eps, m->h, m->cu, batch, cap, s, h_out_tiled);
             else launch_ffn2(m->y, true, L, eps, m->h, m->cu, batch, cap, s);
@@ -3795,7 +3795,7 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
         enqueue_forward(m, m->d_in, type_ids ? m->d_in + cap : nullptr, m->d_in + 2 * cap, batch, max_len, mode, m->d_out, kind == RMU_BERT_CE_LOGIT ? 1 : H, s);
         (void)hipMemcpyAsync(m->h_out, m->d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost, s);
     };
-    static const bool use_graph = !(getenv("RMU_GRAPH") && atoi(getenv("RMU_GRAPH")) == 0);
+    static const bool use_graph = !(rmu_env("RMU_GRAPH") && atoi(rmu_env("RMU_GRAPH")) == 0);
     const uint64_t key = ((uint64_t)batch << 32) | ((uint64_t)max_len << 16) | ((uint64_t)(mode & 0xfff) << 1) | (type_ids ? 1u : 0u);
     if (use_graph && !m->graphs.count(key) && m->graphs.size() >= MAX_GRAPHS) {          // full: the least recently used shape goes
         auto victim = m->graphs.begin();

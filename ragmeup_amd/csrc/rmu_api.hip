@@ -448,7 +448,7 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
     }
     idx->cap = cap;
     // screening image (+50% corpus memory): 384-wide rows only; RMU_SCREEN=0 disables
-    static const bool screen_on = !(getenv("RMU_SCREEN") && atoi(getenv("RMU_SCREEN")) == 0);
+    static const bool screen_on = !(rmu_env("RMU_SCREEN") && atoi(rmu_env("RMU_SCREEN")) == 0);
     if (screen_on && idx->dpad == 384 && dim == 384) {
         if (hipMalloc((void**)&idx->split, (size_t)(cap + kSlackRows) * RMU_IMG_ROW_BYTES) != hipSuccess) {
             idx->split = nullptr;   // not fatal: exact path only
@@ -677,7 +677,7 @@ extern "C" int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t
 
 static void launch_mmr(const rmu_index* idx, const float* dq, const int64_t* dr, int64_t nq, int fetch_k, int k, double lambda_mult, int* dout,
                        hipStream_t s) {
-    static const bool lds_off = getenv("RMU_MMR_LDS") && atoi(getenv("RMU_MMR_LDS")) == 0;
+    static const bool lds_off = rmu_env("RMU_MMR_LDS") && atoi(rmu_env("RMU_MMR_LDS")) == 0;
     if (idx->dim <= 384 && nq <= 65535 && !lds_off) {          // one workgroup per query, candidates staged in LDS (bit-identical picks)
         // rows [64][dim + 1] + q [dim] at the head of a (64 * 385 + 384)-float area, then the fp64 Gram block [65][64] + 1
         const size_t lds = (size_t)(64 * 385 + 384) * sizeof(float) + (size_t)(65 * 64 + 1) * sizeof(double);
@@ -870,7 +870,7 @@ static u64* dbg_buffer() {
 #endif
     static std::once_flag once;
     std::call_once(once, [] {
-        if (getenv("RMU_SCAN_EXP") && atoi(getenv("RMU_SCAN_EXP")) == 7) (void)hipMalloc((void**)&g_dbg, 128);
+        if (rmu_env("RMU_SCAN_EXP") && atoi(rmu_env("RMU_SCAN_EXP")) == 7) (void)hipMalloc((void**)&g_dbg, 128);
     });
     return g_dbg;
 }
@@ -885,15 +885,15 @@ static void dbg_dump(const char* what, int64_t rows, hipStream_t s) {
 
 // row ranges of the threshold ladder over n rows (see the comment in screen_enqueue)
 static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb) {
-    static const int lvl_min = getenv("RMU_SCREEN_MINLVL") ? atoi(getenv("RMU_SCREEN_MINLVL")) : 256;
-    static const int lvl_ratio_env = getenv("RMU_SCREEN_RATIO") ? atoi(getenv("RMU_SCREEN_RATIO")) : 0;   // <= 1: single launch
+    static const int lvl_min = rmu_env("RMU_SCREEN_MINLVL") ? atoi(rmu_env("RMU_SCREEN_MINLVL")) : 256;
+    static const int lvl_ratio_env = rmu_env("RMU_SCREEN_RATIO") ? atoi(rmu_env("RMU_SCREEN_RATIO")) : 0;   // <= 1: single launch
     // ratio 3 for full batches; small batches (one query tile, HBM-bound: 7.68 GB image per batch) have few appends to
     // save and pay for every launch gap and merge, so they climb faster
     const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
     std::vector<int64_t> bounds{n};
     // (round 4: from 4 096 rows up -- was 262 144.  A single COLD launch over 200k rows x 1024 queries takes 1.74 ms, twice what the ladder
     // needs for 1M rows: every score that beats a still-empty threshold is appended.  With the ladder: 200k 0.45 ms, 20k 0.27, 8k 0.29.)
-    static const int64_t ladder_min = getenv("RMU_SCREEN_LADDER_MIN") ? atoll(getenv("RMU_SCREEN_LADDER_MIN")) : 4096;
+    static const int64_t ladder_min = rmu_env("RMU_SCREEN_LADDER_MIN") ? atoll(rmu_env("RMU_SCREEN_LADDER_MIN")) : 4096;
     if (lvl_ratio > 1 && n >= ladder_min) {
         int64_t c = n / lvl_ratio / 32 * 32;
         for (; c >= 65536 && bounds.size() < 24; c = c / lvl_ratio / 32 * 32) bounds.insert(bounds.begin(), c);
@@ -915,7 +915,7 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
                           ScanLaunch* last_geom) {
     const int kp = kScreenKp;
     const int dpad = idx->dpad;
-    static const int share = getenv("RMU_NO_SHARED_THR") ? 0 : 1;
+    static const int share = rmu_env("RMU_NO_SHARED_THR") ? 0 : 1;
     const std::vector<int64_t> bounds = ladder_bounds(idx->n, nb);
     const int nl = (int)bounds.size();
     std::vector<ScanLaunch> lv((size_t)nl);
@@ -941,7 +941,7 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
     if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
         t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.ensure_events(2 * nl))
         return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
-    static const int nofilter = getenv("RMU_SCREEN_NOFILTER") != nullptr ? 2 : 0;
+    static const int nofilter = rmu_env("RMU_SCREEN_NOFILTER") != nullptr ? 2 : 0;
     const int sflags = share | nofilter;
     HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
     int rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
@@ -976,8 +976,8 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
 
 static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
     // (read once: the per-index switch is rmu_index_set_option(RMU_OPT_SCREEN_MIN_NQ))
-    static const bool env_set = getenv("RMU_SCREEN_MIN_NQ") != nullptr;
-    static const int env_min_nq = env_set ? atoi(getenv("RMU_SCREEN_MIN_NQ")) : 1;
+    static const bool env_set = rmu_env("RMU_SCREEN_MIN_NQ") != nullptr;
+    static const int env_min_nq = env_set ? atoi(rmu_env("RMU_SCREEN_MIN_NQ")) : 1;
     const bool min_nq_set = env_set || idx->screen_min_nq > 0;
     const int64_t screen_min_nq = idx->screen_min_nq > 0 ? idx->screen_min_nq : env_min_nq;
     // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays for the
@@ -990,12 +990,12 @@ static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
 
 // deep k (the 128-deep candidate geometry) over a large corpus takes the exact scan as a threshold ladder (see rmu_index_search)
 static bool deep_applies(const rmu_index* idx, int k) {
-    static const bool off = getenv("RMU_DEEP") && atoi(getenv("RMU_DEEP")) == 0;
+    static const bool off = rmu_env("RMU_DEEP") && atoi(rmu_env("RMU_DEEP")) == 0;
     return !off && k > 32 && idx->n >= 262144;
 }
 static std::vector<int64_t> deep_bounds(int64_t n) {
-    static const int first = getenv("RMU_DEEP_FIRST") ? atoi(getenv("RMU_DEEP_FIRST")) : 8192;
-    static const int ratio = getenv("RMU_DEEP_RATIO") ? atoi(getenv("RMU_DEEP_RATIO")) : 4;
+    static const int first = rmu_env("RMU_DEEP_FIRST") ? atoi(rmu_env("RMU_DEEP_FIRST")) : 8192;
+    static const int ratio = rmu_env("RMU_DEEP_RATIO") ? atoi(rmu_env("RMU_DEEP_RATIO")) : 4;
     std::vector<int64_t> b{n};
     for (int64_t c = n / ratio / 128 * 128; c >= first && b.size() < 8; c = c / ratio / 128 * 128) b.insert(b.begin(), c);
     return b;
@@ -1057,7 +1057,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             d_s = (float*)t.out_s.p;
             d_r = (int64_t*)t.out_r.p;
         }
-        static const int share = getenv("RMU_NO_SHARED_THR") ? 0 : 1;
+        static const int share = rmu_env("RMU_NO_SHARED_THR") ? 0 : 1;
         bool exact_timed = false;
         // ---- the exact fp32 fused scan + merge of `nqq` device queries.  plan first (all workspace is sized before anything
         // is enqueued: a grow-only buffer must not be re-allocated under work already in flight), then run.  `cond`

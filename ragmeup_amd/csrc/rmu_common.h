@@ -1,5 +1,6 @@
 // rmu_common.h -- shared device/host helpers for librmu.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -88,6 +89,13 @@ __device__ __forceinline__ void rmu_bitonic_merge_desc(u64 (&key)[NPL], int lane
             }
         }
     }
+}
+
+// Tuning / experiment switches (RMU_SCREEN_LEAN, RMU_GEMM3, ...) are honoured ONLY when RMU_TUNING=1 is set as well: a stray
+// RMU_* variable in a server's environment cannot change which kernels run.  Every switch is read once per process.
+inline const char* rmu_env(const char* name) {
+    static const bool on = [] { const char* t = getenv("RMU_TUNING"); return t != nullptr && atoi(t) == 1; }();
+    return on ? getenv(name) : nullptr;
 }
 
 // ---- launch descriptors shared between rmu_api.hip and the kernel translation units -------------

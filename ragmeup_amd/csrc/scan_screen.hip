@@ -2563,21 +2563,21 @@ int rmu_screen_lds_bytes(int qg) { return qg == 2 ? ScreenCfg<2>::LDS_BYTES : Sc
 // S row chunks (a multiple of 8 for the XCD-aware block map) so that grid = S * nqt fills the 256 CUs evenly
 int rmu_screen_plan(ScanLaunch* p) {
     if (p->k < 1 || p->k > 32 || p->nq < 1 || p->n_rows < 0 || p->dpad != SD) return RMU_E_INVALID;
-    static const int force_g = getenv("RMU_SCREEN_G") ? atoi(getenv("RMU_SCREEN_G")) : 0;
+    static const int force_g = rmu_env("RMU_SCREEN_G") ? atoi(rmu_env("RMU_SCREEN_G")) : 0;
     p->qg = force_g == 1 || force_g == 2 ? force_g : (p->nq > 128 ? 2 : 1);
     p->wq = 4; p->kv = 0;
     // Round-4 experiments (debug builds only; all bit-identical to the product kernel, none faster -- DESIGN.md 4.5): RMU_SCREEN_G4=1 = one wave per
     // SIMD, 128 queries per wave, four MFMAs per LDS fragment (scan_screen_g4_kernel, batches >= 512); RMU_SCREEN_KS=1 = K-split pairs
     // (scan_screen_ks_kernel; RMU_SCREEN_KPP=0 for its interleaved form)
 #ifdef RMU_DEBUG_KERNELS
-    static const int g4 = getenv("RMU_SCREEN_G4") ? atoi(getenv("RMU_SCREEN_G4")) : 0;
-    static const int ks = getenv("RMU_SCREEN_KS") ? atoi(getenv("RMU_SCREEN_KS")) : 0;
+    static const int g4 = rmu_env("RMU_SCREEN_G4") ? atoi(rmu_env("RMU_SCREEN_G4")) : 0;
+    static const int ks = rmu_env("RMU_SCREEN_KS") ? atoi(rmu_env("RMU_SCREEN_KS")) : 0;
 #else
     constexpr int g4 = 0, ks = 0;
 #endif
     const bool use_g4 = g4 && !force_g && p->nq >= 512;
     // full query tiles (> 128 queries): 8 waves x 32 queries (two waves per SIMD) instead of 4 x 64 -- RMU_SCREEN_W8=0 keeps the 4-wave form
-    static const int w8 = getenv("RMU_SCREEN_W8") ? atoi(getenv("RMU_SCREEN_W8")) : 1;
+    static const int w8 = rmu_env("RMU_SCREEN_W8") ? atoi(rmu_env("RMU_SCREEN_W8")) : 1;
     if (w8 && p->qg == 2 && !force_g) { p->qg = 1; p->wq = 8; }
     if (use_g4) { p->qg = 4; p->wq = 4; }
     const int qwg = use_g4 ? 512 : p->wq == 8 ? 256 : 128 * p->qg;
@@ -2600,11 +2600,11 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->s_chunks = s;
     p->grid = s * p->nqt;
     p->parts = s;
-    static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
+    static const int nt_env = rmu_env("RMU_NT") ? atoi(rmu_env("RMU_NT")) : 1;
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
     // lean form with one barrier per tile and candidates in global memory (scan_screen_lean2_kernel): RMU_SCREEN_LEAN=2
-    static const int lean_env = getenv("RMU_SCREEN_LEAN") ? atoi(getenv("RMU_SCREEN_LEAN")) : 3;
-    static const int lean4 = getenv("RMU_SCREEN_LEAN4") ? atoi(getenv("RMU_SCREEN_LEAN4")) : 1;     // 0: round 3's kernel for one query tile
+    static const int lean_env = rmu_env("RMU_SCREEN_LEAN") ? atoi(rmu_env("RMU_SCREEN_LEAN")) : 3;
+    static const int lean4 = rmu_env("RMU_SCREEN_LEAN4") ? atoi(rmu_env("RMU_SCREEN_LEAN4")) : 1;     // 0: round 3's kernel for one query tile
     const bool one_tile = p->wq == 4 && p->qg == 1 && p->nqt == 1;
     p->kv = use_g4 ? 2 : (ks && p->wq == 8) ? 1 : (lean_env == 3 && (p->wq == 8 || (lean4 && one_tile))) ? 4 : (lean_env == 2 && p->wq == 8) ? 3 : 0;
     p->lds_bytes = p->kv == 4 ? (p->wq == 8 ? Lean3Cfg<8>::LDS_BYTES : Lean3Cfg<4>::LDS_BYTES) : p->kv == 3 ? Lean2Cfg::LDS_BYTES : p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
@@ -2613,7 +2613,7 @@ int rmu_screen_plan(ScanLaunch* p) {
     // window in tiles (0 = off).  Measured (tools/pace_probe.py, 10M x 1024): 0 / 4 / 8 / 16 / 32 all 7.82-7.86 ms of scan kernels -- the pacing
     // costs nothing -- and on the round-4 boxes the siblings did not drift without it either (FETCH_SIZE 7.75-7.80 GB per batch = 1.01x
     // the image, L2 hit 0.758 with pacing off AND on; round 3's boxes: 15.1 GB, 0.53): kept on as the bound on that drift.
-    static const int pace_env = getenv("RMU_SCREEN_PACE") ? atoi(getenv("RMU_SCREEN_PACE")) : 8;
+    static const int pace_env = rmu_env("RMU_SCREEN_PACE") ? atoi(rmu_env("RMU_SCREEN_PACE")) : 8;
     static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
@@ -2698,7 +2698,7 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
 #ifdef RMU_DEBUG_KERNELS
     if (p->kv == 2) {
         if (p->dbg) return screen_launch_g4<4>(p, s);
-        static const int ex4 = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;   // timing ablations (wrong results)
+        static const int ex4 = rmu_env("RMU_SCREEN_EXP") ? atoi(rmu_env("RMU_SCREEN_EXP")) : 0;   // timing ablations (wrong results)
         if (ex4 == 1) return screen_launch_g4<1>(p, s);
         if (ex4 == 2) return screen_launch_g4<2>(p, s);
         if (ex4 == 3) return screen_launch_g4<3>(p, s);
@@ -2707,8 +2707,8 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
         return screen_launch_g4<0>(p, s);
     }
     if (p->kv == 1) {
-        if (p->dbg) return (getenv("RMU_SCREEN_KPP") && atoi(getenv("RMU_SCREEN_KPP")) == 0) ? screen_launch_ks<4>(p, s) : screen_launch_ks<20>(p, s);
-        static const int kpp = getenv("RMU_SCREEN_KPP") ? atoi(getenv("RMU_SCREEN_KPP")) : 1;
+        if (p->dbg) return (rmu_env("RMU_SCREEN_KPP") && atoi(rmu_env("RMU_SCREEN_KPP")) == 0) ? screen_launch_ks<4>(p, s) : screen_launch_ks<20>(p, s);
+        static const int kpp = rmu_env("RMU_SCREEN_KPP") ? atoi(rmu_env("RMU_SCREEN_KPP")) : 1;
         if (kpp) return screen_launch_ks<16>(p, s);
         return screen_launch_ks<0>(p, s);
     }
@@ -2717,10 +2717,10 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
 #endif
 #ifdef RMU_DEBUG_KERNELS      // timing ablations, ring / prefetch depth experiments, cycle counters (wrong results by design for EXP != 0):
                               // python -m ragmeup_amd.build --debug-kernels; tools/ablate_screen.sh
-    static const int ex = getenv("RMU_SCREEN_EXP") ? atoi(getenv("RMU_SCREEN_EXP")) : 0;
-    static const int pre = getenv("RMU_SCREEN_SPRE") ? atoi(getenv("RMU_SCREEN_SPRE")) : 4;
+    static const int ex = rmu_env("RMU_SCREEN_EXP") ? atoi(rmu_env("RMU_SCREEN_EXP")) : 0;
+    static const int pre = rmu_env("RMU_SCREEN_SPRE") ? atoi(rmu_env("RMU_SCREEN_SPRE")) : 4;
     if (p->wq == 8 && p->dbg) {
-        static const int ppd = getenv("RMU_SCREEN_PP") ? atoi(getenv("RMU_SCREEN_PP")) : 0;
+        static const int ppd = rmu_env("RMU_SCREEN_PP") ? atoi(rmu_env("RMU_SCREEN_PP")) : 0;
         return ppd ? screen_launch_cfg<1, 20, 4, 0, 0, 8>(p, s) : screen_launch_cfg<1, 4, 4, 0, 0, 8>(p, s);
     }
     if (p->dbg) {
@@ -2738,7 +2738,7 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
         if (ex == 9) return screen_launch_cfg<2, 9>(p, s);
         if (ex == 10) return screen_launch_cfg<2, 10>(p, s);
         if (ex == 11) return screen_launch_cfg<2, 11>(p, s);
-        static const int nrv = getenv("RMU_SCREEN_NR") ? atoi(getenv("RMU_SCREEN_NR")) : 0;
+        static const int nrv = rmu_env("RMU_SCREEN_NR") ? atoi(rmu_env("RMU_SCREEN_NR")) : 0;
         if (nrv == 4) return screen_launch_cfg<2, 0, 4, 4>(p, s);
         if (nrv == 5) return screen_launch_cfg<2, 0, 4, 5>(p, s);
         if (pre == 6) return screen_launch_cfg<2, 0, 6>(p, s);
@@ -2746,7 +2746,7 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     }
 #endif
     if (p->wq == 8) {                                                                 // full query tiles: 8 waves x 32 queries
-        static const int lean = getenv("RMU_SCREEN_LEAN") ? atoi(getenv("RMU_SCREEN_LEAN")) : 1;   // 0: round 3's form of the same kernel
+        static const int lean = rmu_env("RMU_SCREEN_LEAN") ? atoi(rmu_env("RMU_SCREEN_LEAN")) : 1;   // 0: round 3's form of the same kernel
         if (lean) {
             static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                   LeanCfg::LDS_BYTES);
@@ -2766,7 +2766,7 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
 #ifdef RMU_DEBUG_KERNELS
         // the PING-PONG form (EXP bit 4; see the kernel): measured 8.27-8.32 ms of scan kernels per 10M x 1024 batch against 7.69-7.81 for the
         // interleaved form (compares in the compute segment; 9.3 with them in the load segment, 9.0-9.1 with the DMA there, 11.0 in the first cut)
-        static const int pp = getenv("RMU_SCREEN_PP") ? atoi(getenv("RMU_SCREEN_PP")) : 0;
+        static const int pp = rmu_env("RMU_SCREEN_PP") ? atoi(rmu_env("RMU_SCREEN_PP")) : 0;
         if (pp) return screen_launch_cfg<1, 16, 4, 0, 0, 8>(p, s);
 #endif
         return screen_launch_cfg<1, 0, 4, 0, 0, 8>(p, s);

@@ -447,7 +447,7 @@ int launch_d(const ScanLaunch* p, hipStream_t s) {
     switch (p->wq * 2 + p->kv) {
         case 8: {
 #ifdef RMU_DEBUG_KERNELS      // timing ablations / cycle counters (wrong results by design): python -m ragmeup_amd.build --debug-kernels
-            static const int exp = getenv("RMU_SCAN_EXP") ? atoi(getenv("RMU_SCAN_EXP")) : 0;
+            static const int exp = rmu_env("RMU_SCAN_EXP") ? atoi(rmu_env("RMU_SCAN_EXP")) : 0;
             if (D == 384 && exp == 1) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 1>>(p, s);
             if (D == 384 && exp == 2) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 2>>(p, s);
             if (D == 384 && exp == 3) return launch_cfg<Cfg<384, 4, 96, 4, 64, 1, 3>>(p, s);
@@ -508,7 +508,7 @@ int rmu_scan_plan(ScanLaunch* p) {
     p->s_chunks = s;
     p->grid = s * p->nqt;
     p->parts = s * (4 / p->wq);
-    static const int nt_env = getenv("RMU_NT") ? atoi(getenv("RMU_NT")) : 1;
+    static const int nt_env = rmu_env("RMU_NT") ? atoi(rmu_env("RMU_NT")) : 1;
     p->nt = (nt_env && p->nqt == 1 && p->kv == 0 && p->wq <= 2) ? 1 : 0;
     p->lds_bytes = p->dpad == 384 ? lds_d<384>(p->wq, p->kv)
                  : p->dpad == 768 ? lds_d<768>(p->wq, p->kv) : lds_d<192>(p->wq, p->kv);

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restric
 
 static int merge_wg_launch(const u64* partial, int parts, int64_t nq, int k, const MergeOut& o, const RmuCond& cond, hipStream_t s) {
     if (k < 1 || k > 128 || parts < 1 || nq < 1) return RMU_E_INVALID;
-    static const int use_select = getenv("RMU_MERGE_SELECT") ? atoi(getenv("RMU_MERGE_SELECT")) : 1;
+    static const int use_select = rmu_env("RMU_MERGE_SELECT") ? atoi(rmu_env("RMU_MERGE_SELECT")) : 1;
     if (use_select && k <= 32 && parts <= 1024) {          // selection merge: one workgroup per query
         if (nq <= 512) hipLaunchKernelGGL((merge_select_kernel<1024, 1024>), dim3((unsigned)nq), dim3(1024), 0, s, partial, parts, nq, k, o, cond);
         else hipLaunchKernelGGL((merge_select_kernel<256, 1024>), dim3((unsigned)nq), dim3(256), 0, s, partial, parts, nq, k, o, cond);

@@ -72,3 +72,19 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path, librmu):
                         "-Wl,--allow-shlib-undefined", "-lm", "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert exe.exists()
+
+
+def test_the_library_reads_tuning_switches_only_behind_the_master_switch():
+    """Every RMU_* environment switch of librmu goes through rmu_env(), which answers only when RMU_TUNING=1 is set: a stray variable in
+    a server's environment cannot change which kernels run."""
+    import glob
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ragmeup_amd", "csrc")
+    direct = []
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        for m in re.finditer(r'(?<![_a-z])getenv\("(\w+)"\)', open(f).read()):
+            if m.group(1) != "RMU_TUNING":
+                direct.append((os.path.basename(f), m.group(1)))
+    assert direct == []
+    common = open(os.path.join(csrc, "rmu_common.h")).read()
+    assert 'inline const char* rmu_env(const char* name)' in common and 'getenv("RMU_TUNING")' in common

@@ -271,7 +271,7 @@ def test_every_switchable_kernel_variant_keeps_parity(env):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    out = subprocess.run([sys.executable, os.path.join(here, "enc_variant_driver.py")], env=dict(os.environ, **env),
+    out = subprocess.run([sys.executable, os.path.join(here, "enc_variant_driver.py")], env=dict(os.environ, RMU_TUNING="1", **env),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])

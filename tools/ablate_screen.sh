@@ -5,6 +5,7 @@
 # RMU_SCREEN_EXP bits: 1 = no corpus LDS-DMA, 2 = no LDS fragment reads, 8 = no filter compares (results are wrong by design);
 # RMU_SCREEN_NOFILTER=1 skips the candidate appends; RMU_SCAN_EXP=7 selects the build with cycle counters (clock64 per wave).
 # Prints, for the largest row range of the 10M x 1024 ladder: wall time of the launch (rocprofv3), cycles per wave, clock.
+export RMU_TUNING=1      # librmu honours its RMU_* switches only with this set
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export RMU_SCREEN_NOFILTER=1 RMU_SCAN_EXP=7

@@ -1,6 +1,8 @@
 """Latency of the reference's rerank call on the GPU box: the cross-encoder forward over a handful of (query, passage) pairs
 (<= 14 per ScoredCrossEncoderReranker.compress_documents call), device-resident ids, for a list of RMU_MID_TOKENS thresholds
 (tokens up to which the GEMMs take k_gemm_small; 256 = the round-3 behaviour).  python tools/ce_probe.py [256,4096] [14,30,100]"""
+import os as _os
+_os.environ.setdefault("RMU_TUNING", "1")
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of encoder kernel variants ON THE GPU BOX: per-kernel durations (rocprofv3 --kernel-trace --stats) and the encode rate of
 # tools/enc_smoke.py for each "name:VAR=val,VAR=val" spec.   bash tools/enc_ab.sh default: ffn2:RMU_FFN_V=2 rowmajor:RMU_H_TILED=0,RMU_CTX_TILED=0
+export RMU_TUNING=1      # librmu honours its RMU_* switches only with this set
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for spec in "$@"; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Per-kernel durations of the encoder for a list of RMU_GEMM2 masks (run ON THE GPU BOX):  bash tools/enc_prof.sh 7 3 0
+export RMU_TUNING=1      # librmu honours its RMU_* switches only with this set
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for g in "$@"; do

@@ -2,6 +2,7 @@
 the answers for a list of pacing windows (RMU_SCREEN_PACE, 0 = off), one index build.  Under rocprofv3 give ONE window and few steps.
   python tools/pace_probe.py [--pace 0,4,8,16,32] [--steps 20] [--rows 10000000] [--batch 1024]"""
 import argparse, os, sys, time
+os.environ.setdefault("RMU_TUNING", "1")     # librmu honours its RMU_* switches only with this set
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_shard

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, env...
   name=$1; shift
-  env "$@" timeout 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-include-regex "scan_screen" \
+  env RMU_TUNING=1 "$@" timeout 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-include-regex "scan_screen" \
       --output-format csv -d $OUT/$name -o a -- python $R/tools/pace_probe.py --env RMU_X --pace 0 --steps 3 > $OUT/$name.txt 2>&1
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$name" <<'PY' | tee -a $OUT/summary.txt

@@ -6,6 +6,7 @@
 # rocprofv3 (signal 6) and then hung in its finalisation until the box's limit -- 15 GPU-minutes lost.  The encoder is profiled
 # with --kernel-trace --stats only.
 set -u
+export RMU_TUNING=1      # librmu honours its RMU_* switches (RMU_SCREEN=0 below) only with this set
 TAG=${1:-r04p}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG

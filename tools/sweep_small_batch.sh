@@ -1,6 +1,7 @@
 #!/bin/bash
 # Ladder-geometry sweep for the HBM-bound batch sizes (10M x 384): RMU_SCREEN_RATIO x RMU_SCREEN_MINLVL, merge kernel.
 # usage: bash tools/sweep_small_batch.sh <outdir>
+export RMU_TUNING=1      # librmu honours its RMU_* switches only with this set
 out=${1:-gpurun_out/sweep}; mkdir -p $out
 for b in 32 128; do
   for cfg in "0 256" "8 16384" "8 131072" "16 131072" "32 131072" "64 262144"; do
