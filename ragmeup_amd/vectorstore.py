@@ -408,50 +408,56 @@ class MI355XVectorStore(VectorStore):
         return not ((self._index is not None and not hasattr(self._index, "_h")) or type(self)._new_index is not MI355XVectorStore._new_index)
 
     def _gpu_pump(self):
-        """(worker thread) run every queued GPU half as one forward + one append; resolve their futures."""
+        """(worker thread) run the queued GPU halves -- as many as fit one pipeline block -- as one forward + one append each round; resolve
+        their futures.  (Every call submits a pump; one that finds the queue empty returns: an earlier pump took its item along.)"""
         import contextlib
         import numpy as np
-        with self._wlock:
-            items, self._work = self._work, []
-        if not items:
-            return                                       # an earlier pump took this call's item along
-        if self._pipe_failed:
-            for it in items:
-                it[4].set_exception(RuntimeError("skipped: an earlier insert call of the pipeline failed"))
-            return
         emb = self._embeddings
-        try:
-            if len(items) == 1:
-                ids, lens = items[0][0]
-            else:
-                width = max(it[0][0].shape[1] for it in items)
-                ids = np.zeros((sum(it[0][0].shape[0] for it in items), width), dtype=items[0][0][0].dtype)
-                lo = 0
+        cap = int(getattr(emb, "pipeline_block", 0)) or 8192
+        while True:
+            with self._wlock:
+                items, total = [], 0
+                while self._work and (not items or total + self._work[0][2] <= cap):
+                    items.append(self._work.pop(0))
+                    total += items[-1][2]
+            if not items:
+                return
+            if self._pipe_failed:
                 for it in items:
-                    a = it[0][0]
-                    ids[lo:lo + a.shape[0], :a.shape[1]] = a
-                    lo += a.shape[0]
-                lens = np.concatenate([it[0][1] for it in items])
-            n0, total = items[0][1], sum(it[2] for it in items)
-            dev = getattr(emb.encoder, "device", None)
-            if dev is not None:
-                import torch
-            with (torch.cuda.device(dev) if dev is not None else contextlib.nullcontext()):
-                vecs = emb.embed_token_arrays_device(ids, lens)
-                first = self._index.add(vecs)
-                if first != n0:
-                    self._index.remove_rows(list(range(min(n0, first), first + total)))
-                    raise _RowsOutOfStep(first, total)
-                stale = [r for it in items for r in it[3]]
-                if stale:
-                    self._index.remove_rows(stale)
-        except BaseException as e:
-            self._pipe_failed = True
+                    it[4].set_exception(RuntimeError("skipped: an earlier insert call of the pipeline failed"))
+                continue
+            try:
+                if len(items) == 1:
+                    ids, lens = items[0][0]
+                else:
+                    width = max(it[0][0].shape[1] for it in items)
+                    ids = np.zeros((total, width), dtype=items[0][0][0].dtype)
+                    lo = 0
+                    for it in items:
+                        a = it[0][0]
+                        ids[lo:lo + a.shape[0], :a.shape[1]] = a
+                        lo += a.shape[0]
+                    lens = np.concatenate([it[0][1] for it in items])
+                n0 = items[0][1]
+                dev = getattr(emb.encoder, "device", None)
+                if dev is not None:
+                    import torch
+                with (torch.cuda.device(dev) if dev is not None else contextlib.nullcontext()):
+                    vecs = emb.embed_token_arrays_device(ids, lens)
+                    first = self._index.add(vecs)
+                    if first != n0:
+                        self._index.remove_rows(list(range(min(n0, first), first + total)))
+                        raise _RowsOutOfStep(first, total)
+                    stale = [r for it in items for r in it[3]]
+                    if stale:
+                        self._index.remove_rows(stale)
+            except BaseException as e:
+                self._pipe_failed = True
+                for it in items:
+                    it[4].set_exception(e)
+                continue
             for it in items:
-                it[4].set_exception(e)
-            return
-        for it in items:
-            it[4].set_result(None)
+                it[4].set_result(None)
 
     def _add_pipelined(self, sel_texts, sel_ids, sel_metas_fn) -> bool:
         emb = self._embeddings

@@ -506,6 +506,17 @@ def test_insert_calls_queue_and_run_as_one_forward_and_nothing_can_tell():
         a = [(d.metadata["pk"], s) for d, s in one.similarity_search_with_score(q, k=5)]
         b = [(d.metadata["pk"], s) for d, s in pip.similarity_search_with_score(q, k=5)]
         assert a == b
+    # a forward never grows past one pipeline block: with room for 500 chunks, three queued calls of 200 run as 400 + 200
+    small = PipeStore(embeddings=emb, collection_name="small", auto_persist=False)
+    emb.forwards.clear(); emb.pipeline_block = 500
+    emb.gate.clear(); emb.entered.clear()
+    small.add_documents(docs[:200], ids=pks[:200])
+    assert emb.entered.wait(20)
+    for lo in range(200, 800, 200):
+        small.add_documents(docs[lo:lo + 200], ids=pks[lo:lo + 200])
+    emb.gate.set()
+    assert len(small) == 800 and emb.forwards == [200, 400, 200] and np.array_equal(small._index.x, one._index.x[:800])
+    del emb.pipeline_block                                       # (back to the class default)
     # an upsert spread over queued calls: one live row per pk at the end
     emb.gate.clear(); emb.entered.clear()
     pip.add_documents(_docs(0, 150, "new "), ids=pks[:150])
