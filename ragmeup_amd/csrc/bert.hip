@@ -1554,6 +1554,60 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
     char* ring = gsm;
     float* b1s = (float*)(gsm + B1_OFF);
 
+    // ---- slab stream: W1 / W2 are the k_pack_ffn3 streams (slab images, contiguous); wave w moves bytes [2048 w, +2048) of a W1 slab and
+    // [3072 w, +3072) of a W2 slab, 1 KiB per instruction: one LDS base (M0) and one address per slab, the pieces are immediate offsets
+    // (applied to the global and the LDS address alike) -------------------------------------------------------------------------
+    const u32 v1 = (u32)lane * 16 + (u32)w * 2048, v2 = (u32)lane * 16 + (u32)w * 3072;
+    // (VAR bit 1 clear: W1 / W2 are the row-major matrices; DMA instruction q = it * 8 + w of a slab covers LDS units [64 q, +64), the
+    // swizzle lives in the per-lane source offset -- 4 rows x 256 B resp. 16 rows x 64 B per instruction, one address + M0 per instruction)
+    u32 w1off0 = 0, w2off0 = 0;
+    if constexpr (!(VAR & 2)) {
+        const int row1 = w * 4 + (lane >> 4), lu = (lane & 15) ^ (row1 & 15);
+        w1off0 = (u32)((row1 * H + (lu & 7) * 8 + (lu >> 3) * 192) * 2);
+        const int row2 = w * 16 + (lane >> 2), p2 = lane & 3;
+        w2off0 = (u32)((row2 * FF + ((p2 ^ ((row2 >> 2) & 3)) * 8)) * 2);
+    }
+    auto issue_part = [&](int ci, auto ic, auto itc) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int it = decltype(itc)::value;
+        if (DBG && (dflags & 4)) return;
+        if constexpr (i < 3) {
+            const u32 cc = (u32)(ci < NCH ? ci : NCH - 1);
+            if constexpr (VAR & 2) {
+                const u32 o = v1 + (cc * (u32)(3 * S1) + (u32)(i * S1));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W1 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + i * S1 + w * 2048), 16, it * 1024, 0);
+            } else {
+                const u32 o = w1off0 + (cc * (u32)(CH * H * 2) + (u32)(i * 128 + it * (32 * H * 2)));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W1 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + i * S1 + (it * 8 + w) * 1024), 16, 0, 0);
+            }
+        } else {
+            const u32 cc = (u32)(ci < 1 ? 0 : (ci > NCH ? NCH - 1 : ci - 1));
+            if constexpr (VAR & 2) {
+                const u32 o = v2 + (cc * (u32)(2 * S2) + (u32)((i - 3) * S2));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W2 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + W2_OFF + (i - 3) * S2 + w * 3072), 16, it * 1024, 0);
+            } else {
+                const u32 o = w2off0 + (cc * (u32)(CH * 2) + (u32)((i - 3) * 64 + it * (128 * FF * 2)));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W2 + o),
+                                                 (__attribute__((address_space(3))) void*)(ring + W2_OFF + (i - 3) * S2 + (it * 8 + w) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // (round 5) the stream's first four slabs are requested BEFORE the token rows: the ring is not touched by the LayerNorm prologue, and a
+    // workgroup is alone on its CU (150 KiB of LDS) -- nobody else covers the L2 round trip of slab 0 behind the prologue
+    auto issue_stream_prologue = [&]() {
+        static_for<4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            issue_part(0, ic, std::integral_constant<int, 0>{});
+            issue_part(0, ic, std::integral_constant<int, 1>{});
+            if constexpr (i == 3) issue_part(0, ic, std::integral_constant<int, 2>{});
+        });
+    };
+    if constexpr (!OP) issue_stream_prologue();
+
     // ---- this half's k range of the token rows as B fragments; b1 into LDS ---------------------------------------------------
     bf16x8 hf[12];
     if constexpr (!OP) {
@@ -1724,48 +1778,6 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- slab stream: W1 / W2 are the k_pack_ffn3 streams (slab images, contiguous); wave w moves bytes [2048 w, +2048) of a W1 slab and
-    // [3072 w, +3072) of a W2 slab, 1 KiB per instruction: one LDS base (M0) and one address per slab, the pieces are immediate offsets
-    // (applied to the global and the LDS address alike) -------------------------------------------------------------------------
-    const u32 v1 = (u32)lane * 16 + (u32)w * 2048, v2 = (u32)lane * 16 + (u32)w * 3072;
-    // (VAR bit 1 clear: W1 / W2 are the row-major matrices; DMA instruction q = it * 8 + w of a slab covers LDS units [64 q, +64), the
-    // swizzle lives in the per-lane source offset -- 4 rows x 256 B resp. 16 rows x 64 B per instruction, one address + M0 per instruction)
-    u32 w1off0 = 0, w2off0 = 0;
-    if constexpr (!(VAR & 2)) {
-        const int row1 = w * 4 + (lane >> 4), lu = (lane & 15) ^ (row1 & 15);
-        w1off0 = (u32)((row1 * H + (lu & 7) * 8 + (lu >> 3) * 192) * 2);
-        const int row2 = w * 16 + (lane >> 2), p2 = lane & 3;
-        w2off0 = (u32)((row2 * FF + ((p2 ^ ((row2 >> 2) & 3)) * 8)) * 2);
-    }
-    auto issue_part = [&](int ci, auto ic, auto itc) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int it = decltype(itc)::value;
-        if (DBG && (dflags & 4)) return;
-        if constexpr (i < 3) {
-            const u32 cc = (u32)(ci < NCH ? ci : NCH - 1);
-            if constexpr (VAR & 2) {
-                const u32 o = v1 + (cc * (u32)(3 * S1) + (u32)(i * S1));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W1 + o),
-                                                 (__attribute__((address_space(3))) void*)(ring + i * S1 + w * 2048), 16, it * 1024, 0);
-            } else {
-                const u32 o = w1off0 + (cc * (u32)(CH * H * 2) + (u32)(i * 128 + it * (32 * H * 2)));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W1 + o),
-                                                 (__attribute__((address_space(3))) void*)(ring + i * S1 + (it * 8 + w) * 1024), 16, 0, 0);
-            }
-        } else {
-            const u32 cc = (u32)(ci < 1 ? 0 : (ci > NCH ? NCH - 1 : ci - 1));
-            if constexpr (VAR & 2) {
-                const u32 o = v2 + (cc * (u32)(2 * S2) + (u32)((i - 3) * S2));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W2 + o),
-                                                 (__attribute__((address_space(3))) void*)(ring + W2_OFF + (i - 3) * S2 + w * 3072), 16, it * 1024, 0);
-            } else {
-                const u32 o = w2off0 + (cc * (u32)(CH * 2) + (u32)((i - 3) * 64 + it * (128 * FF * 2)));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)W2 + o),
-                                                 (__attribute__((address_space(3))) void*)(ring + W2_OFF + (i - 3) * S2 + (it * 8 + w) * 1024), 16, 0, 0);
-            }
-        }
-    };
-
     f32x16 acc2[6];                                 // outputs [192 s + 32 j, +32)
 #pragma unroll
     for (int o = 0; o < 6; ++o)
@@ -1898,13 +1910,8 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         }
     };
 
-    // prologue of the stream: slabs 0 .. 3 of iteration 0
-    static_for<4>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        issue_part(0, ic, std::integral_constant<int, 0>{});
-        issue_part(0, ic, std::integral_constant<int, 1>{});
-        if constexpr (i == 3) issue_part(0, ic, std::integral_constant<int, 2>{});
-    });
+    // prologue of the stream: slabs 0 .. 3 of iteration 0 (OP: the ring carried Wo until here; else they were requested at the top)
+    if constexpr (OP) issue_stream_prologue();
     load_bias(0);
     constexpr bool LA = (VAR & 4) != 0;
     if constexpr (LA) {
@@ -2026,9 +2033,96 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
             }
         });
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the tail reloads: the LDS becomes the pre-LN tile
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the tail reloads: the LDS becomes the output tile
     __syncthreads();
     char* tile = gsm;
+    // ---- epilogue (round 5): y = bf16(bf16(acc + b2) + resid), LayerNorm 2, store.  The round-3/4 form wrote y into an LDS tile and gave
+    // each wave 16 rows to normalise ONE AFTER THE OTHER, each with two 6-step ds_bpermute butterflies: 13 dependent LDS round trips per
+    // row, 208 per wave, with nothing else resident on the CU (one workgroup per CU) -- ~25 k cycles of a ~190 k-cycle workgroup.  Here the
+    // statistics are taken where the values are: a lane holds 96 of its token's 384 values, lane ^ 32 another 96, the partner wave
+    // (w ^ 4) the other 192 -- the same two exchanges as LayerNorm 1 in the prologue (two-pass, fp32); the tile receives the FINISHED
+    // bf16 rows and is copied out with 16-byte accesses, all reads in flight.  dflags bit 2048 (RMU_FFN3_EPI=0): the old form.
+    if (!(dflags & 2048)) {
+        // acc2[j][4 q + e] = output feature n = 192 s + 32 j + 8 q + 4 hh + e of token 32 p + r31; the residual h1[token][n] sits in
+        // hf[2 j + (q >> 1)] of this lane ((q & 1) == hh) or of lane ^ 32 (as k_ffn2); OP: in this lane's fragment in accumulator order
+        const int tr = 32 * p + r31;
+        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const u32x4 hv = __builtin_bit_cast(u32x4, hf[2 * j + qq]);
+                const u32x2 own = hh ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]};
+                const u32x2 oth = hh ? u32x2{hv[0], hv[1]} : u32x2{hv[2], hv[3]};
+                u32x2 rcv = {0u, 0u};
+                if constexpr (!OP) {
+                    rcv[0] = (u32)__shfl_xor((int)oth[0], 32);
+                    rcv[1] = (u32)__shfl_xor((int)oth[1], 32);
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int q = 2 * qq + qb;
+                    const u32x2 rs2 = OP ? (qb ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]}) : ((qb == hh) ? own : rcv);
+                    const bf16x4 res = __builtin_bit_cast(bf16x4, rs2);
+                    const int n = s * 192 + j * 32 + q * 8 + hh * 4;
+                    const f32x4 bv = *(const f32x4*)(b2 + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = bf2f((bf16)(bf2f((bf16)(acc2[j][4 * q + e] + bv[e])) + bf2f(res[e])));
+                        acc2[j][4 * q + e] = yv;
+                        sm += yv;
+                    }
+                }
+            }
+        float* sc = (float*)(gsm + XP_OFF);          // beyond the tile (TOK * TSTR <= RING); the loop's exchanges are over (barrier 4 of the last iteration)
+        sm += __shfl_xor(sm, 32);
+        if (hh == 0) sc[w * 32 + r31] = sm;
+        __syncthreads();
+        sm += sc[(w ^ 4) * 32 + r31];
+        const float mu = sm * (1.0f / H);
+        float qv = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc2[j][r] - mu; qv = fmaf(d, d, qv); }
+        qv += __shfl_xor(qv, 32);
+        if (hh == 0) sc[256 + w * 32 + r31] = qv;
+        __syncthreads();
+        qv += sc[256 + (w ^ 4) * 32 + r31];
+        const float rs = rsqrtf(qv * (1.0f / H) + eps);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = s * 192 + j * 32 + q * 8 + hh * 4;
+                const f32x4 ga = *(const f32x4*)(g + n), ba = *(const f32x4*)(bta + n);
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16)((acc2[j][4 * q + e] - mu) * rs * ga[e] + ba[e]);
+                *(bf16x4*)(tile + tr * TSTR + n * 2) = v;
+            }
+        __syncthreads();
+        // copy-out: wave w owns rows [16 w, +16), lanes 0..47 a 16-byte piece each; every read issued before the first store
+        const bool act = lane < 48;
+        const int c0 = (act ? lane : 0) * 8;
+        bf16x8 ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = *(const bf16x8*)(tile + (w * 16 + r) * TSTR + c0 * 2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + w * 16 + r;
+            if (act && m < M) {
+                // dflags bit 8: the TILED activation form -- 1-KiB blocks of 16 tokens x 32 features, [token block][feature block] order, unit u
+                // (8 features) of row r at u ^ tswz(r): exactly what a ring slot of the next layer's QKV GEMM / the out-proj's
+                // residual piece holds, so their DMA instructions read whole contiguous KiB
+                int64_t off = (int64_t)m * H + c0;
+                if (dflags & 256) { const int rr = m & 15; off = ((int64_t)(m >> 4) * (H / 32) + (c0 >> 5)) * 512 + rr * 32 + ((((c0 >> 3) & 3) ^ tswz(rr)) * 8); }
+                *(bf16x8*)(out + off) = ov[r];
+            }
+        }
+        return;
+    }
     {
         // acc2[j][4 q + e] = output feature n = 192 s + 32 j + 8 q + 4 hh + e of token 32 p + r31; the residual h1[token][n] sits in
         // hf[2 j + (q >> 1)] of this lane ((q & 1) == hh) or of lane ^ 32 (as k_ffn2).  y = bf16(bf16(acc + b2) + resid).
@@ -3446,8 +3540,9 @@ static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* ou
 #endif
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_ffn3<LN_IN, PF, false, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
     (void)attr_rc;
+    static const int epi_old = rmu_env("RMU_FFN3_EPI") && atoi(rmu_env("RMU_FFN3_EPI")) == 0 ? 2048 : 0;   // A/B: the round-3/4 epilogue (row-serial LayerNorm 2)
     hipLaunchKernelGGL((k_ffn3<LN_IN, PF, false, VAR>), grid, dim3(512), ffn3::LDS_BYTES, s, x, w1, L.b1, w2, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
-                       L.ln1g, L.ln1b, out_tiled ? 256 : 0);
+                       L.ln1g, L.ln1b, (out_tiled ? 256 : 0) | epi_old);
 }
 #ifdef RMU_DEBUG_KERNELS
 // the attention output in, the layer output out: out-proj + residual + LayerNorm 1 + FFN + LayerNorm 2 in one launch.  MEASURED (8192
@@ -3795,7 +3890,7 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
         enqueue_forward(m, m->d_in, type_ids ? m->d_in + cap : nullptr, m->d_in + 2 * cap, batch, max_len, mode, m->d_out, kind == RMU_BERT_CE_LOGIT ? 1 : H, s);
         (void)hipMemcpyAsync(m->h_out, m->d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost, s);
     };
-    static const bool use_graph = !(rmu_env("RMU_GRAPH") && atoi(rmu_env("RMU_GRAPH")) == 0);
+    static const bool use_graph = !(rmu_env_kill("RMU_GRAPH") && atoi(rmu_env_kill("RMU_GRAPH")) == 0);
     const uint64_t key = ((uint64_t)batch << 32) | ((uint64_t)max_len << 16) | ((uint64_t)(mode & 0xfff) << 1) | (type_ids ? 1u : 0u);
     if (use_graph && !m->graphs.count(key) && m->graphs.size() >= MAX_GRAPHS) {          // full: the least recently used shape goes
         auto victim = m->graphs.begin();

@@ -448,7 +448,7 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
     }
     idx->cap = cap;
     // screening image (+50% corpus memory): 384-wide rows only; RMU_SCREEN=0 disables
-    static const bool screen_on = !(rmu_env("RMU_SCREEN") && atoi(rmu_env("RMU_SCREEN")) == 0);
+    static const bool screen_on = !(rmu_env_kill("RMU_SCREEN") && atoi(rmu_env_kill("RMU_SCREEN")) == 0);
     if (screen_on && idx->dpad == 384 && dim == 384) {
         if (hipMalloc((void**)&idx->split, (size_t)(cap + kSlackRows) * RMU_IMG_ROW_BYTES) != hipSuccess) {
             idx->split = nullptr;   // not fatal: exact path only

@@ -1,6 +1,8 @@
 // rmu_common.h -- shared device/host helpers for librmu.so (gfx950 only).
 #pragma once
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -91,12 +93,30 @@ __device__ __forceinline__ void rmu_bitonic_merge_desc(u64 (&key)[NPL], int lane
     }
 }
 
-// Tuning / experiment switches (RMU_SCREEN_LEAN, RMU_GEMM3, ...) are honoured ONLY when RMU_TUNING=1 is set as well: a stray
-// RMU_* variable in a server's environment cannot change which kernels run.  Every switch is read once per process.
+// Tuning / experiment switches (RMU_GEMM3, RMU_SCREEN_PACE, ...) are honoured ONLY when RMU_TUNING=1 is set as well: a stray
+// RMU_* variable in a server's environment cannot change which kernels run.  Every switch is read once per process.  A process that
+// sets RMU_* variables WITHOUT the master switch is told so once on stderr (they used to be honoured: silence would hide the change).
+extern "C" char** environ;
 inline const char* rmu_env(const char* name) {
-    static const bool on = [] { const char* t = getenv("RMU_TUNING"); return t != nullptr && atoi(t) == 1; }();
+    static const bool on = [] {
+        const char* t = getenv("RMU_TUNING");
+        const bool o = t != nullptr && atoi(t) == 1;
+        if (!o && environ) {
+            for (char** e = environ; *e; ++e)
+                if (!strncmp(*e, "RMU_", 4) && strncmp(*e, "RMU_TUNING=", 11) && strncmp(*e, "RMU_SCREEN=", 11) && strncmp(*e, "RMU_GRAPH=", 10)) {
+                    fprintf(stderr, "librmu: %.*s is set but ignored: tuning switches are honoured only with RMU_TUNING=1 (DESIGN.md 6.1)\n",
+                            (int)(strchr(*e, '=') ? strchr(*e, '=') - *e : (long)strlen(*e)), *e);
+                    break;
+                }
+        }
+        return o;
+    }();
     return on ? getenv(name) : nullptr;
 }
+// The two SAFETY kill switches deployments may rely on -- RMU_SCREEN=0 (no fp16 screening image: every search is the exact fp32 scan) and
+// RMU_GRAPH=0 (rmu_bert_encode_host never captures a hipGraph) -- are honoured with or without the master switch: they only ever select
+// the more conservative path.
+inline const char* rmu_env_kill(const char* name) { return getenv(name); }
 
 // ---- launch descriptors shared between rmu_api.hip and the kernel translation units -------------
 // Device-side launch predicate.  The screening path decides per query ON THE DEVICE whether the exact scan has to re-run

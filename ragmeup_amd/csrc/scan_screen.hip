@@ -2563,7 +2563,15 @@ int rmu_screen_lds_bytes(int qg) { return qg == 2 ? ScreenCfg<2>::LDS_BYTES : Sc
 // S row chunks (a multiple of 8 for the XCD-aware block map) so that grid = S * nqt fills the 256 CUs evenly
 int rmu_screen_plan(ScanLaunch* p) {
     if (p->k < 1 || p->k > 32 || p->nq < 1 || p->n_rows < 0 || p->dpad != SD) return RMU_E_INVALID;
+    // (round 5) The PRODUCT library carries exactly the kernels it takes: scan_screen_lean3_kernel<NW = 8> for full query tiles and
+    // <NW = 4, nt> for one query tile.  The earlier forms of the same kernel (scan_screen_kernel in its 4- and 8-wave instantiations,
+    // scan_screen_lean_kernel, scan_screen_lean2_kernel) and the switches that select them (RMU_SCREEN_G / _W8 / _LEAN / _LEAN4) exist in
+    // debug builds only (python -m ragmeup_amd.build --debug-kernels), where tools/pace_probe.py reproduces DESIGN.md 4.5's A/B table.
+#ifdef RMU_DEBUG_KERNELS
     static const int force_g = rmu_env("RMU_SCREEN_G") ? atoi(rmu_env("RMU_SCREEN_G")) : 0;
+#else
+    constexpr int force_g = 0;
+#endif
     p->qg = force_g == 1 || force_g == 2 ? force_g : (p->nq > 128 ? 2 : 1);
     p->wq = 4; p->kv = 0;
     // Round-4 experiments (debug builds only; all bit-identical to the product kernel, none faster -- DESIGN.md 4.5): RMU_SCREEN_G4=1 = one wave per
@@ -2577,7 +2585,11 @@ int rmu_screen_plan(ScanLaunch* p) {
 #endif
     const bool use_g4 = g4 && !force_g && p->nq >= 512;
     // full query tiles (> 128 queries): 8 waves x 32 queries (two waves per SIMD) instead of 4 x 64 -- RMU_SCREEN_W8=0 keeps the 4-wave form
+#ifdef RMU_DEBUG_KERNELS
     static const int w8 = rmu_env("RMU_SCREEN_W8") ? atoi(rmu_env("RMU_SCREEN_W8")) : 1;
+#else
+    constexpr int w8 = 1;
+#endif
     if (w8 && p->qg == 2 && !force_g) { p->qg = 1; p->wq = 8; }
     if (use_g4) { p->qg = 4; p->wq = 4; }
     const int qwg = use_g4 ? 512 : p->wq == 8 ? 256 : 128 * p->qg;
@@ -2603,10 +2615,17 @@ int rmu_screen_plan(ScanLaunch* p) {
     static const int nt_env = rmu_env("RMU_NT") ? atoi(rmu_env("RMU_NT")) : 1;
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
     // lean form with one barrier per tile and candidates in global memory (scan_screen_lean2_kernel): RMU_SCREEN_LEAN=2
+#ifdef RMU_DEBUG_KERNELS
     static const int lean_env = rmu_env("RMU_SCREEN_LEAN") ? atoi(rmu_env("RMU_SCREEN_LEAN")) : 3;
     static const int lean4 = rmu_env("RMU_SCREEN_LEAN4") ? atoi(rmu_env("RMU_SCREEN_LEAN4")) : 1;     // 0: round 3's kernel for one query tile
+#else
+    constexpr int lean_env = 3, lean4 = 1;
+#endif
     const bool one_tile = p->wq == 4 && p->qg == 1 && p->nqt == 1;
     p->kv = use_g4 ? 2 : (ks && p->wq == 8) ? 1 : (lean_env == 3 && (p->wq == 8 || (lean4 && one_tile))) ? 4 : (lean_env == 2 && p->wq == 8) ? 3 : 0;
+#ifndef RMU_DEBUG_KERNELS
+    if (p->kv != 4) return RMU_E_INVALID;      // every product geometry is one of the two lean3 instantiations
+#endif
     p->lds_bytes = p->kv == 4 ? (p->wq == 8 ? Lean3Cfg<8>::LDS_BYTES : Lean3Cfg<4>::LDS_BYTES) : p->kv == 3 ? Lean2Cfg::LDS_BYTES : p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
     // sibling pacing (see the kernel): query tiles of a chunk on one XCD, 2..4 of them, the whole grid resident at once (these
     // kernels take > 80 KiB of LDS: one workgroup per CU), and enough tiles per workgroup for drift to matter
@@ -2678,6 +2697,9 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
         hipLaunchKernelGGL((scan_screen_lean3_kernel<0>), dim3(p->grid), dim3(512), Lean3Cfg<8>::LDS_BYTES, s, *p);
         return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
     }
+#ifndef RMU_DEBUG_KERNELS
+    return RMU_E_INVALID;                      // rmu_screen_plan hands the product library kv == 4 only
+#else
     if (p->kv == 3) {
         static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                               Lean2Cfg::LDS_BYTES);
@@ -2773,6 +2795,7 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     }
     if (p->qg == 2) return screen_launch_cfg<2>(p, s);                                // RMU_SCREEN_W8=0 / RMU_SCREEN_G=2: 4 waves x 64 queries
     return p->nt ? screen_launch_cfg<1, 0, 4, 0, 1>(p, s) : screen_launch_cfg<1>(p, s);
+#endif
 }
 
 int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s) {

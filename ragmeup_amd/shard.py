@@ -136,9 +136,14 @@ class ShardedSearcher:
         with torch.cuda.stream(side):
             s, r = self.index.search(q, k, row_base=self.row_base, stream=side.cuda_stream)
             out = self.comm.allgather_topk(s, r, smaller_better=self.smaller_better, stream=side.cuda_stream)
-            for t in (q, s, r, *out):
-                t.record_stream(side)
         cur.wait_stream(side)
+        # Allocator bookkeeping.  q was allocated on the caller's stream and is READ on `side`: q.record_stream(side).  s, r and the
+        # outputs were allocated under `side` (their home stream) and are used on the CALLER's stream from here on: recording `side` on
+        # them is a no-op -- once the caller dropped them the allocator could hand the blocks to the next side-stream search while the
+        # caller's stream is still reading -- so the stream to record is `cur`.
+        q.record_stream(side)
+        for t in (s, r, *out):
+            t.record_stream(cur)
         return out
 
     @property

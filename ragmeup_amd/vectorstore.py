@@ -29,7 +29,9 @@ import atexit
 import json
 import os
 import re
+import sys
 import threading
+import time
 import weakref
 from typing import Any, Iterable, Optional
 
@@ -131,7 +133,8 @@ class MI355XVectorStore(VectorStore):
     def __init__(self, embeddings: Any = None, collection_name: str = "LangChainCollection", connection: Any = None,
                  use_jsonb: bool = True, *, embedding_function: Any = None, connection_args: dict | None = None,
                  drop_old: bool = False, score_mode: str | None = None, metric: str = "ip", dim: int | None = None,
-                 device: int | None = None, auto_persist: bool | str = "atexit"):
+                 device: int | None = None, auto_persist: bool | str = "atexit", pipeline_inserts: bool | str = "auto",
+                 pipeline_window: float = 0.25):
         self._embeddings = embeddings if embeddings is not None else embedding_function
         if self._embeddings is None:
             raise ValueError("an Embeddings object is required")
@@ -159,6 +162,15 @@ class MI355XVectorStore(VectorStore):
         self._pks: list[str] = []
         self._alive: list[bool] = []
         self._pk_to_row: dict[str, int] = {}
+        # Cross-call insert pipeline (see _add_pipelined).  "auto" (default): a call's GPU half is deferred only INSIDE an insert loop --
+        # another add_texts ended less than `pipeline_window` seconds ago or halves are still pending -- so a single upload (the
+        # reference's POST /add_document -> _add_to_vector_database, server/RAGHelper.py:518-538) is synchronous and a failure is raised
+        # in the call that caused it; True: every call of 128..pipeline_block texts is deferred (round 4's behaviour); False: never.
+        if pipeline_inserts not in (True, False, "auto"):
+            raise ValueError("pipeline_inserts must be True, False or 'auto'")
+        self.pipeline_inserts = pipeline_inserts
+        self.pipeline_window = float(pipeline_window)
+        self._last_add_end = float("-inf")   # time.monotonic() at the end of the latest add_texts
         self._pending = []                   # GPU halves of add_texts calls still in flight, oldest first (see _add_pipelined)
         self._pipe_failed = False            # set by the worker when a half fails: the halves queued behind it do nothing
         self._work = []                      # GPU halves not yet taken by the worker (tok, n0, cnt, stale, future), oldest first
@@ -211,6 +223,7 @@ class MI355XVectorStore(VectorStore):
                                        f"re-index (vector_store_initial_load=True) or convert it to {paths[1]}")
         if documents:
             store.add_documents(documents, ids=ids)
+            store.flush()                    # a constructor-style call: the rows are in the index (or the failure raised) when it returns
         return store
 
     @classmethod
@@ -350,27 +363,34 @@ class MI355XVectorStore(VectorStore):
     # Nothing can observe the difference: every entry point that reads or changes the index (search, delete, persist, flush()) first
     # waits for the pending halves, and a failure rolls back that call's records AND those of the calls queued with or behind it, and is
     # raised there.
-    pipeline_depth = max(1, int(os.environ.get("RMU_ADD_DEPTH", "8")))   # insert calls whose GPU half may be pending (1 = no coalescing)
+    # insert calls whose GPU half may be pending (1 = no coalescing).  RMU_ADD_DEPTH is a tuning switch like librmu's: honoured only with
+    # RMU_TUNING=1, and a value that is not a number is ignored (it must not break the import)
+    pipeline_depth = 8
+    if os.environ.get("RMU_TUNING") == "1" and os.environ.get("RMU_ADD_DEPTH"):
+        try:
+            pipeline_depth = max(1, int(os.environ["RMU_ADD_DEPTH"]))
+        except ValueError:
+            import warnings
+            warnings.warn(f"RMU_ADD_DEPTH={os.environ['RMU_ADD_DEPTH']!r} is not an integer: ignored")
 
     def _drain(self, keep: int = 0):
         """(under self._lock) wait for pending GPU halves, oldest first, until at most `keep` are left; on failure undo and re-raise."""
+        from concurrent.futures import wait as _wait
         while len(self._pending) > keep:
-            try:
-                self._pending[0][0].result()
-            except BaseException as exc:
+            # An interrupt of THIS wait (KeyboardInterrupt / SystemExit in the waiting thread) is not a failure of the GPU half: it
+            # propagates with the records untouched and the half still pending.  Whether the half failed is read off the FINISHED future.
+            _wait([self._pending[0][0]])
+            exc = self._pending[0][0].exception()
+            if exc is not None:
                 ents, self._pending = self._pending, []
-                for ent in ents[1:]:                     # queued behind the failure: skipped by the worker
-                    try:
-                        ent[0].result()
-                    except BaseException:
-                        pass
+                _wait([ent[0] for ent in ents[1:]])      # queued behind the failure: skipped by the worker (their futures carry that)
                 self._pipe_failed = False
                 for (_f, n02, _c, undo2, stale2) in reversed(ents[1:]):   # newest first: a pk may appear in several calls
                     del self._texts[n02:], self._metas[n02:], self._pks[n02:], self._alive[n02:]
                     self._undo_pks(undo2, stale2)
                 self._rollback_failed_half(ents[0], exc)
-            else:
-                self._pending.pop(0)
+                raise AssertionError("unreachable: _rollback_failed_half raises")
+            self._pending.pop(0)
 
     def _rollback_failed_half(self, ent, exc):
         _fut, n0, cnt, undo, stale = ent
@@ -384,7 +404,7 @@ class MI355XVectorStore(VectorStore):
                 self._texts.append(""); self._metas.append({}); self._pks.append(""); self._alive.append(False)
             self._undo_pks(undo, stale)
             raise RuntimeError(f"index rows ({e.first}) and host records ({n0}) out of step: the batch was rolled back") from None
-        except Exception:
+        except BaseException:            # whatever the worker caught (it re-raises nothing itself: the exception lives in the future)
             del self._texts[n0:], self._metas[n0:], self._pks[n0:], self._alive[n0:]
             self._undo_pks(undo, stale)
             raise
@@ -448,11 +468,24 @@ class MI355XVectorStore(VectorStore):
                     if first != n0:
                         self._index.remove_rows(list(range(min(n0, first), first + total)))
                         raise _RowsOutOfStep(first, total)
-                    stale = [r for it in items for r in it[3]]
-                    if stale:
-                        self._index.remove_rows(stale)
+                    try:
+                        stale = [r for it in items for r in it[3]]
+                        if stale:
+                            self._index.remove_rows(stale)
+                    except Exception as e2:
+                        # the rows ARE in the index: a plain rollback would delete the records and leave them live (a search could return a
+                        # row without a record).  Tombstone them and report "out of step": placeholder records keep rows and records aligned.
+                        try:
+                            self._index.remove_rows(list(range(first, first + total)))
+                        except Exception:   # noqa: BLE001 - the index is beyond repair from here; the caller still learns of e2
+                            pass
+                        raise _RowsOutOfStep(first, total) from e2
             except BaseException as e:
                 self._pipe_failed = True
+                # said where it happens: with deferred halves the RuntimeError itself is raised by whichever call touches the store next
+                print(f"ragmeup_amd: a deferred insert of collection {self.collection_name!r} failed ({type(e).__name__}: {e}); "
+                      f"{sum(it[2] for it in items)} records of {len(items)} add_texts call(s) and everything queued behind them are rolled back",
+                      file=sys.stderr)
                 for it in items:
                     it[4].set_exception(e)
                 continue
@@ -461,9 +494,11 @@ class MI355XVectorStore(VectorStore):
 
     def _add_pipelined(self, sel_texts, sel_ids, sel_metas_fn) -> bool:
         emb = self._embeddings
-        if (self.auto_persist is True or not hasattr(emb, "tokenize_for_index") or not (128 <= len(sel_texts) <= getattr(emb, "pipeline_block", 0))
-                or not self._can_pipeline()):
+        if (self.pipeline_inserts is False or self.auto_persist is True or not hasattr(emb, "tokenize_for_index")
+                or not (128 <= len(sel_texts) <= getattr(emb, "pipeline_block", 0)) or not self._can_pipeline()):
             return False
+        if self.pipeline_inserts == "auto" and not self._pending and time.monotonic() - self._last_add_end > self.pipeline_window:
+            return False                                 # not inside an insert loop: this call is synchronous and raises its own failures
         tok = emb.tokenize_for_index(sel_texts)          # the previous call's GPU half may still be running: this is the overlap
         if tok is None:
             return False
@@ -514,6 +549,12 @@ class MI355XVectorStore(VectorStore):
         else:
             keep = sorted(last.values())
             sel_texts, sel_ids = [texts[i] for i in keep], [ids[i] for i in keep]
+        try:
+            return self._add_texts_body(texts, metadatas, ids, keep, sel_texts, sel_ids)
+        finally:
+            self._last_add_end = time.monotonic()
+
+    def _add_texts_body(self, texts, metadatas, ids, keep, sel_texts, sel_ids) -> list[str]:
         if self._add_pipelined(sel_texts, sel_ids, lambda: [dict(metadatas[i]) for i in keep]):
             return list(ids)
         # The host records are prepared WHILE the GPU embeds (both the tokenizer and the encoder run in librmu.so with the GIL

