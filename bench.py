@@ -736,7 +736,7 @@ def leg_rerank(args, x1m) -> dict:
     ids_t, tt_t, lens_t = (torch.as_tensor(a).cuda() for a in (ids, tt, lens))
 
     def step():
-        s, r = idx.search(q, 100)                                            # dense top-100 (exact fp32 scan: k > 24)
+        s, r = idx.search(q, 100)                                            # dense top-100 (exact fp32 scan: k > 32)
         logits = ce.encode_ids(ids_t, lens_t, tt_t, mode=1)                  # 100 (query, passage) pairs per query
         top = torch.topk(logits.view(nqr, 100), 10, dim=1)                   # final top-10
         return r.gather(1, top.indices)
@@ -859,7 +859,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,c1,mmr,chat,c2,embed,index,rerank")
+    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank")
     ap.add_argument("--index-texts", type=int, default=1_000_000, help="texts pushed through add_documents by the `index` leg (BASELINE.json configs[2]: 1M chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-identity-check", action="store_true",
@@ -929,11 +929,13 @@ def main(argv=None, hooks=None):
     if world > 1:
         dist.broadcast(q, 0)
         dist.broadcast(planted, 0)
-    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,c1,mmr,chat,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
+    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
     sample_host = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample_host = shard[:min(n_local, 2_000_000)].cpu().numpy()
     x1m = shard[:1_000_000].clone() if (legs & {"c2", "rerank"}) and n_local >= 1_000_000 else None
+    n_emu = N // 8
+    x_emu = shard[:n_emu].clone() if "emu8" in legs and on_gpu and n_local >= n_emu >= 1 else None
     del shard
     if on_gpu:
         torch.cuda.empty_cache()
@@ -1017,6 +1019,14 @@ def main(argv=None, hooks=None):
 
     # ---- secondary legs (N = 1): the other BASELINE configurations, each with its own roofline -------
     secondary = []
+    t_leg = [time.perf_counter()]
+
+    def note(what):               # progress on stderr (the JSON line on stdout stays the only stdout output)
+        now = time.perf_counter()
+        print(f"[bench] {what}: {now - t_leg[0]:.1f} s", file=sys.stderr, flush=True)
+        t_leg[0] = now
+
+    note("headline + identity check + kernel timing")
 
     def scan_leg(name, idx, qq, n_rows, steps, note=None):
         nq = qq.shape[0]
@@ -1036,6 +1046,50 @@ def main(argv=None, hooks=None):
         if f"b{b}" in legs and B >= b:
             secondary.append(scan_leg(f"HBM-bound regime: batch {b}" + (" (the reference's one query per call)" if b == 1 else ""),
                                       index, q[:b].contiguous(), n_local, 20))
+    # the north-star sentence of BASELINE.json (">= 10k queries/sec dense top-10 over 10M x 384 at >= 70 % HBM-bandwidth roofline on 1 GPU") lives in
+    # the small-batch regime; the driver keeps `roofline`, so the leg's figures are repeated there (on STEP time and on kernel time)
+    for leg in secondary:
+        if leg["name"].startswith("HBM-bound regime: batch 32") and roofline is not None and leg.get("roofline"):
+            r32 = leg["roofline"]
+            abytes = r32.get("algorithmic_bytes") or 0
+            roofline["north_star"] = {"batch": 32, "qps": leg["value"], "step_ms": leg["ms_per_step"], "kernel_ms": r32.get("kernel_ms"),
+                                      "hbm_frac_step": round(abytes / (leg["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if abytes else None,
+                                      "hbm_frac_kernel": r32.get("hbm_frac", r32.get("frac")), "launches": (r32.get("launch") or {}).get("launches"),
+                                      "target": ">= 10000 queries/sec at >= 0.70 of 8 TB/s (BASELINE.json north_star)"}
+    note("scan legs (exact / b128 / b32 / b1)")
+    if x_emu is not None:
+        # the 8-GPU step of BASELINE.json configs[3] EMULATED on one GPU -- the shard one rank of 8 owns (N / 8 rows), the
+        # whole sharded step as ShardedSearcher runs it (local scan -> pack -> rmu_shard_allgather_topk on a WORLD-SIZE-1 RCCL communicator ->
+        # device merge, all ordered on one side stream); what a real 8-rank step adds is the wire time of one 120-KB-per-rank all-gather
+        # (latency-bound, tens of us) -- NOT measured here and labelled so.  No 8-GPU node is reachable from this box.
+        try:
+            ie = FlatIndex(D, _native.METRIC_IP, capacity_hint=n_emu, device=local_rank)
+            ie.add(x_emu)
+            comm1 = NativeComm(NativeComm.unique_id(), 1, 0, device=local_rank)
+            se = ShardedSearcher(ie, row_base=0, comm=comm1, force_collective=True)
+            ms_emu = timed(lambda: se.search(q, K), steps=20, warmup=3)
+            ms_local = timed(lambda: ie.search(q, K), steps=20, warmup=3)
+            rl = scan_roofline(ie, lambda: ie.search(q, K), n_emu, D, B, K, steps=5)
+            ideal = ms_per_step / 8.0
+            secondary.append({
+                "name": "emu8: the per-rank step of the 8-way row-sharded search (BASELINE.json configs[3]) EMULATED on one GPU", "emulated": True,
+                "value": round(B / (ms_emu * 1e-3), 1), "unit": "queries/sec (projected whole-job rate of 8 ranks = queries of a batch / one rank's step time)",
+                "ms_per_step": round(ms_emu, 4),
+                "config": {"workload": f"{n_emu}x{D} shard (1/8 of {N} rows), batch {B}, top-{K}; local scan + pack + world-1 ncclAllGather + device merge, stream-ordered",
+                           "local_scan_only_ms": round(ms_local, 4), "exchange_and_merge_ms": round(ms_emu - ms_local, 4),
+                           "one_gpu_step_ms": round(ms_per_step, 4), "ideal_step_ms": round(ideal, 4)},
+                "projected_speedup_8_ranks": round(ms_per_step / ms_emu, 2),
+                "parallel_efficiency": round(ideal / ms_emu, 3),
+                "not_measured": "the xGMI wire time of the 8-rank all-gather (960 KB in all); a run on more than one GPU",
+                "roofline": rl})
+            if roofline is not None:
+                roofline["emulated_shard_8"] = {"emulated": True, "rows": n_emu, "step_ms": round(ms_emu, 4), "local_scan_ms": round(ms_local, 4),
+                                                "projected_speedup_8_ranks": round(ms_per_step / ms_emu, 2), "parallel_efficiency": round(ideal / ms_emu, 3)}
+            comm1.close(); ie.close()
+        except Exception as e:   # noqa: BLE001 - RCCL could not be bound on this box: say so instead of failing the bench
+            secondary.append({"name": "emu8", "emulated": True, "error": repr(e)[:300]})
+        del x_emu
+        note("emu8")
     if "c2" in legs and x1m is not None:
         i2 = FlatIndex(D, _native.METRIC_IP, capacity_hint=x1m.shape[0], device=local_rank)
         i2.add(x1m)
@@ -1070,18 +1124,14 @@ def main(argv=None, hooks=None):
     index.close()
     if on_gpu:
         torch.cuda.empty_cache()
-    if "c1" in legs:
-        secondary.append(leg_c1(args))
-    if "mmr" in legs:
-        secondary.append(leg_mmr(args))
-    if "chat" in legs:
-        secondary.append(leg_chat(args))
-    if "embed" in legs:
-        secondary.append(leg_embed(args))
-    if "index" in legs:
-        secondary.append(leg_index(args))
+    note("c2 + cpu baselines")
+    for name, fn in (("c1", leg_c1), ("mmr", leg_mmr), ("chat", leg_chat), ("embed", leg_embed), ("index", leg_index)):
+        if name in legs:
+            secondary.append(fn(args))
+            note(name)
     if "rerank" in legs and x1m is not None:
         secondary.append(leg_rerank(args, x1m))
+        note("rerank")
 
     path = roofline["path"] if roofline else "unknown"
     line = {

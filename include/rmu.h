@@ -51,6 +51,10 @@ extern "C" {
                              * default small batches over small corpora take the exact scan, which is faster there); 0: default.
                              * Results are identical either way (the tests force the path through this switch). */
 
+#define RMU_OPT_LADDER_RATIO 3   /* tuning: growth ratio of the screening path's threshold ladder above 64k rows (0 = default: 3, or the
+                             * small-batch default for <= 128 queries).  Results are identical for every value. */
+#define RMU_OPT_LADDER_FIRST 4   /* tuning: rows of the ladder's smallest first range (0 = default).  Results identical for every value. */
+
 #define RMU_MAX_K 112       /* largest k the fused scan keeps in LDS */
 #define RMU_MAX_DIM 768
 
@@ -119,7 +123,7 @@ int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch
 int rmu_index_save(rmu_index_t* idx, const char* path);
 int rmu_index_load(rmu_index_t** out, const char* path);
 
-/* Exact top-k of every query against all live rows (dim 384, k <= 24: fp16 screening + exact fp32 re-score under a
+/* Exact top-k of every query against all live rows (dim 384, k <= 32: fp16 screening + exact fp32 re-score under a
  * per-query sufficiency test; otherwise, and for every query that fails the test, the exact fp32 fused scan -- the
  * returned ids and scores are those of the exact scan either way; the failing queries are re-run by launches that are
  * predicated on the device, so the call never waits on the host for a decision and, given a caller stream with device

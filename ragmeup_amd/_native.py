@@ -14,6 +14,7 @@ METRIC_IP, METRIC_COSINE, METRIC_L2SQ = 0, 1, 2
 F_Q_DEVICE, F_OUT_DEVICE, F_SMALLER_BETTER = 1, 2, 4
 OPT_SCREEN = 1
 OPT_SCREEN_MIN_NQ = 2
+OPT_LADDER_RATIO, OPT_LADDER_FIRST = 3, 4
 STAT_CAPACITY, STAT_GROW_COUNT, STAT_GROW_MS, STAT_LIVE_ROWS = 1, 2, 3, 4
 COMM_ID_BYTES = 128
 MAX_K = 112

@@ -1606,7 +1606,6 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
             if constexpr (i == 3) issue_part(0, ic, std::integral_constant<int, 2>{});
         });
     };
-    if constexpr (!OP) issue_stream_prologue();
 
     // ---- this half's k range of the token rows as B fragments; b1 into LDS ---------------------------------------------------
     bf16x8 hf[12];
@@ -1615,6 +1614,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         const bf16* row = x + (int64_t)tok * H + s * 192 + hh * 8;
 #pragma unroll
         for (int j = 0; j < 12; ++j) hf[j] = *(const bf16x8*)(row + j * 16);
+        issue_stream_prologue();       // behind the token loads in the CU's in-order memory queue: LayerNorm 1 starts on the rows while the slabs land
     }
     for (int i = threadIdx.x; i < FF; i += 512) b1s[i] = b1[i];
     if constexpr (OP) {
@@ -1925,6 +1925,8 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         });
     }
 
+    // (measured and not kept, round 5: s_setprio 1 for the second-dispatched half of the workgroup -- waves 4-7 lose every contested issue
+    // slot to their older partners -- 3424.8 vs 3429.4 us per launch, same box: nothing)
     // Iteration c (ONE body, as k_ffn2): FFN1 partials of chunk min(c, NCH - 1); activation of the own tile of chunk c - 1;
     // FFN2 of chunk c - 1 over this half's outputs.
     for (int c = 0; c <= NCH; ++c) {
@@ -2041,8 +2043,13 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
     // row, 208 per wave, with nothing else resident on the CU (one workgroup per CU) -- ~25 k cycles of a ~190 k-cycle workgroup.  Here the
     // statistics are taken where the values are: a lane holds 96 of its token's 384 values, lane ^ 32 another 96, the partner wave
     // (w ^ 4) the other 192 -- the same two exchanges as LayerNorm 1 in the prologue (two-pass, fp32); the tile receives the FINISHED
-    // bf16 rows and is copied out with 16-byte accesses, all reads in flight.  dflags bit 2048 (RMU_FFN3_EPI=0): the old form.
+    // bf16 rows and is copied out with 16-byte accesses, all reads in flight.  Measured (profiles/r05_ab_ffn3.txt, same box): 3193.4 -> 3056.2 us
+    // per launch.  The old form stays in debug builds (dflags bit 2048, RMU_FFN3_EPI=0); with both in one kernel hipcc spills two registers.
+#ifdef RMU_DEBUG_KERNELS
     if (!(dflags & 2048)) {
+#else
+    {
+#endif
         // acc2[j][4 q + e] = output feature n = 192 s + 32 j + 8 q + 4 hh + e of token 32 p + r31; the residual h1[token][n] sits in
         // hf[2 j + (q >> 1)] of this lane ((q & 1) == hh) or of lane ^ 32 (as k_ffn2); OP: in this lane's fragment in accumulator order
         const int tr = 32 * p + r31;
@@ -2123,6 +2130,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         }
         return;
     }
+#ifdef RMU_DEBUG_KERNELS
     {
         // acc2[j][4 q + e] = output feature n = 192 s + 32 j + 8 q + 4 hh + e of token 32 p + r31; the residual h1[token][n] sits in
         // hf[2 j + (q >> 1)] of this lane ((q & 1) == hh) or of lane ^ 32 (as k_ffn2).  y = bf16(bf16(acc + b2) + resid).
@@ -2193,6 +2201,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
             }
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------

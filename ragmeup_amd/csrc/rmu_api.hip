@@ -407,6 +407,7 @@ struct rmu_index {
     int64_t grow_count = 0;         // re-allocations of the corpus matrix (+ image) by rmu_index_add, and their wall time
     double grow_ms = 0.0;
     bool screen_enabled = true;     // RMU_OPT_SCREEN: searches may take the screening path (when `split` exists)
+    int ladder_ratio = 0, ladder_first = 0;   // RMU_OPT_LADDER_RATIO / _FIRST (0 = defaults; tools/ladder_sweep.py)
     int64_t screen_min_nq = 0;      // RMU_OPT_SCREEN_MIN_NQ: > 0 = screen every batch of at least this many queries, whatever the corpus size
     std::vector<uint8_t> alive;
     std::shared_mutex mu;
@@ -861,7 +862,9 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
 // search
 // ------------------------------------------------------------------------------------------------
 static const int64_t kMaxQueriesPerLaunch = 8192;
-static const int kScreenKp = 32;     // K': candidates the screening pass keeps per query
+static const int kScreenKp = 32;     // K': candidates the screening pass keeps per query (k <= 24)
+// (round 5) 24 < k <= 32: K' = 40 -- the same eight spare candidates behind the k-th for the sufficiency test; the slots hold RMU_KS_CAP = 48
+static inline int screen_kp(int k) { return k <= 24 ? kScreenKp : 40; }
 
 static u64* g_dbg = nullptr;         // RMU_SCAN_EXP=7: cycle / event counters of the scan kernels (diagnostics only)
 static u64* dbg_buffer() {
@@ -884,9 +887,17 @@ static void dbg_dump(const char* what, int64_t rows, hipStream_t s) {
 }
 
 // row ranges of the threshold ladder over n rows (see the comment in screen_enqueue)
-static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb) {
-    static const int lvl_min = rmu_env("RMU_SCREEN_MINLVL") ? atoi(rmu_env("RMU_SCREEN_MINLVL")) : 256;
-    static const int lvl_ratio_env = rmu_env("RMU_SCREEN_RATIO") ? atoi(rmu_env("RMU_SCREEN_RATIO")) : 0;   // <= 1: single launch
+// first range of the ladder for batches of <= 128 queries (one query tile).  tools/ladder_sweep.py, 10M rows, same box, step ms at
+// (ratio : first) 8:256 / 8:2048 / 8:16384 / 16:16384 / 32:16384 -- B = 1: 1.302 / 1.277 / 1.269 / 1.303 / 1.275; B = 32: 1.414 / 1.380 /
+// 1.649 / 2.027 / 1.823; B = 128: 1.551 / 1.485 / 1.788 / 2.276 / 2.004 (profiles/r05_ladder_sweep.txt): one launch + merge less pays,
+// a colder start does not.  Full batches keep 256 (1.25M rows x 1024: 1.245 ms at 256, 1.372 at 2048, 1.794 at 16384).
+static constexpr int LADDER_FIRST_SMALL = 2048;
+static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb, int opt_ratio = 0, int opt_first = 0) {
+    static const int lvl_min_env = rmu_env("RMU_SCREEN_MINLVL") ? atoi(rmu_env("RMU_SCREEN_MINLVL")) : 0;
+    static const int lvl_ratio_env0 = rmu_env("RMU_SCREEN_RATIO") ? atoi(rmu_env("RMU_SCREEN_RATIO")) : 0;   // <= 1: single launch
+    // (per-index options RMU_OPT_LADDER_RATIO / _FIRST first, then the environment, then the defaults)
+    const int lvl_ratio_env = opt_ratio ? opt_ratio : lvl_ratio_env0;
+    const int lvl_min = opt_first ? opt_first : lvl_min_env ? lvl_min_env : (nb <= 128 ? LADDER_FIRST_SMALL : 256);
     // ratio 3 for full batches; small batches (one query tile, HBM-bound: 7.68 GB image per batch) have few appends to
     // save and pay for every launch gap and merge, so they climb faster
     const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
@@ -912,11 +923,10 @@ static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb) {
 // K' (ratio - 1) per query in total, and every append stalls a whole workgroup for ~1-3k cycles: this cut
 // the filter overhead of the 10M x 1024 scan from 5.2 to ~1.5 ms.
 static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb, hipStream_t s, bool timed, int* n_launches,
-                          ScanLaunch* last_geom) {
-    const int kp = kScreenKp;
+                          ScanLaunch* last_geom, int kp = kScreenKp) {
     const int dpad = idx->dpad;
     static const int share = rmu_env("RMU_NO_SHARED_THR") ? 0 : 1;
-    const std::vector<int64_t> bounds = ladder_bounds(idx->n, nb);
+    const std::vector<int64_t> bounds = ladder_bounds(idx->n, nb, idx->ladder_ratio, idx->ladder_first);
     const int nl = (int)bounds.size();
     std::vector<ScanLaunch> lv((size_t)nl);
     int slots = nl - 1;
@@ -984,7 +994,7 @@ static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
     // ladder's launches and merges per batch, which only pays off on a large enough corpus
     const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || min_nq_set;
     return idx->split && idx->screen_enabled && idx->dpad == 384 && idx->dim == 384 && idx->metric != RMU_METRIC_L2SQ &&
-           nb >= screen_min_nq && screen_pays && k <= 24 && idx->n > 0 && idx->xnorm_max > 0.f &&
+           nb >= screen_min_nq && screen_pays && k <= 32 && idx->n > 0 && idx->xnorm_max > 0.f &&
            idx->xnorm_max < 500.f;   // fp16(64*x) must not overflow
 }
 
@@ -1076,14 +1086,15 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             need_gthr = std::max(need_gthr, (size_t)((nqq + 127) / 128 * 128 + 64) * sizeof(u32));
             return RMU_OK;
         };
-        auto run_exact = [&](ScanLaunch& L, float* os, int64_t* orr, const int64_t* scatter, bool time_it) -> int {
+        // zero_gthr_bytes: bytes of the shared thresholds to zero in front of the launch (0: an earlier launch of a mutually exclusive
+        // group already did -- only ONE launch of such a group ever runs, and a launch that does not run touches nothing)
+        auto run_exact = [&](ScanLaunch& L, float* os, int64_t* orr, const int64_t* scatter, bool time_it, size_t zero_gthr_bytes) -> int {
             const bool has_cond = L.cond.p != nullptr;
             const size_t pbytes = (size_t)L.parts * L.nq * L.k * sizeof(u64);
-            const size_t gbytes = (size_t)((L.nq + 127) / 128 * 128 + 64) * sizeof(u32);
             L.partial = (u64*)t.partial.p;
             L.gthr = (u32*)t.gthr.p;
             L.share_thr = share;
-            HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
+            if (zero_gthr_bytes) HIP_TRY(hipMemsetAsync(t.gthr.p, 0, zero_gthr_bytes, s));
             int rc2;
             if (idx->n > 0) {
                 if (time_it) HIP_TRY(hipEventRecord(t.ev[2], s));
@@ -1107,14 +1118,18 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             //   1..32 flagged: the 32-query HBM-bound geometry; 33..nb/8: a batch of nb/8; more: the whole batch.
             // With nothing flagged (the normal case) each costs one empty grid (~2 us); no host round trip either way, so
             // the whole search is asynchronous on the stream it was given.
-            const int small_n = (int)(nb < 32 ? nb : 32), mid_n = (int)(nb / 8);
+            // (round 5) Every dependent launch of a search costs ~4.4 us of kernel boundary on this part, run or not, and a batch of <= 32
+            // queries already IS the 32-query geometry: one class there -- "anything flagged: the exact scan of the whole batch" -- without
+            // the gather (3 stream operations behind the re-score instead of 7); the classes of a larger batch share ONE threshold memset.
+            const bool one_class = nb <= 32;
+            const int small_n = (int)(nb < 32 ? nb : 32), mid_n = one_class ? 0 : (int)(nb / 8);
             const int gather_n = mid_n > small_n ? mid_n : small_n;
-            const int lim_small = mid_n > small_n ? small_n : mid_n;    // no mid launch: the small one covers 1..nb/8
+            const int lim_small = one_class ? 0 : (mid_n > small_n ? small_n : mid_n);    // no mid launch: the small one covers 1..nb/8
             if (t.flag.ensure(2 * sizeof(int)) || t.fb_i.ensure((size_t)nb * sizeof(int64_t)) ||
                 t.fbq.ensure((size_t)gather_n * dpad * sizeof(float)))
                 return fail(RMU_E_OOM, "rmu_index_search: re-run workspace");
             const int* cnt = (const int*)t.flag.p;
-            const RmuCond c1{cnt, 1, lim_small, 1}, c2{cnt, small_n + 1, mid_n, 1}, c3{cnt, mid_n + 1, 0x7fffffff, 0};
+            const RmuCond c1{cnt, 1, lim_small, 1}, c2{cnt, small_n + 1, mid_n, 1}, c3{cnt, (lim_small > 0 || mid_n > small_n ? mid_n : 0) + 1, 0x7fffffff, 0};
             ScanLaunch L1{}, L2{}, L3{};
             if (lim_small > 0 && (rc = plan_exact((const float*)t.fbq.p, small_n, &c1, &L1))) return rc;
             if (mid_n > small_n && (rc = plan_exact((const float*)t.fbq.p, mid_n, &c2, &L2))) return rc;
@@ -1123,20 +1138,23 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             int nl = 0;
             ScanLaunch lastg{};
             HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
-            rc = screen_enqueue(idx, t, qdev, nb, s, timed, &nl, &lastg);
+            rc = screen_enqueue(idx, t, qdev, nb, s, timed, &nl, &lastg, screen_kp(k));
             if (rc) return rc;
             // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip); queries failing the
             // sufficiency test are appended to the list fb_i (count in flag[0])
-            rc = rmu_rescore_launch((const u64*)t.ckeys.p, kScreenKp, idx->x, qdev, nb, k, idx->xnorm_max, idx->dx_max, row_base, d_s, d_r,
+            rc = rmu_rescore_launch((const u64*)t.ckeys.p, screen_kp(k), idx->x, qdev, nb, k, idx->xnorm_max, idx->dx_max, row_base, d_s, d_r,
                                     (int*)t.flag.p, (int64_t*)t.fb_i.p, nullptr, s);
             if (rc) return fail(rc, "rmu_index_search: re-score launch");
             t.grid = lastg.grid; t.block = 256; t.lds = lastg.lds_bytes; t.passes += nl;
-            hipLaunchKernelGGL(k_gather_flagged, dim3((unsigned)gather_n), dim3(128), 0, s, qdev, dpad, (const int64_t*)t.fb_i.p, cnt,
-                               (float*)t.fbq.p);
-            HIP_TRY(hipGetLastError());
-            if (lim_small > 0 && (rc = run_exact(L1, d_s, d_r, (const int64_t*)t.fb_i.p, false))) return rc;
-            if (mid_n > small_n && (rc = run_exact(L2, d_s, d_r, (const int64_t*)t.fb_i.p, false))) return rc;
-            if ((rc = run_exact(L3, d_s, d_r, nullptr, false))) return rc;
+            if (lim_small > 0 || mid_n > small_n) {
+                hipLaunchKernelGGL(k_gather_flagged, dim3((unsigned)gather_n), dim3(128), 0, s, qdev, dpad, (const int64_t*)t.fb_i.p, cnt,
+                                   (float*)t.fbq.p);
+                HIP_TRY(hipGetLastError());
+            }
+            size_t zero_once = need_gthr;          // the mutually exclusive re-run launches share one zeroing of the thresholds
+            if (lim_small > 0) { if ((rc = run_exact(L1, d_s, d_r, (const int64_t*)t.fb_i.p, false, zero_once))) return rc; zero_once = 0; }
+            if (mid_n > small_n) { if ((rc = run_exact(L2, d_s, d_r, (const int64_t*)t.fb_i.p, false, zero_once))) return rc; zero_once = 0; }
+            if ((rc = run_exact(L3, d_s, d_r, nullptr, false, zero_once))) return rc;
             HIP_TRY(hipMemcpyAsync(t.hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
             if (timed)
                 for (int l = 0; l < nl; ++l) {
@@ -1194,7 +1212,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             ScanLaunch L{};
             if ((rc = plan_exact(qdev, nb, nullptr, &L))) return rc;
             if (t.partial.ensure(need_partial) || t.gthr.ensure(need_gthr)) return fail(RMU_E_OOM, "rmu_index_search: partial workspace");
-            if ((rc = run_exact(L, d_s, d_r, nullptr, timed))) return rc;
+            if ((rc = run_exact(L, d_s, d_r, nullptr, timed, need_gthr))) return rc;
         }
         if (!out_dev) {
             HIP_TRY(hipMemcpyAsync(out_scores + q0 * k, d_s, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1281,6 +1299,8 @@ extern "C" int rmu_index_set_option(rmu_index_t* idx, int option, int64_t value)
     switch (option) {
         case RMU_OPT_SCREEN: idx->screen_enabled = value != 0; return RMU_OK;
         case RMU_OPT_SCREEN_MIN_NQ: idx->screen_min_nq = value > 0 ? value : 0; return RMU_OK;
+        case RMU_OPT_LADDER_RATIO: idx->ladder_ratio = value > 0 && value <= 4096 ? (int)value : 0; return RMU_OK;
+        case RMU_OPT_LADDER_FIRST: idx->ladder_first = value > 0 && value <= (1 << 30) ? (int)value : 0; return RMU_OK;
         default: return fail(RMU_E_INVALID, "rmu_index_set_option: unknown option");
     }
 }

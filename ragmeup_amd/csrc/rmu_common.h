@@ -156,7 +156,7 @@ struct ScanLaunch {
     // initialisation (the slot counts live in registers); contents are dead once the launch has written its partials
     u64* gcand;
 };
-#define RMU_KS_CAP 40
+#define RMU_KS_CAP 48     /* K' <= 40 kept candidates + 8 free slots between compactions (one key per lane in the rank: <= 64) */
 
 int rmu_scan_plan(ScanLaunch* p);                        // chooses geometry; returns 0 or RMU_E_INVALID
 int rmu_scan_launch(const ScanLaunch* p, hipStream_t s); // launches the fused scan

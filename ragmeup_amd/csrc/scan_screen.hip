@@ -2562,13 +2562,14 @@ int rmu_screen_lds_bytes(int qg) { return qg == 2 ? ScreenCfg<2>::LDS_BYTES : Sc
 // geometry of one screening launch: p->qg 32-query groups per wave (2 when the batch fills 256-query workgroups),
 // S row chunks (a multiple of 8 for the XCD-aware block map) so that grid = S * nqt fills the 256 CUs evenly
 int rmu_screen_plan(ScanLaunch* p) {
-    if (p->k < 1 || p->k > 32 || p->nq < 1 || p->n_rows < 0 || p->dpad != SD) return RMU_E_INVALID;
+    if (p->k < 1 || p->k > RMU_KS_CAP - 8 || p->nq < 1 || p->n_rows < 0 || p->dpad != SD) return RMU_E_INVALID;   // (p->k is K': 32 or 40)
     // (round 5) The PRODUCT library carries exactly the kernels it takes: scan_screen_lean3_kernel<NW = 8> for full query tiles and
     // <NW = 4, nt> for one query tile.  The earlier forms of the same kernel (scan_screen_kernel in its 4- and 8-wave instantiations,
     // scan_screen_lean_kernel, scan_screen_lean2_kernel) and the switches that select them (RMU_SCREEN_G / _W8 / _LEAN / _LEAN4) exist in
     // debug builds only (python -m ragmeup_amd.build --debug-kernels), where tools/pace_probe.py reproduces DESIGN.md 4.5's A/B table.
 #ifdef RMU_DEBUG_KERNELS
-    static const int force_g = rmu_env("RMU_SCREEN_G") ? atoi(rmu_env("RMU_SCREEN_G")) : 0;
+    static const int force_g_env = rmu_env("RMU_SCREEN_G") ? atoi(rmu_env("RMU_SCREEN_G")) : 0;
+    const int force_g = p->k > 32 ? 0 : force_g_env;      // K' = 40 (24 < k <= 32) exists for the lean3 kernel only: slots of RMU_KS_CAP keys
 #else
     constexpr int force_g = 0;
 #endif
@@ -2578,15 +2579,17 @@ int rmu_screen_plan(ScanLaunch* p) {
     // SIMD, 128 queries per wave, four MFMAs per LDS fragment (scan_screen_g4_kernel, batches >= 512); RMU_SCREEN_KS=1 = K-split pairs
     // (scan_screen_ks_kernel; RMU_SCREEN_KPP=0 for its interleaved form)
 #ifdef RMU_DEBUG_KERNELS
-    static const int g4 = rmu_env("RMU_SCREEN_G4") ? atoi(rmu_env("RMU_SCREEN_G4")) : 0;
-    static const int ks = rmu_env("RMU_SCREEN_KS") ? atoi(rmu_env("RMU_SCREEN_KS")) : 0;
+    static const int g4_env = rmu_env("RMU_SCREEN_G4") ? atoi(rmu_env("RMU_SCREEN_G4")) : 0;
+    static const int ks_env = rmu_env("RMU_SCREEN_KS") ? atoi(rmu_env("RMU_SCREEN_KS")) : 0;
+    const int g4 = p->k > 32 ? 0 : g4_env, ks = p->k > 32 ? 0 : ks_env;
 #else
     constexpr int g4 = 0, ks = 0;
 #endif
     const bool use_g4 = g4 && !force_g && p->nq >= 512;
     // full query tiles (> 128 queries): 8 waves x 32 queries (two waves per SIMD) instead of 4 x 64 -- RMU_SCREEN_W8=0 keeps the 4-wave form
 #ifdef RMU_DEBUG_KERNELS
-    static const int w8 = rmu_env("RMU_SCREEN_W8") ? atoi(rmu_env("RMU_SCREEN_W8")) : 1;
+    static const int w8_env = rmu_env("RMU_SCREEN_W8") ? atoi(rmu_env("RMU_SCREEN_W8")) : 1;
+    const int w8 = p->k > 32 ? 1 : w8_env;
 #else
     constexpr int w8 = 1;
 #endif
@@ -2616,8 +2619,9 @@ int rmu_screen_plan(ScanLaunch* p) {
     p->nt = (nt_env && p->nqt == 1 && p->qg == 1) ? 1 : 0;     // one query tile: each image byte is read by one workgroup
     // lean form with one barrier per tile and candidates in global memory (scan_screen_lean2_kernel): RMU_SCREEN_LEAN=2
 #ifdef RMU_DEBUG_KERNELS
-    static const int lean_env = rmu_env("RMU_SCREEN_LEAN") ? atoi(rmu_env("RMU_SCREEN_LEAN")) : 3;
-    static const int lean4 = rmu_env("RMU_SCREEN_LEAN4") ? atoi(rmu_env("RMU_SCREEN_LEAN4")) : 1;     // 0: round 3's kernel for one query tile
+    static const int lean_env0 = rmu_env("RMU_SCREEN_LEAN") ? atoi(rmu_env("RMU_SCREEN_LEAN")) : 3;
+    static const int lean4_env = rmu_env("RMU_SCREEN_LEAN4") ? atoi(rmu_env("RMU_SCREEN_LEAN4")) : 1;     // 0: round 3's kernel for one query tile
+    const int lean_env = p->k > 32 ? 3 : lean_env0, lean4 = p->k > 32 ? 1 : lean4_env;
 #else
     constexpr int lean_env = 3, lean4 = 1;
 #endif

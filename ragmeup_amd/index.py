@@ -181,6 +181,12 @@ class FlatIndex:
         (0 restores the default heuristics); results are identical either way."""
         N.check(self._lib.rmu_index_set_option(self._h, N.OPT_SCREEN_MIN_NQ, int(n)), "rmu_index_set_option")
 
+    def set_ladder(self, ratio: int = 0, first: int = 0):
+        """Tuning (RMU_OPT_LADDER_RATIO / RMU_OPT_LADDER_FIRST): geometry of the screening path's threshold ladder -- growth ratio above
+        64k rows and the size of the first range; 0 = the defaults.  Results are identical for every value (tools/ladder_sweep.py)."""
+        N.check(self._lib.rmu_index_set_option(self._h, N.OPT_LADDER_RATIO, int(ratio)), "rmu_index_set_option")
+        N.check(self._lib.rmu_index_set_option(self._h, N.OPT_LADDER_FIRST, int(first)), "rmu_index_set_option")
+
     def screen_candidates(self, q):
         """Test hook (rmu_index_screen_candidates): per query the screening pass's 32 candidates ->
         (approx scores [nq,32], rows [nq,32], exact fp32 scores of the same rows [nq,32], EPS [nq])."""

@@ -287,8 +287,8 @@ def test_text_in_recall_at_10_vs_transformers_on_weights_that_discriminate(kind,
     q = np.concatenate([enc.encode_host(qids[i:i + 1], qlens[i:i + 1], None, mode=0) for i in range(nq)])    # one query per call
     idx = FlatIndex(384)
     idx.add(x)
-    got_s, got_r = idx.search(q, 10)
-    got_r = got_r.cpu().numpy()
+    got_s, got_r = idx.search(q, 10)                                           # (host queries in -> host arrays out)
+    got_r = np.asarray(got_r.cpu() if hasattr(got_r, "cpu") else got_r)
     # the reference: transformers fp32 on the device (true fp32 matmuls), pinned to the host run of the same model on a sample
     model = bench.transformers_bert(w, "cuda")
     xr, qr = bench.reference_embed(model, ids, lens), bench.reference_embed(model, qids, qlens)

@@ -176,7 +176,7 @@ def test_cosine_metric_on_the_screening_path(rmu):
     s, r = idx.search(q, 10)
     assert idx.last_screened() != 0
     assert_topk_parity(s, r, *O.flat_search(q, x, 14, O.METRIC_COSINE))
-    s2, r2 = idx.search(q, 25)
+    s2, r2 = idx.search(q, 33)
     assert idx.last_screened() == 0 and np.array_equal(r2[:, :10], r) and np.array_equal(s2[:, :10], s)
     idx.close()
 
@@ -333,9 +333,10 @@ def test_rccl_allgather_path_world1(rmu, corpus50k):
             dist.destroy_process_group()
 
 
-# ---- fp16 screening pass + exact fp32 re-score (k <= 24, dim 384; RMU_OPT_SCREEN_MIN_NQ = 1 where the batch is small) ----------------------
-@pytest.mark.parametrize("nq,k", [(1, 20), (7, 10), (64, 24), (128, 10), (200, 1), (256, 16), (1024, 10)])
+# ---- fp16 screening pass + exact fp32 re-score (k <= 32, dim 384; RMU_OPT_SCREEN_MIN_NQ = 1 where the batch is small) ----------------------
+@pytest.mark.parametrize("nq,k", [(1, 20), (7, 10), (64, 24), (128, 10), (200, 1), (256, 16), (1024, 10), (7, 25), (200, 32), (1024, 28)])
 def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
+    """(round 5: 24 < k <= 32 screens with K' = 40 kept candidates)"""
     x = O.make_corpus(60_000)
     q, planted = O.make_queries(x, nq)
     idx = rmu.FlatIndex(384)
@@ -346,13 +347,13 @@ def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
     assert_topk_parity(s, r, *O.flat_search(q, x, k + 4))      # oracle a few ranks deeper: boundary near-ties
     assert (r[:, 0] == planted).all()
     # bit-identical to the exact fp32 scan (same summation order in the re-score)
-    s2, r2 = idx.search(q, 25 if k <= 24 else k)     # k > 24 always takes the exact scan
+    s2, r2 = idx.search(q, 33)                       # k > 32 always takes the exact scan
     assert idx.last_screened() == 0
     assert np.array_equal(r2[:, :k], r) and np.array_equal(s2[:, :k], s)
     idx.close()
 
 
-@pytest.mark.parametrize("n,nq,k", [(300_000, 384, 10), (262_144 + 17, 129, 16), (700_001, 1024, 5)])
+@pytest.mark.parametrize("n,nq,k", [(300_000, 384, 10), (262_144 + 17, 129, 16), (700_001, 1024, 5), (300_000, 300, 32), (262_144 + 17, 64, 27)])
 def test_screened_ladder_matches_oracle_and_exact_path(rmu, n, nq, k):
     """n >= 262144 rows: the corpus is scanned as a ladder of row ranges whose merged K'-th best seeds the next launch's
     thresholds (ragged last tiles, partial query tiles, 1- and 2-group wave geometries)."""
@@ -363,7 +364,7 @@ def test_screened_ladder_matches_oracle_and_exact_path(rmu, n, nq, k):
     s, r = idx.search(q, k)
     assert idx.last_screened() != 0, "expected the screening path"
     assert idx.last_geometry()["launches"] >= 3, "expected a multi-launch ladder"
-    s2, r2 = idx.search(q, 25)                       # exact fp32 scan
+    s2, r2 = idx.search(q, 33)                       # exact fp32 scan (k > 32)
     assert idx.last_screened() == 0
     assert np.array_equal(r2[:, :k], r) and np.array_equal(s2[:, :k], s)          # bit-identical
     assert (r[:, 0] == planted).all()
@@ -381,8 +382,8 @@ def test_screened_ladder_after_deletes_and_reload(rmu, tmp_path):
     idx.remove_rows(dead)
     s, r = idx.search(q, 10)
     assert idx.last_screened() != 0 and not np.isin(r, dead).any()
-    s2, r2 = idx.search(q, 25)
-    assert np.array_equal(r2[:, :10], r) and np.array_equal(s2[:, :10], s)
+    s2, r2 = idx.search(q, 33)
+    assert idx.last_screened() == 0 and np.array_equal(r2[:, :10], r) and np.array_equal(s2[:, :10], s)
     path = str(tmp_path / "big.rmu")
     idx.save(path)
     idx2 = rmu.FlatIndex.load(path)
