@@ -1151,6 +1151,14 @@ def main(argv=None, hooks=None):
         "identical_check": f"{nchk} queries x full shard, ids and scores bit-equal; default path answered by {'screen' if path_chk != 0 else 'exact'}",
         "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary, "host_cores": os.cpu_count(),
     }
+    # RCCL writes "Librccl path : ..." to the C stdout at communicator creation; with stdout redirected that sits in the C buffer until exit and
+    # would land BEHIND the JSON line.  Flush the C streams first: the JSON line is the last thing this process writes to stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    sys.stdout.flush()
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

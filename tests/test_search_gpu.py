@@ -353,7 +353,7 @@ def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
     idx.close()
 
 
-@pytest.mark.parametrize("n,nq,k", [(300_000, 384, 10), (262_144 + 17, 129, 16), (700_001, 1024, 5), (300_000, 300, 32), (262_144 + 17, 64, 27)])
+@pytest.mark.parametrize("n,nq,k", [(300_000, 384, 10), (262_144 + 17, 129, 16), (700_001, 1024, 5), (300_000, 300, 32), (262_144 + 17, 129, 27)])
 def test_screened_ladder_matches_oracle_and_exact_path(rmu, n, nq, k):
     """n >= 262144 rows: the corpus is scanned as a ladder of row ranges whose merged K'-th best seeds the next launch's
     thresholds (ragged last tiles, partial query tiles, 1- and 2-group wave geometries)."""
