@@ -222,12 +222,30 @@ __device__ __forceinline__ void ln_row(float (&v)[8], bool act, const float* __r
 
 // embeddings + LayerNorm: one wave per (sequence, position); packed output row cu[b] + pos.  (Four slots per wave, as in
 // k_layernorm below, measured slower here: half the slots are padding and exit at once.)
+// CU_HERE (round 5, the interactive path: batch <= 256): `cu` is an OUTPUT -- every workgroup rebuilds the sequence offsets from `lens` in
+// LDS (a few adds) and workgroup 0 writes them for the launches behind it; the k_cu_seqlens launch (one of ~34 dependent ~4.4-us launches
+// of a query forward) is gone.
+template <bool CU_HERE>
 __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, const int* __restrict__ type_ids,
                                                   const int* __restrict__ cu, int batch, int max_len,
                                                   const float* __restrict__ wemb, const float* __restrict__ pemb,
                                                   const float* __restrict__ temb, const float* __restrict__ g,
                                                   const float* __restrict__ bta, float eps, int vocab, int type_vocab,
-                                                  bf16* __restrict__ out) {
+                                                  bf16* __restrict__ out, const int* __restrict__ lens = nullptr, int* __restrict__ cu_out = nullptr) {
+    __shared__ int s_len[CU_HERE ? 256 : 1], s_cu[CU_HERE ? 257 : 1];
+    if constexpr (CU_HERE) {
+        const int tid = threadIdx.x;
+        if (tid < batch) s_len[tid] = min(max(lens[tid], 0), max_len);
+        __syncthreads();
+        for (int j = tid; j <= batch; j += 256) {      // (batch <= 256: entry `batch` is the second turn of thread 0)
+            int run = 0;
+            for (int i = 0; i < j; ++i) run += s_len[i];
+            s_cu[j] = run;
+            if (blockIdx.x == 0) cu_out[j] = run;
+        }
+        __syncthreads();
+        cu = s_cu;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= (int64_t)batch * max_len) return;
@@ -497,6 +515,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
 // four partial sums meet in LDS and all 256 threads run the epilogue (bias | + GELU | + residual).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int SMALL_M = 256;                           // tokens (upper bound batch * max_len) below which launch_gemm's callers take k_gemm_small
+constexpr int QKV_ATTN_TOKENS = 512;                   // ... and up to which QKV projection + attention are one launch (k_qkv_attn_small)
 constexpr int FOLD_TOKENS = 2560;                      // ... and up to which a whole forward runs on it with the LayerNorms folded (enqueue_forward)
 // Round 4: the token dimension is a grid dimension too -- workgroup (x, y) takes features [32 x, +32) of tokens [SMALL_TB y, +SMALL_TB)
 // -- so the same kernel serves a few THOUSAND tokens (the reference's rerank call: <= 14 (query, passage) pairs, ~1.5k tokens,
@@ -2873,6 +2892,241 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_qkv_attn_small -- the interactive path's QKV projection AND attention in ONE launch (round 5).  One query per call is a chain of
+// ~34 dependent launches of ~4.4 us each; the QKV GEMM (k_gemm_small) and the attention (k_attn3) of a layer are two of the five.
+// Workgroup = (head, sequence), 4 waves:
+//   phase 1: Q_h | K_h | V_h = LN?(x) . W[part * 384 + 32 head .. +32]^T + b for the sequence's tokens, exactly as k_gemm_small computes
+//            them -- wave w holds the K quarter [96 w, +96) of the 3 x 32 weight rows as MFMA A fragments (18), token fragments come
+//            straight from global memory (the next tile's requested before this tile's MFMAs), LNA normalises them on the way in with the
+//            same two-pass statistics (the workgroup of head 0 leaves (mean, rstd) for the out-proj's residual fold), the four partial
+//            sums meet in LDS and are added in the same order, bias first, one bf16 rounding -- but the results go into the LDS images
+//            k_attn3 stages from global memory: K rows (swizzled 16-byte units), V^T (key-permuted), and Q rows in K's layout;
+//   phase 2: k_attn3's two-pass attention, unchanged arithmetic, Q fragments read from LDS.
+// Bit-identical to k_gemm_small + k_attn3 (same summation orders and rounding points).  Sequences up to 32 KT tokens.
+// ------------------------------------------------------------------------------------------------------------
+template <int KT>
+struct QkvAttnCfg {
+    static constexpr int LP = KT * 32, VSTR = LP * 2 + 16;
+    static constexpr int RED_OFF = 0, RED_BYTES = 4 * 32 * 100 * 4;          // [K quarter][token][96 features + 4 pad] fp32
+    static constexpr int LNP_OFF = RED_OFF + RED_BYTES, LNP_BYTES = 2 * 4 * 32 * 4;
+    static constexpr int QS_OFF = LNP_OFF + LNP_BYTES, KS_OFF = QS_OFF + LP * 64, VT_OFF = KS_OFF + LP * 64;
+    static constexpr int LDS_BYTES = VT_OFF + 32 * VSTR;
+};
+
+template <int KT, bool LNA>
+__global__ __launch_bounds__(256) void k_qkv_attn_small(const bf16* __restrict__ A, const bf16* __restrict__ W, const float* __restrict__ bias,
+                                                        const int* __restrict__ cu, int batch, const float* __restrict__ lng,
+                                                        const float* __restrict__ lnb, float eps, float2* __restrict__ stats_out,
+                                                        bf16* __restrict__ ctx) {
+    using C = QkvAttnCfg<KT>;
+    constexpr int NF = 6, VSTR = C::VSTR;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const int head = blockIdx.x % NH, b = blockIdx.x / NH;
+    if (b >= batch) return;
+    const int t0g = cu[b], L = cu[b + 1] - t0g;
+    if (L <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int nkt = (L + 31) >> 5;
+    float (*red)[32][100] = (float (*)[32][100])(gsm + C::RED_OFF);
+    float (*lnp)[4][32] = (float (*)[4][32])(gsm + C::LNP_OFF);
+    char* qs = gsm + C::QS_OFF;
+    char* ks = gsm + C::KS_OFF;
+    char* vt = gsm + C::VT_OFF;
+
+    // ---- phase 1 ------------------------------------------------------------------------------------------------------------
+    bf16x8 wf[3][NF];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const bf16* wr = W + (int64_t)(part * H + head * DH + r31) * H + w * 96 + hh * 8;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) wf[part][f] = *(const bf16x8*)(wr + f * 16);
+    }
+    float lg[LNA ? NF : 1][8], lb[LNA ? NF : 1][8];
+    if constexpr (LNA) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int k0 = w * 96 + f * 16 + hh * 8;
+            const f32x4 g0 = *(const f32x4*)(lng + k0), g1 = *(const f32x4*)(lng + k0 + 4);
+            const f32x4 b0 = *(const f32x4*)(lnb + k0), b1 = *(const f32x4*)(lnb + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lg[f][e] = g0[e]; lg[f][4 + e] = g1[e]; lb[f][e] = b0[e]; lb[f][4 + e] = b1[e]; }
+        }
+    }
+    const int et = tid >> 3, ef = (tid & 7) * 4;           // epilogue: token et of the tile, features ef .. ef + 3 of each part
+    f32x4 bv[3];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) bv[part] = *(const f32x4*)(bias + part * H + head * DH + ef);
+    auto load_x = [&](int t0, bf16x8 (&x)[NF]) {
+        const int tok = t0g + min(t0 + r31, L - 1);
+        const bf16* xr = A + (int64_t)tok * H + w * 96 + hh * 8;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) x[f] = *(const bf16x8*)(xr + f * 16);
+    };
+    bf16x8 xn[NF];
+    load_x(0, xn);
+    for (int t0 = 0; t0 < nkt * 32; t0 += 32) {
+        bf16x8 xf[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) xf[f] = xn[f];
+        if (t0 + 32 < L) load_x(t0 + 32, xn);
+        if constexpr (LNA) {
+            float v[NF][8], sm = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[f][e] = bf2f(xf[f][e]); sm += v[f][e]; }
+            sm += __shfl_xor(sm, 32);
+            if (hh == 0) lnp[0][w][r31] = sm;
+            __syncthreads();
+            const float mu = ((lnp[0][0][r31] + lnp[0][1][r31]) + (lnp[0][2][r31] + lnp[0][3][r31])) * (1.0f / H);
+            float qv = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[f][e] - mu; qv = fmaf(d, d, qv); }
+            qv += __shfl_xor(qv, 32);
+            if (hh == 0) lnp[1][w][r31] = qv;
+            __syncthreads();
+            const float rs = rsqrtf(((lnp[1][0][r31] + lnp[1][1][r31]) + (lnp[1][2][r31] + lnp[1][3][r31])) * (1.0f / H) + eps);
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xf[f][e] = (bf16)((v[f][e] - mu) * rs * lg[f][e] + lb[f][e]);
+            if (stats_out && head == 0 && w == 0 && hh == 0 && t0 + r31 < L) stats_out[t0g + t0 + r31] = float2{mu, rs};
+        }
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[part][f], xf[f], acc, 0, 0, 0);
+            // acc[4 q + e] = feature 8 q + 4 hh + e (of this part's 32) of token r31, summed over this wave's K quarter
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(f32x4*)&red[w][r31][part * 32 + q * 8 + hh * 4] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        }
+        __syncthreads();
+        {
+            const int r = t0 + et;                         // row (token of the sequence) this thread finishes
+            const bool live = r < L;
+            bf16x4 o[3];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                f32x4 v = bv[part];
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) v += *(const f32x4*)&red[ww][et][part * 32 + ef];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[part][e] = live ? (bf16)v[e] : (bf16)0.0f;     // rows [L, 32 nkt) are zero (as k_attn3 stages them)
+            }
+            const int u = ef >> 3, sw = (r >> 2) & 3;
+            *(bf16x4*)(qs + r * 64 + ((u ^ sw) * 16) + (ef & 7) * 2) = o[0];
+            *(bf16x4*)(ks + r * 64 + ((u ^ sw) * 16) + (ef & 7) * 2) = o[1];
+            // key r -> slot inside its 16-block: keys 0-3 -> 0-3, 4-7 -> 8-11, 8-11 -> 4-7, 12-15 -> 12-15 (k_attn3)
+            const int r16 = r & 15, slot = (r & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *(bf16*)(vt + (ef + e) * VSTR + slot * 2) = o[2][e];
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: k_attn3's attention over the LDS images ---------------------------------------------------------------------
+    const int c31 = r31;
+    f32x16 maskc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) maskc[r] = ((nkt - 1) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3) < L) ? 0.f : -INFINITY;
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    const u32 ksw = (u32)((c31 >> 2) & 3);
+    const u32 kaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ks + (u32)(c31 * 64);
+    const u32 qaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)qs + (u32)(c31 * 64);
+    auto kfrag = [&](int kt, int s2) -> bf16x8 {
+        return *(const bf16x8*)((const __attribute__((address_space(3))) char*)(uintptr_t)(kaddr + (u32)(kt * 2048) + (((u32)(2 * s2 + hh) ^ ksw) * 16)));
+    };
+    auto qfrag = [&](int qt, int s2) -> bf16x8 {
+        return *(const bf16x8*)((const __attribute__((address_space(3))) char*)(uintptr_t)(qaddr + (u32)(qt * 2048) + (((u32)(2 * s2 + hh) ^ ksw) * 16)));
+    };
+    for (int qt = w; qt < nkt; qt += 4) {
+        const bf16x8 qf0 = qfrag(qt, 0), qf1 = qfrag(qt, 1);
+        float mx = -INFINITY;
+        auto pass1 = [&](int kt, const f32x16& c0) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 0), qf0, c0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 1), qf1, acc, 0, 0, 0);
+            float m3 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r + 1 < 16; r += 2) m3 = fmaxf(fmaxf(m3, acc[r]), acc[r + 1]);
+            mx = fmaxf(mx, fmaxf(m3, acc[15]));
+        };
+#pragma unroll 1
+        for (int kt = 0; kt < nkt - 1; ++kt) pass1(kt, zero16);
+        pass1(nkt - 1, maskc);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        f32x16 negm, negmm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { negm[r] = -mx; negmm[r] = maskc[r] - mx; }
+        f32x16 ot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+        float sum = 0.f;
+        const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+        auto pass2 = [&](int kt, const f32x16& c0) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 0), qf0, c0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kt, 1), qf1, acc, 0, 0, 0);
+            u32x4 pu[2];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                bf16x2 pb;
+                pb[0] = (bf16)__builtin_amdgcn_exp2f(acc[r]);
+                pb[1] = (bf16)__builtin_amdgcn_exp2f(acc[r + 1]);
+                sum = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, sum, false);
+                pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 vf = *(const bf16x8*)(vt + c31 * VSTR + (kt * 32 + s2 * 16 + hh * 8) * 2);
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pu[s2]), ot, 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int kt = 0; kt < nkt - 1; ++kt) pass2(kt, negm);
+        pass2(nkt - 1, negmm);
+        sum += __shfl_xor(sum, 32);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        {
+            union { bf16x4 v; int i[2]; } pc[4], rcv[2];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pc[g4].v[e] = (bf16)(ot[4 * g4 + e] * inv);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int snd0 = hh ? pc[j].i[0] : pc[2 + j].i[0], snd1 = hh ? pc[j].i[1] : pc[2 + j].i[1];
+                rcv[j].i[0] = __shfl_xor(snd0, 32);
+                rcv[j].i[1] = __shfl_xor(snd1, 32);
+            }
+            const int q = qt * 32 + c31;
+            if (q < L) {
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = hh ? rcv[0].v[e] : pc[0].v[e];
+                    o0[4 + e] = hh ? pc[2].v[e] : rcv[0].v[e];
+                    o1[e] = hh ? rcv[1].v[e] : pc[1].v[e];
+                    o1[4 + e] = hh ? pc[3].v[e] : rcv[1].v[e];
+                }
+                bf16* dst = ctx + (int64_t)(t0g + q) * H + head * DH + hh * 16;
+                *(bf16x8*)dst = o0;
+                *(bf16x8*)(dst + 8) = o1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_attn4 -- k_attn3 made PERSISTENT (round 4).  k_attn3 starts one workgroup per (sequence, head): 98k of them for 8192 chunks, each
 // paying a cold global round trip for its K / V / Q pieces before the first MFMA -- by the round-3 ablation 0.45 of its 0.82 ms per
 // layer is that start-up, not arithmetic.  Here a workgroup walks a list of (sequence, head) items (item it -> XCD it & 7, as the
@@ -3127,6 +3381,81 @@ __global__ __launch_bounds__(64) void k_pool(const bf16* __restrict__ h, const i
     if (act) {
         float* dst = out + (int64_t)b * out_stride + c0;
         if ((((uintptr_t)out | (uintptr_t)(out_stride * 4)) & 15) == 0) {   // any caller stride is legal: wide stores when aligned
+            *(f32x4*)dst = f32x4{s[0] * rn, s[1] * rn, s[2] * rn, s[3] * rn};
+            *(f32x4*)(dst + 4) = f32x4{s[4] * rn, s[5] * rn, s[6] * rn, s[7] * rn};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = s[i] * rn;
+        }
+    }
+}
+
+// The same with the LAST LayerNorm inside (round 5, the interactive path: sequences of <= 64 tokens): y is the last layer's pre-LN sum,
+// each token row is normalised (k_layernorm's two-pass statistics, four rows in flight, rounded to bf16 as k_layernorm stores it) and
+// added to the pooled sum in token order -- what k_layernorm + k_pool compute, bit for bit, in one launch instead of two.
+__global__ __launch_bounds__(64) void k_pool_ln(const bf16* __restrict__ y, const int* __restrict__ cu, const float* __restrict__ g,
+                                                const float* __restrict__ bta, float eps, float* __restrict__ out, int64_t out_stride,
+                                                int pool_cls, int normalize) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int t0 = cu[b], Lr = cu[b + 1] - t0;
+    const int L = pool_cls ? min(Lr, 1) : Lr;
+    const bool act = lane < 48;
+    const int c0 = lane * 8;
+    f32x4 g0 = {}, g1 = {}, b0 = {}, b1 = {};
+    if (act) { g0 = *(const f32x4*)(g + c0); g1 = *(const f32x4*)(g + c0 + 4); b0 = *(const f32x4*)(bta + c0); b1 = *(const f32x4*)(bta + c0 + 4); }
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16* r = y + (int64_t)t0 * H + c0;
+    for (int t = 0; t < L; t += 4) {
+        bf16x8 rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rv[u] = bf16x8{};
+            if (act && t + u < L) rv[u] = *(const bf16x8*)(r + (int64_t)(t + u) * H);
+        }
+        float v[4][8], m[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[u][i] = bf2f(rv[u][i]); m[u] += v[u][i]; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[u] += __shfl_xor(m[u], o);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m[u] *= (1.0f / H);
+            q[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = act ? v[u][i] - m[u] : 0.f; q[u] = fmaf(d, d, q[u]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] += __shfl_xor(q[u], o);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t + u < L) {
+                const float rs = rsqrtf(q[u] * (1.0f / H) + eps);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[i] += bf2f((bf16)((v[u][i] - m[u]) * rs * g0[i] + b0[i]));
+                    s[4 + i] += bf2f((bf16)((v[u][4 + i] - m[u]) * rs * g1[i] + b1[i]));
+                }
+            }
+        }
+    }
+    const float inv = pool_cls ? 1.0f : 1.0f / fmaxf((float)L, 1e-9f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = act ? s[i] * inv : 0.f; q = fmaf(s[i], s[i], q); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rn = normalize ? 1.0f / fmaxf(sqrtf(q), 1e-12f) : 1.0f;
+    if (act) {
+        float* dst = out + (int64_t)b * out_stride + c0;
+        if ((((uintptr_t)out | (uintptr_t)(out_stride * 4)) & 15) == 0) {
             *(f32x4*)dst = f32x4{s[0] * rn, s[1] * rn, s[2] * rn, s[3] * rn};
             *(f32x4*)(dst + 4) = f32x4{s[4] * rn, s[5] * rn, s[6] * rn, s[7] * rn};
         } else {
@@ -3629,6 +3958,15 @@ static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, b
     hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx, ctx_tiled ? 1 : 0, (long)hm_stride);
 }
 
+template <int KT, bool LNA>
+static void launch_qkv_attn_small(hipStream_t s, int batch, const bf16* A, const bf16* W, const float* bias, const int* cu, const float* lng,
+                                  const float* lnb, float eps, float2* stats_out, bf16* ctx) {
+    using C = QkvAttnCfg<KT>;
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_qkv_attn_small<KT, LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)attr_rc;
+    hipLaunchKernelGGL((k_qkv_attn_small<KT, LNA>), dim3((unsigned)(batch * NH)), dim3(256), C::LDS_BYTES, s, A, W, bias, cu, batch, lng, lnb, eps, stats_out, ctx);
+}
+
 #ifdef RMU_DEBUG_KERNELS
 template <int KT, int OCC>
 static void launch_attn4(int batch, const bf16* qkv, const int* cu, bf16* ctx, bool ctx_tiled, int64_t hm_stride, hipStream_t s) {
@@ -3670,10 +4008,21 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     const float eps = m->cfg.ln_eps;
 
     // (thread 0 folds one partial per thread serially: a block no wider than the batch needs -- 1024 threads cost 12 us for 14 sequences)
-    hipLaunchKernelGGL(k_cu_seqlens, dim3(1), dim3(batch <= 64 ? 64 : batch <= 256 ? 256 : 1024), 0, s, (const int*)lens, batch, max_len, m->cu);
-    hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, (const int*)ids, (const int*)type_ids,
-                       (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
-                       m->cfg.type_vocab, m->h);
+    // (round 5) the interactive sizes: the sequence offsets are built inside k_embed_ln and the last LayerNorm inside the pooling launch
+    // (RMU_SMALL_FUSE=0: the separate launches)
+    static const bool small_fuse = !(rmu_env("RMU_SMALL_FUSE") && atoi(rmu_env("RMU_SMALL_FUSE")) == 0);
+    const bool cu_here = small_fuse && batch <= 256 && cap <= FOLD_TOKENS;
+    if (cu_here) {
+        hipLaunchKernelGGL(k_embed_ln<true>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, (const int*)ids, (const int*)type_ids,
+                           (const int*)nullptr, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
+                           m->cfg.type_vocab, m->h, (const int*)lens, m->cu);
+    } else {
+        hipLaunchKernelGGL(k_cu_seqlens, dim3(1), dim3(batch <= 64 ? 64 : batch <= 256 ? 256 : 1024), 0, s, (const int*)lens, batch, max_len, m->cu);
+        hipLaunchKernelGGL(k_embed_ln<false>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, (const int*)ids, (const int*)type_ids,
+                           (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
+                           m->cfg.type_vocab, m->h);
+    }
+    bool pooled_ln = false;                        // the pooling launch carries the last LayerNorm (small path, short sequences)
     const dim3 ln_grid((unsigned)((cap + 4 * LN_ROWS - 1) / (4 * LN_ROWS)));
     const dim3 at_grid(NH, (unsigned)batch);   // k_attention: one workgroup per (head, sequence); k_attn3: one per sequence
     size_t li = 0;
@@ -3721,17 +4070,34 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
                 continue;
             }
 #endif
+            // (round 5) up to QKV_ATTN_TOKENS tokens -- one query, a few short sequences -- the QKV projection and the attention are ONE launch
+            // (k_qkv_attn_small: a workgroup per (head, sequence); bit-identical to the pair below); RMU_QKV_ATTN_TOKENS=0 keeps them apart
+            static const int64_t qa_tokens = rmu_env("RMU_QKV_ATTN_TOKENS") ? atoll(rmu_env("RMU_QKV_ATTN_TOKENS")) : QKV_ATTN_TOKENS;
+            if (cap <= qa_tokens) {
+                if (max_len <= 128) {
+                    if (!prev) launch_qkv_attn_small<4, false>(s, batch, m->h, L.wqkv, L.bqkv, cu, nullptr, nullptr, eps, nullptr, m->ctx);
+                    else launch_qkv_attn_small<4, true>(s, batch, y2, L.wqkv, L.bqkv, cu, prev->ln2g, prev->ln2b, eps, m->st2, m->ctx);
+                } else {
+                    if (!prev) launch_qkv_attn_small<8, false>(s, batch, m->h, L.wqkv, L.bqkv, cu, nullptr, nullptr, eps, nullptr, m->ctx);
+                    else launch_qkv_attn_small<8, true>(s, batch, y2, L.wqkv, L.bqkv, cu, prev->ln2g, prev->ln2b, eps, m->st2, m->ctx);
+                }
+            } else {
             if (!prev) launch_small<EPI_BIAS, H>(s, cap, tq, m->h, L.wqkv, L.bqkv, nullptr, m->qkv, cu, batch, 3 * H);
             else launch_small<EPI_BIAS, H, true>(s, cap, tq, y2, L.wqkv, L.bqkv, nullptr, m->qkv, cu, batch, 3 * H, prev->ln2g, prev->ln2b, eps, m->st2);
             if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
             else launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, false, 0, s);
+            }
             if (!prev) launch_small<EPI_RESID, H>(s, cap, th, m->ctx, L.wo, L.bo, m->h, y1, cu, batch, H);
             else launch_small<EPI_RESID, H, false, true>(s, cap, th, m->ctx, L.wo, L.bo, y2, y1, cu, batch, H, nullptr, nullptr, eps, nullptr, prev->ln2g, prev->ln2b, m->st2);
             launch_small<EPI_GELU, H, true>(s, cap, tf, y1, L.w1, L.b1, nullptr, m->mid, cu, batch, FF, L.ln1g, L.ln1b, eps, m->st1);
             launch_small<EPI_RESID, FF, false, true>(s, cap, th, m->mid, L.w2, L.b2, y1, y2, cu, batch, H, nullptr, nullptr, eps, nullptr, L.ln1g, L.ln1b, m->st1);
             prev = &L;
         }
-        if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);
+        if (prev && small_fuse && max_len <= 64 && (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)) {
+            hipLaunchKernelGGL(k_pool_ln, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)y2, (const int*)m->cu, prev->ln2g, prev->ln2b, eps, out_dev,
+                               out_stride, kind == RMU_BERT_POOL_CLS ? 1 : 0, normalize ? 1 : 0);
+            pooled_ln = true;
+        } else if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);
     } else
     for (const BertLayer& L : m->layers) {
         ++li;
@@ -3842,7 +4208,8 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
         hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
     }
-    if (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)
+    if (pooled_ln) {
+    } else if (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)
         hipLaunchKernelGGL(k_pool, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)m->h, (const int*)m->cu, out_dev, out_stride,
                            kind == RMU_BERT_POOL_CLS ? 1 : 0, normalize ? 1 : 0);
     else if (kind == RMU_BERT_TOKENS)

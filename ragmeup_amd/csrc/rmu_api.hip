@@ -92,6 +92,17 @@ struct Tls {
         return RMU_OK;
     }
     int* hflag = nullptr;          // pinned landing word of the screening path's re-run count
+    char* hpin = nullptr;          // pinned landing buffer of search_mmr_on's results (rows | scores in ONE device-to-host copy)
+    size_t hpin_cap = 0;
+    int ensure_hpin(size_t bytes) {
+        if (bytes <= hpin_cap) return RMU_OK;
+        if (hpin) (void)hipHostFree(hpin);
+        hpin = nullptr; hpin_cap = 0;
+        const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
+        if (hipHostMalloc((void**)&hpin, cap) != hipSuccess) return RMU_E_OOM;
+        hpin_cap = cap;
+        return RMU_OK;
+    }
     bool timing = false;
     float scan_ms = -1.f, search_ms = -1.f;
     int grid = 0, block = 0, lds = 0, passes = 0, screened = 0;
@@ -734,26 +745,36 @@ static int search_mmr_on(rmu_index_t* idx, const float* q, bool q_dev, int64_t n
     if (t.mm_s.ensure(nf * sizeof(float)) || t.mm_r.ensure(nf * sizeof(int64_t)) || t.mm_q.ensure((size_t)nq * idx->dim * sizeof(float)) ||
         t.mm_p.ensure(nk * (sizeof(int) + sizeof(int64_t) + sizeof(float))))
         return fail(RMU_E_OOM, std::string(who) + ": workspace");
-    // the search on the given stream, results left on the device (no synchronisation inside)
-    int rc = rmu_index_search(idx, q, nq, fetch_k, RMU_F_OUT_DEVICE | (q_dev ? RMU_F_Q_DEVICE : 0u), 0, (float*)t.mm_s.p, (int64_t*)t.mm_r.p,
-                              (uint64_t)(uintptr_t)s);
-    if (rc) return rc;
-    std::shared_lock<std::shared_mutex> lk(idx->mu);
-    const float* dq = q;
-    if (!q_dev) {
-        HIP_TRY(hipMemcpyAsync(t.mm_q.p, q, (size_t)nq * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
-        dq = (const float*)t.mm_q.p;
-    }
     int64_t* d_rows = (int64_t*)t.mm_p.p;
     float* d_sc = (float*)(d_rows + nk);
     int* d_pos = (int*)(d_sc + nk);
-    if (lambda_mult >= 0.0) launch_mmr(idx, dq, (const int64_t*)t.mm_r.p, nq, fetch_k, k, lambda_mult, d_pos, s);
-    hipLaunchKernelGGL(k_take_picks, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, lambda_mult >= 0.0 ? (const int*)d_pos : (const int*)nullptr,
-                       (const int64_t*)t.mm_r.p, (const float*)t.mm_s.p, nq, fetch_k, k, row_base, d_rows, d_sc);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_rows, d_rows, nk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    if (out_scores) HIP_TRY(hipMemcpyAsync(out_scores, d_sc, nk * sizeof(float), hipMemcpyDeviceToHost, s));
+    // (round 5: every stream operation of the one-query path is ~4.4 us of dependent-kernel boundary.)  No selection and fetch_k == k: the
+    // search writes the result rows (row_base applied) and scores where the copy below reads them -- no k_take_picks launch.
+    const bool direct = lambda_mult < 0.0 && fetch_k == k;
+    if (t.ensure_hpin(nk * (sizeof(int64_t) + sizeof(float)))) return fail(RMU_E_OOM, std::string(who) + ": pinned result buffer");
+    // the search on the given stream, results left on the device (no synchronisation inside)
+    int rc = direct ? rmu_index_search(idx, q, nq, k, RMU_F_OUT_DEVICE | (q_dev ? RMU_F_Q_DEVICE : 0u), row_base, d_sc, d_rows, (uint64_t)(uintptr_t)s)
+                    : rmu_index_search(idx, q, nq, fetch_k, RMU_F_OUT_DEVICE | (q_dev ? RMU_F_Q_DEVICE : 0u), 0, (float*)t.mm_s.p, (int64_t*)t.mm_r.p,
+                                       (uint64_t)(uintptr_t)s);
+    if (rc) return rc;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    if (!direct) {
+        const float* dq = q;
+        if (!q_dev && lambda_mult >= 0.0) {
+            HIP_TRY(hipMemcpyAsync(t.mm_q.p, q, (size_t)nq * idx->dim * sizeof(float), hipMemcpyHostToDevice, s));
+            dq = (const float*)t.mm_q.p;
+        }
+        if (lambda_mult >= 0.0) launch_mmr(idx, dq, (const int64_t*)t.mm_r.p, nq, fetch_k, k, lambda_mult, d_pos, s);
+        hipLaunchKernelGGL(k_take_picks, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, lambda_mult >= 0.0 ? (const int*)d_pos : (const int*)nullptr,
+                           (const int64_t*)t.mm_r.p, (const float*)t.mm_s.p, nq, fetch_k, k, row_base, d_rows, d_sc);
+        HIP_TRY(hipGetLastError());
+    }
+    // rows | scores are contiguous on the device: ONE copy into pinned memory (a copy into the caller's pageable arrays is staged by the
+    // runtime, one staging round per call), split on the host behind the synchronisation
+    HIP_TRY(hipMemcpyAsync(t.hpin, d_rows, nk * (sizeof(int64_t) + sizeof(float)), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    memcpy(out_rows, t.hpin, nk * sizeof(int64_t));
+    if (out_scores) memcpy(out_scores, t.hpin + nk * sizeof(int64_t), nk * sizeof(float));
     t.finished(s, true);
     return RMU_OK;
 }

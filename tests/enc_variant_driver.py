@@ -25,7 +25,18 @@ cu = np.concatenate([[0], np.cumsum(lens)])
 rel = token_rel_error(np.concatenate([tok[cu[b]:cu[b + 1]] for b in sel]), hid, lens[sel])
 g = got[sel]
 cos = (g * ref).sum(1) / np.linalg.norm(g, axis=1) / np.linalg.norm(ref, axis=1)
-print("RESULT " + json.dumps({"min_cos": float(cos.min()), "finite": bool(np.isfinite(got).all()),
+# the interactive sizes (k_gemm_small with the LayerNorm folds; round 5: k_qkv_attn_small, offsets inside k_embed_ln, k_pool_ln): one short
+# query, a few sequences, a long one -- every token's final hidden state and the pooled vectors against the oracle
+small_rel, small_cos = 0.0, 1.0
+for n, lmax, mean in ((1, 16, 12), (3, 40, 24), (2, 200, 150), (5, 64, 40)):
+    sids, _, slens = synth_tokens(n, seed=40 + n, lmin=2, lmax=lmax, mean=mean, std=max(2, mean // 3))
+    shid = O.bert_hidden(w, sids, np.zeros_like(sids), slens)
+    stok = enc.encode_ids(sids, slens, None, mode=3).cpu().numpy()
+    small_rel = max(small_rel, float(token_rel_error(stok, shid, slens).max()))
+    sp, sr = enc.encode_ids(sids, slens, None, mode=0).cpu().numpy(), O.embed_pool(shid, slens)
+    small_cos = min(small_cos, float(((sp * sr).sum(1) / np.linalg.norm(sp, axis=1) / np.linalg.norm(sr, axis=1)).min()))
+    assert np.array_equal(enc.encode_host(sids, slens, None, 0), sp)          # the graph-replayed host entry point takes the same kernels
+print("RESULT " + json.dumps({"small_max_tok_rel": small_rel, "small_min_cos": small_cos, "min_cos": float(cos.min()), "finite": bool(np.isfinite(got).all()),
                               "max_tok_rel": float(rel.max()), "mean_tok_rel": float(rel.mean()),
                               "min_centred_cos": float(centred_cosine(g, ref).min()),
                               "norm_err": float(np.abs(np.linalg.norm(got, axis=1) - 1).max())}))

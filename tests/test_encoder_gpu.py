@@ -327,9 +327,11 @@ def test_cross_encoder_100_pairs_tolerance_1e2(cross):
 
 @pytest.mark.parametrize("env", [{"RMU_GEMM3": "0"}, {"RMU_GEMM3": "7"}, {"RMU_GEMM3": "2", "RMU_FUSED_FFN": "0"},
                                  {"RMU_FFN_LNIN": "0"}, {"RMU_FFN_V": "2"}, {"RMU_FFN_V": "2", "RMU_FFN_LNIN": "0"},
-                                 {"RMU_FFN_V": "2", "RMU_FFN_GELU": "1"}, {"RMU_CTX_TILED": "0"}, {"RMU_H_TILED": "0"}, {"RMU_QKV_HM": "0"}],
+                                 {"RMU_FFN_V": "2", "RMU_FFN_GELU": "1"}, {"RMU_CTX_TILED": "0"}, {"RMU_H_TILED": "0"}, {"RMU_QKV_HM": "0"},
+                                 {"RMU_QKV_ATTN_TOKENS": "0", "RMU_SMALL_FUSE": "0"}],
                          ids=["k_gemm_only", "k_gemm3_everywhere", "unfused_ffn", "ffn3_separate_layernorm", "ffn2_one_wave_per_simd",
-                              "ffn2_separate_layernorm", "ffn2_scalar_gelu", "row_major_ctx", "row_major_h_between_layers", "row_major_qkv"])
+                              "ffn2_separate_layernorm", "ffn2_scalar_gelu", "row_major_ctx", "row_major_h_between_layers", "row_major_qkv",
+                              "interactive_path_unfused"])
 def test_every_switchable_kernel_variant_keeps_parity(env):
     """Every kernel the PRODUCT library can be switched to is held to the same bar as the default path (the default itself --
     k_ffn3, k_attn3, k_gemm3 for QKV, tiled activations -- is what every other test of this file runs).  The round-1/2 kernels
@@ -345,6 +347,7 @@ def test_every_switchable_kernel_variant_keeps_parity(env):
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["finite"] and res["min_cos"] >= 0.999 and res["norm_err"] < 1e-5, res
     assert res["max_tok_rel"] <= 2e-2 and res["min_centred_cos"] >= 0.99, res
+    assert res["small_max_tok_rel"] <= 2e-2 and res["small_min_cos"] >= 0.999, res
 
 
 def test_host_entry_point_replays_a_graph_and_matches_the_device_path(bi, cross):
