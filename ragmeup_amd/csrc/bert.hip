@@ -515,7 +515,11 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
 // four partial sums meet in LDS and all 256 threads run the epilogue (bias | + GELU | + residual).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int SMALL_M = 256;                           // tokens (upper bound batch * max_len) below which launch_gemm's callers take k_gemm_small
-constexpr int QKV_ATTN_TOKENS = 512;                   // ... and up to which QKV projection + attention are one launch (k_qkv_attn_small)
+// ... and up to which QKV projection + attention are one launch (k_qkv_attn_small).  tools/small_ab.sh, one box, every output bit-identical:
+// a 16-token query forward 0.182 ms fused / 0.183 apart (no gain: inside a replayed graph a kernel boundary is not the 4.4 us it costs under
+// the profiler, a kernel's own load -> MFMA -> store chain is), the 14-pair rerank forward (1.5k tokens) 0.417 fused / 0.437 apart: the
+// whole folded path takes it.
+constexpr int QKV_ATTN_TOKENS = 2560;
 constexpr int FOLD_TOKENS = 2560;                      // ... and up to which a whole forward runs on it with the LayerNorms folded (enqueue_forward)
 // Round 4: the token dimension is a grid dimension too -- workgroup (x, y) takes features [32 x, +32) of tokens [SMALL_TB y, +SMALL_TB)
 // -- so the same kernel serves a few THOUSAND tokens (the reference's rerank call: <= 14 (query, passage) pairs, ~1.5k tokens,
@@ -3390,81 +3394,6 @@ __global__ __launch_bounds__(64) void k_pool(const bf16* __restrict__ h, const i
     }
 }
 
-// The same with the LAST LayerNorm inside (round 5, the interactive path: sequences of <= 64 tokens): y is the last layer's pre-LN sum,
-// each token row is normalised (k_layernorm's two-pass statistics, four rows in flight, rounded to bf16 as k_layernorm stores it) and
-// added to the pooled sum in token order -- what k_layernorm + k_pool compute, bit for bit, in one launch instead of two.
-__global__ __launch_bounds__(64) void k_pool_ln(const bf16* __restrict__ y, const int* __restrict__ cu, const float* __restrict__ g,
-                                                const float* __restrict__ bta, float eps, float* __restrict__ out, int64_t out_stride,
-                                                int pool_cls, int normalize) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int t0 = cu[b], Lr = cu[b + 1] - t0;
-    const int L = pool_cls ? min(Lr, 1) : Lr;
-    const bool act = lane < 48;
-    const int c0 = lane * 8;
-    f32x4 g0 = {}, g1 = {}, b0 = {}, b1 = {};
-    if (act) { g0 = *(const f32x4*)(g + c0); g1 = *(const f32x4*)(g + c0 + 4); b0 = *(const f32x4*)(bta + c0); b1 = *(const f32x4*)(bta + c0 + 4); }
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bf16* r = y + (int64_t)t0 * H + c0;
-    for (int t = 0; t < L; t += 4) {
-        bf16x8 rv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            rv[u] = bf16x8{};
-            if (act && t + u < L) rv[u] = *(const bf16x8*)(r + (int64_t)(t + u) * H);
-        }
-        float v[4][8], m[4], q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            m[u] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { v[u][i] = bf2f(rv[u][i]); m[u] += v[u][i]; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) m[u] += __shfl_xor(m[u], o);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            m[u] *= (1.0f / H);
-            q[u] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const float d = act ? v[u][i] - m[u] : 0.f; q[u] = fmaf(d, d, q[u]); }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] += __shfl_xor(q[u], o);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (t + u < L) {
-                const float rs = rsqrtf(q[u] * (1.0f / H) + eps);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    s[i] += bf2f((bf16)((v[u][i] - m[u]) * rs * g0[i] + b0[i]));
-                    s[4 + i] += bf2f((bf16)((v[u][4 + i] - m[u]) * rs * g1[i] + b1[i]));
-                }
-            }
-        }
-    }
-    const float inv = pool_cls ? 1.0f : 1.0f / fmaxf((float)L, 1e-9f);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s[i] = act ? s[i] * inv : 0.f; q = fmaf(s[i], s[i], q); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rn = normalize ? 1.0f / fmaxf(sqrtf(q), 1e-12f) : 1.0f;
-    if (act) {
-        float* dst = out + (int64_t)b * out_stride + c0;
-        if ((((uintptr_t)out | (uintptr_t)(out_stride * 4)) & 15) == 0) {
-            *(f32x4*)dst = f32x4{s[0] * rn, s[1] * rn, s[2] * rn, s[3] * rn};
-            *(f32x4*)(dst + 4) = f32x4{s[4] * rn, s[5] * rn, s[6] * rn, s[7] * rn};
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dst[i] = s[i] * rn;
-        }
-    }
-}
-
 // final hidden states of every real token as fp32 rows (sentence-transformers' output_value = "token_embeddings"; the
 // parity tests compare them with the fp64 oracle token by token): packed row cu[b] + pos -> out[(cu[b] + pos) * stride ..]
 __global__ __launch_bounds__(256) void k_tokens_out(const bf16* __restrict__ h, const int* __restrict__ cu, int batch,
@@ -4008,8 +3937,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
     const float eps = m->cfg.ln_eps;
 
     // (thread 0 folds one partial per thread serially: a block no wider than the batch needs -- 1024 threads cost 12 us for 14 sequences)
-    // (round 5) the interactive sizes: the sequence offsets are built inside k_embed_ln and the last LayerNorm inside the pooling launch
-    // (RMU_SMALL_FUSE=0: the separate launches)
+    // (round 5) the interactive sizes: the sequence offsets are built inside k_embed_ln (RMU_SMALL_FUSE=0: the separate k_cu_seqlens launch)
     static const bool small_fuse = !(rmu_env("RMU_SMALL_FUSE") && atoi(rmu_env("RMU_SMALL_FUSE")) == 0);
     const bool cu_here = small_fuse && batch <= 256 && cap <= FOLD_TOKENS;
     if (cu_here) {
@@ -4022,7 +3950,6 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
                            (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
                            m->cfg.type_vocab, m->h);
     }
-    bool pooled_ln = false;                        // the pooling launch carries the last LayerNorm (small path, short sequences)
     const dim3 ln_grid((unsigned)((cap + 4 * LN_ROWS - 1) / (4 * LN_ROWS)));
     const dim3 at_grid(NH, (unsigned)batch);   // k_attention: one workgroup per (head, sequence); k_attn3: one per sequence
     size_t li = 0;
@@ -4070,7 +3997,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
                 continue;
             }
 #endif
-            // (round 5) up to QKV_ATTN_TOKENS tokens -- one query, a few short sequences -- the QKV projection and the attention are ONE launch
+            // (round 5) up to QKV_ATTN_TOKENS tokens the QKV projection and the attention are ONE launch
             // (k_qkv_attn_small: a workgroup per (head, sequence); bit-identical to the pair below); RMU_QKV_ATTN_TOKENS=0 keeps them apart
             static const int64_t qa_tokens = rmu_env("RMU_QKV_ATTN_TOKENS") ? atoll(rmu_env("RMU_QKV_ATTN_TOKENS")) : QKV_ATTN_TOKENS;
             if (cap <= qa_tokens) {
@@ -4093,11 +4020,9 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
             launch_small<EPI_RESID, FF, false, true>(s, cap, th, m->mid, L.w2, L.b2, y1, y2, cu, batch, H, nullptr, nullptr, eps, nullptr, L.ln1g, L.ln1b, m->st1);
             prev = &L;
         }
-        if (prev && small_fuse && max_len <= 64 && (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)) {
-            hipLaunchKernelGGL(k_pool_ln, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)y2, (const int*)m->cu, prev->ln2g, prev->ln2b, eps, out_dev,
-                               out_stride, kind == RMU_BERT_POOL_CLS ? 1 : 0, normalize ? 1 : 0);
-            pooled_ln = true;
-        } else if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);
+        // (measured and dropped, round 5: the last LayerNorm inside the pooling launch -- one wave per sequence normalising its rows four at a
+        // time -- made a 16-token query forward SLOWER, 0.182 vs 0.171-0.176 ms: k_layernorm spreads the rows over the chip, the fold serialises them)
+        if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);
     } else
     for (const BertLayer& L : m->layers) {
         ++li;
@@ -4208,8 +4133,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
         hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
     }
-    if (pooled_ln) {
-    } else if (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)
+    if (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)
         hipLaunchKernelGGL(k_pool, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)m->h, (const int*)m->cu, out_dev, out_stride,
                            kind == RMU_BERT_POOL_CLS ? 1 : 0, normalize ? 1 : 0);
     else if (kind == RMU_BERT_TOKENS)
