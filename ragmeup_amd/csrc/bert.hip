@@ -3487,7 +3487,15 @@ struct rmu_bert {
     uint64_t graph_clock = 0;                      // bumps per host call: the least recently used graph goes when the cache is full
     int32_t *h_in = nullptr, *d_in = nullptr;      // [ids | type ids | lens], pinned host / device
     float *h_out = nullptr, *d_out = nullptr;
+    // (round 5) Host-path calls from SEVERAL threads (LCEL runs the reference's retriever branches in parallel: server/RAGHelper_local.py:254-258;
+    // a bulk embed_documents beside an embed_query) used to queue on `mu` for the whole forward + synchronisation.  A call that finds this
+    // model busy takes a CLONE: the same weight pointers, its own workspace, stream, staging buffers and graph cache (created on first
+    // need, at most MAX_CLONES); the forwards of two threads then overlap on the device.  Clones own no weights.
+    std::vector<rmu_bert*> clones;
+    std::mutex clones_mu;
+    bool is_clone = false;
 };
+static constexpr size_t MAX_CLONES = 3;
 // rmu_bert_encode_host / rmu_bert_search_mmr carry up to HOST_TOKENS tokens (batch * max_len): one query, or the <= 14 (query, passage)
 // pairs of one rerank call (server/ScoredCrossEncoderReranker.py:42) -- staging: ids | type ids | lens; results: <= 256 rows of 384
 // floats (pooled vectors / the token states of a 256-token call) or one logit per sequence
@@ -3527,6 +3535,8 @@ static int conv_bf16(bf16* dst, const void* src, size_t n, float scale, hipStrea
 extern "C" int rmu_bert_free(rmu_bert_t* m) {
     if (!m) return RMU_OK;
     (void)hipDeviceSynchronize();
+    for (rmu_bert* c : m->clones) (void)rmu_bert_free(c);      // (their `owned` lists are empty: workspaces, staging, graphs, stream)
+    m->clones.clear();
     for (void* p : m->owned) (void)hipFree(p);
     for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->cu, (void*)m->st1, (void*)m->st2})
         if (p) (void)hipFree(p);
@@ -3629,6 +3639,36 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
     }
     *out = m;
     return RMU_OK;
+}
+
+// the context a host-path call runs on: the model itself when it is free, else a free clone (created on first need), else -- everything
+// busy -- the model itself, queued.  `lk` holds the chosen context's mutex on return.
+static rmu_bert* acquire_ctx(rmu_bert* m, std::unique_lock<std::mutex>& lk) {
+    lk = std::unique_lock<std::mutex>(m->mu, std::try_to_lock);
+    if (lk.owns_lock()) return m;
+    {
+        std::lock_guard<std::mutex> g(m->clones_mu);
+        for (rmu_bert* c : m->clones) {
+            lk = std::unique_lock<std::mutex>(c->mu, std::try_to_lock);
+            if (lk.owns_lock()) return c;
+        }
+        if (m->clones.size() < MAX_CLONES) {
+            auto* c = new (std::nothrow) rmu_bert();
+            if (c && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess) {
+                c->cfg = m->cfg;
+                c->wemb = m->wemb; c->pemb = m->pemb; c->temb = m->temb; c->elng = m->elng; c->elnb = m->elnb;
+                c->layers = m->layers;                       // (weight POINTERS: the tensors stay the model's)
+                c->wp = m->wp; c->bp = m->bp; c->wc = m->wc; c->bc = m->bc;
+                c->is_clone = true;
+                m->clones.push_back(c);
+                lk = std::unique_lock<std::mutex>(c->mu);
+                return c;
+            }
+            delete c;
+        }
+    }
+    lk = std::unique_lock<std::mutex>(m->mu);
+    return m;
 }
 
 static void drop_graphs(rmu_bert* m) {       // the captured launches hold workspace addresses
@@ -4235,7 +4275,8 @@ extern "C" int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int
     int rc = check_encode_args(m, ids, lens, out_host, batch, max_len, mode, out_stride);
     if (rc) return rc;
     const int kind = mode & 0xff;
-    std::lock_guard<std::mutex> lk(m->mu);
+    std::unique_lock<std::mutex> lk;
+    m = acquire_ctx(m, lk);
     rc = host_forward_locked(m, ids, type_ids, lens, batch, max_len, mode, "rmu_bert_encode_host");
     if (rc) return rc;
     B_TRY(hipStreamSynchronize(m->stream));
@@ -4264,7 +4305,8 @@ extern "C" int rmu_bert_search_mmr(rmu_bert_t* m, rmu_index_t* idx, const int32_
     if (rc) return rc;
     const int kind = mode & 0xff;
     if (kind != RMU_BERT_POOL_MEAN && kind != RMU_BERT_POOL_CLS) return bfail(RMU_E_INVALID, "rmu_bert_search_mmr: mode must be a pooling mode");
-    std::lock_guard<std::mutex> lk(m->mu);
+    std::unique_lock<std::mutex> lk;
+    m = acquire_ctx(m, lk);
     rc = host_forward_locked(m, ids, type_ids, lens, batch, max_len, mode, "rmu_bert_search_mmr");
     if (rc) return rc;
     // drains m->stream: forward, search, selection and the copies of the results

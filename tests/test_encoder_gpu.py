@@ -381,6 +381,58 @@ def test_host_entry_point_replays_a_graph_and_matches_the_device_path(bi, cross)
         enc.encode_host(np.zeros((40, 128), np.int32), np.full(40, 128, np.int32))             # 5120 tokens: beyond the host entry point
 
 
+def test_host_path_calls_from_several_threads_overlap_on_their_own_contexts(bi):
+    """one mutex serialised every encode of a model across the stream synchronisation, so LCEL's parallel retriever
+    branches (/root/reference/server/RAGHelper_local.py:254-258) ran back to back.  Round 5: a host-path call that finds the model busy runs
+    on a clone context (same weights, own workspace / stream / graphs).  Four threads x 40 embed_query-sized calls, a bulk encode beside
+    them: every result equals the sequential answer bit for bit; the wall time of two threads is printed next to one thread's."""
+    import threading
+    import time
+    enc, _ = bi
+    rng = np.random.default_rng(17)
+    qs = []
+    for L in (12, 16, 31, 48, 20, 64, 9, 27):
+        ids = rng.integers(1000, 30522, (1, L)).astype(np.int32)
+        ids[0, 0], ids[0, -1] = 101, 102
+        qs.append((ids, np.array([L], np.int32)))
+    want = [enc.encode_host(i, l, None, 0) for i, l in qs]
+    for _ in range(3):                                                         # every shape captured on the model's own context
+        for i, l in qs:
+            enc.encode_host(i, l, None, 0)
+    big_ids, _, big_lens = synth_tokens(400, seed=3, lmax=128, mean=100, std=20)
+    big_want = enc.encode_ids(big_ids, big_lens, None, mode=0).cpu().numpy()
+    errors = []
+
+    def worker(t, reps):
+        try:
+            for r in range(reps):
+                j = (t * 3 + r) % len(qs)
+                got = enc.encode_host(qs[j][0], qs[j][1], None, 0)
+                if not np.array_equal(got, want[j]):
+                    errors.append((t, r, j))
+        except Exception as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    def bulk():
+        try:
+            for _ in range(3):
+                if not np.array_equal(enc.encode_ids(big_ids, big_lens, None, mode=0).cpu().numpy(), big_want):
+                    errors.append("bulk")
+        except Exception as e:   # noqa: BLE001
+            errors.append(("bulk", repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t, 40)) for t in range(4)] + [threading.Thread(target=bulk)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[:5]
+    # informational: the same 2 x 200 calls on one thread and on two
+    t0 = time.perf_counter(); worker(0, 400); one = time.perf_counter() - t0
+    th = [threading.Thread(target=worker, args=(t, 200)) for t in range(2)]
+    t0 = time.perf_counter(); [t.start() for t in th]; [t.join() for t in th]; two = time.perf_counter() - t0
+    print(f"\n[host path, 400 query forwards] one thread {one * 1e3:.1f} ms, two threads {two * 1e3:.1f} ms")
+    assert not errors
+
+
 def test_rerank_sized_host_call_equals_the_device_path_and_the_graph_cache_evicts(cross):
     """The reference's rerank call (<= 14 (query, passage) pairs, ~1.5k tokens; ScoredCrossEncoderReranker.py:42) through the host
     entry point: bucketed shape (14 -> 16 sequences, max_len -> a multiple of 32), graph-replayed from the third call on, logits equal
