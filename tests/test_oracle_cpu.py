@@ -31,6 +31,32 @@ def test_c_oracle_metrics(metric):
     assert_topk_parity(cs, cr, s, r, score_tol=1e-3 if metric == O.METRIC_L2SQ else 1e-4)
 
 
+@pytest.mark.parametrize("metric,sk_metric", [(O.METRIC_L2SQ, "sqeuclidean"), (O.METRIC_COSINE, "cosine"), (O.METRIC_IP, None)])
+def test_oracle_flat_search_against_independent_third_party_exact_search(metric, sk_metric):
+    """The stores the reference runs (Milvus-Lite FLAT, pgvector) are not installable here, so the flat-search oracle cannot be pinned on
+    THEM (parity unpinned) -- but exact nearest-neighbour search has independent third-party statements that ARE installed:
+    scikit-learn's brute-force NearestNeighbors (squared Euclidean = Milvus' "L2", cosine distance = pgvector's `<=>`) and scipy's cdist
+    (distance values).  Ids under the tie rule, distances to 1e-5; inner product against a plain float64 matmul + argsort."""
+    from scipy.spatial.distance import cdist
+    from sklearn.neighbors import NearestNeighbors
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((6000, 384)) * rng.uniform(0.5, 2.0, (6000, 1))).astype(np.float32)
+    q = (x[rng.permutation(6000)[:40]] + 0.2 * rng.standard_normal((40, 384))).astype(np.float32)
+    k = 10
+    s, r = O.flat_search(q, x, k + 2, metric)                                  # oracle: larger = better
+    if sk_metric is None:
+        full = q.astype(np.float64) @ x.astype(np.float64).T
+        ref_r = np.argsort(-full, axis=1, kind="stable")[:, :k]
+        ref_s = np.take_along_axis(full, ref_r, 1)
+    else:
+        nn = NearestNeighbors(n_neighbors=k, algorithm="brute", metric=sk_metric).fit(x.astype(np.float64))
+        dist, ref_r = nn.kneighbors(q.astype(np.float64))
+        d2 = cdist(q.astype(np.float64), x.astype(np.float64), sk_metric)
+        assert np.allclose(np.take_along_axis(d2, ref_r, 1), dist, atol=1e-9)  # (the two third-party statements agree with each other)
+        ref_s = -dist if metric == O.METRIC_L2SQ else 1.0 - dist             # oracle convention: -|q - x|^2, cosine similarity
+    assert_topk_parity(ref_s.astype(np.float64), ref_r, s, r, score_tol=1e-5 * (1 + np.abs(ref_s).max()), tie_tol=1e-6 * (1 + np.abs(ref_s).max()))
+
+
 def test_unit_norm_orderings_coincide():
     """on unit vectors L2 (Milvus), cosine distance (pgvector) and IP rank identically."""
     x = O.make_corpus(4000)

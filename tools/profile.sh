@@ -7,7 +7,7 @@
 # with --kernel-trace --stats only.
 set -u
 export RMU_TUNING=1      # librmu honours its RMU_* switches (RMU_SCREEN=0 below) only with this set
-TAG=${1:-r04p}
+TAG=${1:-r05p}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check"
 keep() {  # keep only our kernels' rows of a CSV
   f=$(find $OUT/$1 -name "*$2" | head -1)
-  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|merge_select|merge_wg|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_cls_head|k_cu_seqlens" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
+  if [ -n "$f" ]; then (head -1 $f; grep -E "scan_topk|scan_screen|k_rescore|k_split_rows|k_seed_thr|k_img_err|k_mmr|merge_keys|merge_lists|merge_select|merge_wg|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm|k_attn3|k_qkv_attn_small|k_attention|k_layernorm|k_embed_ln|k_pool|k_cls_head|k_cu_seqlens" $f) | cut -c1-400 > $OUT/$1_$3.csv; fi
 }
 # 1) headline bench (10M x 384, B=1024) on the default path (fp16 hi/lo screening + exact re-score): stats + PMC passes
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan -o scan -- $B > $OUT/scan_bench.json 2> $OUT/scan.err
@@ -53,6 +53,11 @@ timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b3
 keep scan_b32 kernel_stats.csv stats
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b32 -o b -- $B32 > $OUT/pmc_b32_bench.json 2>> $OUT/scan.err
 keep pmc_b32 counter_collection.csv counters
+# 3c) BASELINE.json configs[1] (1M x 384, batch 1024) and the 8-way shard size (1.25M rows): kernel stats (round 5: VERDICT r4 asked for a c2_stats.csv)
+for cfg in "c2 1000000" "shard8 1250000"; do set -- $cfg
+  timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1 -o scan -- python $R/bench.py --rows $2 --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check > $OUT/$1_bench.json 2>> $OUT/scan.err
+  keep $1 kernel_stats.csv stats
+done
 # 4) encoder (config 3) kernel stats (kernel-trace only: a PMC pass over the encoder hung rocprofv3 in round 1)
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/embed -o e -- python $R/bench.py --legs embed --rows 100000 --steps 2 --no-cpu-baseline --no-identity-check --no-kernel-timing > $OUT/embed_bench.json 2>> $OUT/scan.err
 keep embed kernel_stats.csv stats
@@ -71,5 +76,5 @@ for wl in "embed 8192" "rerank 6400"; do set -- $wl; name=$1; n=$2; extra=""; [ 
   ENC_DEVICE_IDS=1 timeout -k 5 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$ENCK" --output-format csv -d $OUT/enc_${name}_w -o a -- python $R/tools/enc_smoke.py $n $extra > /dev/null 2>> $OUT/scan.err
   keep enc_${name}_w counter_collection.csv counters
 done
-for d in enc_embed_f enc_embed_w enc_rerank_f enc_rerank_w top100 enc_pmc scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
+for d in c2 shard8 enc_embed_f enc_embed_w enc_rerank_f enc_rerank_w top100 enc_pmc scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
 ls -la $OUT

@@ -12,15 +12,15 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04p"
-RP = sys.argv[2] if len(sys.argv) > 2 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05p"
+RP = sys.argv[2] if len(sys.argv) > 2 else "r05"
 src = f"gpurun_out/{tag}"
 STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.py then repeats 10 searches with per-launch events (roofline pass)
 
 
 def short(n):
     m = re.search(r'(scan_topk_kernel|scan_screen_lean3_kernel|scan_screen_lean2_kernel|scan_screen_lean_kernel|scan_screen_kernel|k_rescore|k_split_rows|k_seed_thr|k_img_err|merge_keys_partial_kernel|merge_keys_kernel|'
-                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_gemm_small|k_gemm<\d, \d, \d+, \d(?:, \w+)?>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
+                  r'merge_lists_kernel|merge_select_kernel|merge_wg_kernel|k_gather_flagged|k_ffn3|k_ffn2|k_ffn_fused|k_gemm3|k_qkv_attn_small|k_gemm_small|k_gemm<\d, \d, \d+, \d(?:, \w+)?>|k_attn3|k_attention|k_layernorm|k_embed_ln|k_pool|k_tokens_out|k_cls_head)', n)
     s = m.group(1) if m else n[:40]
     if s in ('scan_topk_kernel',):
         c = re.search(r'Cfg<([^>]*)>', n)
@@ -103,7 +103,7 @@ txt = [
     f"# Round {int(RP[1:])} rocprofv3 summary (MI355X, gfx950, ROCm 7.2)",
     f"Produced by `tools/profile.sh {tag}` on the GPU box, condensed by `tools/summarize_profiles.py {tag}`; per-kernel tables:",
     f"`{RP}_*_stats.csv`; counters (mean per dispatch and sum per bench step): `{RP}_pmc_means.csv`.  The screening path launches its",
-    "kernel once per row range of the threshold ladder (7 launches per 10M-row batch), so its counters are summed per bench step.\n",
+    "kernel once per row range of the threshold ladder (7 launches per 10M-row batch of 1024 queries, 5 for <= 128 queries), so its counters are summed per bench step.\n",
     stats('scan', 'headline bench (10M x 384 fp32, batch 1024, top-10), default path = fp16 screening ladder + exact fp32 re-score'),
     stats('exact', 'same workload forced onto the exact fp32 scan (`RMU_SCREEN=0`)'),
     stats('scan_b1', 'HBM-bound regime: batch 1, default path (fp16 image, 768 B per row, screening ladder with ratio 8)'),
@@ -125,6 +125,11 @@ txt = [
     f"- batch 1, exact scan: HBM fetch {f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
 ]
 open(f'profiles/{RP}_summary.md', 'w').write("\n".join(txt) + "\n")
+for t in ('c2', 'shard8'):      # round 5: BASELINE configs[1] and the 8-way shard size (optional outputs of tools/profile.sh)
+    if os.path.exists(f'{src}/{t}_stats.csv'):
+        shutil.copy(f'{src}/{t}_stats.csv', f'profiles/{RP}_{t}_stats.csv')
+        open(f'profiles/{RP}_{t}_bench.json', 'w').write(open(f'{src}/{t}_bench.json').read().strip().splitlines()[-1] + '\n')
+        open(f'profiles/{RP}_summary.md', 'a').write("\n" + stats(t, {'c2': 'BASELINE.json configs[1]: 1M x 384, batch 1024', 'shard8': 'the 8-way shard size: 1.25M x 384, batch 1024'}[t]))
 # C5's dense part and the encoder PMC pass (optional outputs of tools/profile.sh)
 if os.path.exists(f'{src}/top100_stats.csv'):
     shutil.copy(f'{src}/top100_stats.csv', f'profiles/{RP}_top100_stats.csv')
