@@ -141,7 +141,7 @@ class FlatIndex:
         return rows, scores
 
     # -- search ------------------------------------------------------------------------------------
-    def search(self, q, k: int, row_base: int = 0, stream: int | None = None):
+    def search(self, q, k: int, row_base: int = 0, stream: int | None = None, out=None):
         """Exact top-k.  numpy in -> numpy out; torch CUDA in -> torch CUDA out (same device).
         `stream` (torch CUDA input only): a non-zero hipStream_t handle (`torch.cuda.Stream.cuda_stream`) the search is ORDERED
         on -- the call returns without any host synchronisation (include/rmu.h stream contract) and the outputs are valid for
@@ -152,8 +152,14 @@ class FlatIndex:
             if qq.ndim == 1:
                 qq = qq[None]
             nq = qq.shape[0]
-            out_s = torch.empty((nq, k), dtype=torch.float32, device=qq.device)
-            out_r = torch.empty((nq, k), dtype=torch.int64, device=qq.device)
+            if out is not None:                  # caller-owned result tensors (a serving loop: a search whose every address repeats is
+                out_s, out_r = out               # replayed from a captured hipGraph by librmu from its third call on)
+                if (out_s.shape != (nq, k) or out_r.shape != (nq, k) or out_s.dtype != torch.float32 or out_r.dtype != torch.int64
+                        or not out_s.is_contiguous() or not out_r.is_contiguous() or out_s.device != qq.device or out_r.device != qq.device):
+                    raise ValueError("out must be (float32 [nq, k], int64 [nq, k]) contiguous tensors on the queries' device")
+            else:
+                out_s = torch.empty((nq, k), dtype=torch.float32, device=qq.device)
+                out_r = torch.empty((nq, k), dtype=torch.int64, device=qq.device)
             if not stream:
                 torch.cuda.current_stream().synchronize()
             N.check(self._lib.rmu_index_search(self._h, qq.data_ptr(), nq, int(k), N.F_Q_DEVICE | N.F_OUT_DEVICE,

@@ -112,6 +112,7 @@ class ShardedSearcher:
         self.comm = comm                       # the C-ABI RCCL path when given (else torch.distributed)
         self._native_local = local_search is None
         self._stream = None                    # the searcher's own side stream (stream-ordered steps, torch CUDA queries)
+        self._local = {}                       # (batch, k) -> the local (scores, rows) buffers of the stream-ordered step
         if local_search is None:
             if index is None:
                 raise ValueError("need an index or a local_search callable")
@@ -134,15 +135,25 @@ class ShardedSearcher:
         side = self._stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            s, r = self.index.search(q, k, row_base=self.row_base, stream=side.cuda_stream)
+            # the local lists live in buffers the searcher keeps per (batch, k): every step is ordered on `side`, so the next local scan
+            # overwrites them only after this step's pack has read them -- and a local search whose addresses repeat is replayed from a
+            # captured hipGraph inside librmu (rmu_index_search)
+            key = (int(q.shape[0]), int(k))
+            loc = self._local.get(key)
+            if loc is None or loc[0].device != q.device:
+                loc = (torch.empty(key, dtype=torch.float32, device=q.device), torch.empty(key, dtype=torch.int64, device=q.device))
+                if len(self._local) > 8:
+                    self._local.clear()
+                self._local[key] = loc
+            s, r = self.index.search(q, k, row_base=self.row_base, stream=side.cuda_stream, out=loc)
             out = self.comm.allgather_topk(s, r, smaller_better=self.smaller_better, stream=side.cuda_stream)
         cur.wait_stream(side)
-        # Allocator bookkeeping.  q was allocated on the caller's stream and is READ on `side`: q.record_stream(side).  s, r and the
-        # outputs were allocated under `side` (their home stream) and are used on the CALLER's stream from here on: recording `side` on
-        # them is a no-op -- once the caller dropped them the allocator could hand the blocks to the next side-stream search while the
-        # caller's stream is still reading -- so the stream to record is `cur`.
+        # Allocator bookkeeping.  q was allocated on the caller's stream and is READ on `side`: q.record_stream(side).  The outputs were
+        # allocated under `side` (their home stream) and are used on the CALLER's stream from here on: recording `side` on them is a no-op
+        # -- once the caller dropped them the allocator could hand the blocks to the next side-stream search while the caller's stream is
+        # still reading -- so the stream to record is `cur`.  (s, r never leave the side stream: the searcher keeps them.)
         q.record_stream(side)
-        for t in (s, r, *out):
+        for t in out:
             t.record_stream(cur)
         return out
 
@@ -150,9 +161,12 @@ class ShardedSearcher:
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def search(self, q, k: int):
+    def search(self, q, k: int, out=None):
         """q: [B, d] (torch tensor on this rank's device, identical on every rank).
-        Returns (scores [B,k] f32, rows [B,k] i64) -- identical on every rank."""
+        Returns (scores [B,k] f32, rows [B,k] i64) -- identical on every rank.  `out`: caller-owned result tensors for the single-process
+        native path (FlatIndex.search's `out`)."""
+        if out is not None and self._native_local and self.comm is None and self.world == 1 and not self.force_collective:
+            return self.index.search(q, k, row_base=self.row_base, out=out)
         if (self._native_local and self.comm is not None and (self.comm.world > 1 or self.force_collective)
                 and torch.is_tensor(q) and q.is_cuda):
             return self._search_stream_ordered(q, k)

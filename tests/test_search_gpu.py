@@ -915,3 +915,60 @@ def test_every_switchable_screening_kernel_returns_the_exact_answers(env):
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     for nq, r in res.items():
         assert r["screened"] == 1 and r["same"], (env, nq, r)
+
+
+@pytest.mark.gpu
+def test_repeated_searches_replay_a_captured_graph_and_stay_exact(rmu):
+    """Round 5: a screened / deep-k search whose every address and size repeats (device queries, caller-owned result tensors, unchanged
+    index) is captured into a hipGraph on its second call and replayed from the third.  The replays must return what the eager call
+    returned, see rows deleted between two replays (tombstones are poisoned in place: same launches, other bytes), and a changed index
+    (more rows) or other query values in the SAME tensor must be answered from the new state -- always the exact scan's bits."""
+    import torch
+    x = O.make_corpus(300_000, seed=31)
+    q, planted = O.make_queries(x, 200, seed=32)
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    qd = torch.from_numpy(q).cuda()
+    out = (torch.empty((200, 10), dtype=torch.float32, device="cuda"), torch.empty((200, 10), dtype=torch.int64, device="cuda"))
+    first = None
+    for rep in range(5):                                        # eager, capture + launch, replay x 3
+        s, r = idx.search(qd, 10, out=out)
+        assert idx.last_screened() != 0
+        got = (s.cpu().numpy().copy(), r.cpu().numpy().copy())
+        if first is None:
+            first = got
+            assert (got[1][:, 0] == planted).all()
+            assert_topk_parity(got[0][:64], got[1][:64], *O.flat_search(q[:64], x, 14))
+        assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1]), rep
+    # other query VALUES in the same tensor: the replay reads the tensor, not a copy
+    q2, planted2 = O.make_queries(x, 200, seed=33)
+    qd.copy_(torch.from_numpy(q2))
+    s, r = idx.search(qd, 10, out=out)
+    assert (r[:, 0].cpu().numpy() == planted2).all()
+    s_ex, r_ex = idx.search(qd, 33)                             # exact scan (k > 32)
+    assert torch.equal(r_ex[:, :10], r) and torch.equal(s_ex[:, :10], s)
+    # rows deleted between two replays of the same graph
+    dead = np.unique(planted2[:50])
+    idx.remove_rows(dead)
+    s, r = idx.search(qd, 10, out=out)
+    assert not np.isin(r.cpu().numpy(), dead).any()
+    alive = np.ones(len(x), bool); alive[dead] = False
+    assert_topk_parity(s.cpu().numpy()[:48], r.cpu().numpy()[:48], *O.flat_search(q2[:48], x, 14, alive=alive))
+    # the index grows: another key, the new rows are found
+    extra = q2[:20] / np.linalg.norm(q2[:20], axis=1, keepdims=True)
+    first_new = idx.add(extra.astype(np.float32))
+    for rep in range(3):
+        s, r = idx.search(qd, 10, out=out)
+        assert (r[:20, 0].cpu().numpy() == first_new + np.arange(20)).all(), rep
+    # deep k (the exact threshold ladder) through the same mechanism
+    outd = (torch.empty((64, 100), dtype=torch.float32, device="cuda"), torch.empty((64, 100), dtype=torch.int64, device="cuda"))
+    ref = None
+    for rep in range(4):
+        s, r = idx.search(qd[:64], 100, out=outd)
+        cur = (s.cpu().numpy().copy(), r.cpu().numpy().copy())
+        ref = ref or cur
+        assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])
+    with pytest.raises(ValueError):
+        idx.search(qd, 10, out=(out[0][:10], out[1]))
+    idx.close()
+
