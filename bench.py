@@ -961,7 +961,7 @@ def main(argv=None, hooks=None):
             raise RuntimeError(f"{n_ranks_seen} ranks answered, {world} were launched")
     searcher = ShardedSearcher(index, row_base=lo, comm=comm, merge=hooks.get("merge"))
 
-    # caller-owned result tensors (a serving loop's): a search whose every address repeats is replayed from a captured hipGraph inside librmu
+    # caller-owned result tensors (a serving loop's)
     hout = (torch.empty((B, K), dtype=torch.float32, device=device), torch.empty((B, K), dtype=torch.int64, device=device)) if on_gpu and "index_cls" not in hooks else None
 
     def step():

@@ -16,7 +16,6 @@
 #include <chrono>
 #include <shared_mutex>
 #include <string>
-#include <unordered_map>
 #include <vector>
 #include <cmath>
 #include <cstdio>
@@ -62,8 +61,6 @@ extern "C" int rmu_init(int device_ordinal) {
 static bool g_runtime_down = false;
 namespace { struct RuntimeGuard { ~RuntimeGuard() { g_runtime_down = true; } } g_runtime_guard; }
 
-// bumps whenever a workspace buffer of this thread is re-allocated: captured search graphs hold workspace addresses (see SearchGraph)
-static thread_local uint64_t g_buf_epoch = 0;
 struct Buf {
     void* p = nullptr;
     size_t cap = 0;
@@ -73,7 +70,6 @@ struct Buf {
     }
     int ensure(size_t bytes) {
         if (bytes <= cap) return RMU_OK;
-        ++g_buf_epoch;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 4 + 256;
@@ -94,23 +90,6 @@ struct Tls {
             lev.push_back(e);
         }
         return RMU_OK;
-    }
-    // (round 5) A screened / deep-k search is 15-30 dependent stream operations (memsets, query conversion, a scan + a merge per ladder
-    // range, re-score, the device-predicated re-runs).  Enqueued one by one each costs ~4.4 us while the host is the slower side (the first,
-    // small ranges); replayed from a captured hipGraph ~1.7 us (tools/ubench/graph_chain.hip).  A search whose EVERY address and size repeats
-    // -- same index state, same device query / output buffers (a serving loop with pre-allocated tensors, bench.py) -- is captured on its
-    // second call and replayed from the third on.  The key covers every value the enqueued operations depend on; a re-allocated workspace
-    // buffer (g_buf_epoch) makes every cached graph of the thread unreachable.
-    struct SearchGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool warm = false, screened = false; uint64_t last_use = 0;
-                         int grid = 0, block = 0, lds = 0, passes = 0; };
-    std::unordered_map<uint64_t, SearchGraph> sgraphs;
-    uint64_t sg_clock = 0;
-    void drop_search_graphs() {
-        for (auto& kv : sgraphs) {
-            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-            if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-        }
-        sgraphs.clear();
     }
     int* hflag = nullptr;          // pinned landing word of the screening path's re-run count
     char* hpin = nullptr;          // pinned landing buffer of search_mmr_on's results (rows | scores in ONE device-to-host copy)
@@ -162,8 +141,6 @@ struct Tls {
         if (pending) (void)hipEventSynchronize(pend_ev);
         if (pend_ev) (void)hipEventDestroy(pend_ev);
         if (stream) (void)hipStreamSynchronize(stream);
-        drop_search_graphs();
-        if (hpin) (void)hipHostFree(hpin);
         for (Buf* b : {&q, &partial, &out_s, &out_r, &in_s, &in_r, &qn, &gthr, &mscratch, &qsplit, &ckeys, &flag, &nrm, &fbq, &fb_s,
                        &fb_r, &fb_i, &mm_q, &mm_s, &mm_r, &mm_p})
             b->release();
@@ -1080,9 +1057,6 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
 
     for (int64_t q0 = 0; q0 < nq; q0 += kMaxQueriesPerLaunch) {
         const int64_t nb = (nq - q0) < kMaxQueriesPerLaunch ? (nq - q0) : kMaxQueriesPerLaunch;
-        bool exact_timed = false, screened = false;
-        // everything one query block enqueues on `s` (no synchronisation inside): run eagerly, or captured into / replayed from a hipGraph
-        auto enqueue_block = [&]() -> int {
         // ---- queries -> device, padded to dpad, normalised for COSINE, augmented for L2SQ -----------------------------
         const float* qsrc = q + q0 * dim;
         const float* qdev = qsrc;
@@ -1115,6 +1089,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             d_r = (int64_t*)t.out_r.p;
         }
         static const int share = rmu_env("RMU_NO_SHARED_THR") ? 0 : 1;
+        bool exact_timed = false;
         // ---- the exact fp32 fused scan + merge of `nqq` device queries.  plan first (all workspace is sized before anything
         // is enqueued: a grow-only buffer must not be re-allocated under work already in flight), then run.  `cond`
         // (optional) makes both launches conditional on the device-side count of flagged queries; `scatter` redirects
@@ -1157,7 +1132,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             if (g_dbg && !has_cond) dbg_dump("exact", idx->n, s);
             return RMU_OK;
         };
-        screened = screen_applies(idx, nb, k);
+        const bool screened = screen_applies(idx, nb, k);
         if (screened) {
             // ---- screened path: fp16 scan proposes K' = 32 candidates, exact fp32 re-score decides --------------------------
             // Flagged queries -> exact scan, decided ON THE DEVICE: three mutually exclusive conditional launches
@@ -1263,75 +1238,6 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         if (!out_dev) {
             HIP_TRY(hipMemcpyAsync(out_scores + q0 * k, d_s, (size_t)nb * k * sizeof(float), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(out_rows + q0 * k, d_r, (size_t)nb * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        }
-        return RMU_OK;
-        };
-        static const bool graphs_on = !(rmu_env("RMU_SEARCH_GRAPH") && atoi(rmu_env("RMU_SEARCH_GRAPH")) == 0);
-        const bool graphable = graphs_on && q_dev && out_dev && !timed && !g_dbg && nq <= kMaxQueriesPerLaunch &&
-                               (screen_applies(idx, nb, k) || deep_applies(idx, k));
-        if (!graphable) {
-            if ((rc = enqueue_block())) return rc;
-        } else {
-            // every value the enqueued operations depend on (FNV-1a over the words)
-            uint64_t key = 1469598103934665603ull;
-            auto mix = [&](uint64_t v) { for (int b = 0; b < 8; ++b) { key ^= (v >> (8 * b)) & 0xff; key *= 1099511628211ull; } };
-            uint32_t fb[2];
-            memcpy(&fb[0], &idx->xnorm_max, 4); memcpy(&fb[1], &idx->dx_max, 4);
-            for (uint64_t v : {(uint64_t)(uintptr_t)idx, (uint64_t)(uintptr_t)idx->x, (uint64_t)(uintptr_t)idx->split, (uint64_t)idx->n, (uint64_t)fb[0],
-                               (uint64_t)fb[1], (uint64_t)idx->metric, (uint64_t)idx->screen_enabled, (uint64_t)idx->screen_min_nq, (uint64_t)idx->ladder_ratio,
-                               (uint64_t)idx->ladder_first, (uint64_t)nb, (uint64_t)k, (uint64_t)flags, (uint64_t)row_base, (uint64_t)(uintptr_t)q,
-                               (uint64_t)(uintptr_t)out_scores, (uint64_t)(uintptr_t)out_rows, g_buf_epoch})
-                mix(v);
-            auto it = t.sgraphs.find(key);
-            if (it != t.sgraphs.end() && it->second.exec) {
-                Tls::SearchGraph& g = it->second;
-                g.last_use = ++t.sg_clock;
-                HIP_TRY(hipGraphLaunch(g.exec, s));
-                screened = g.screened;
-                t.grid = g.grid; t.block = g.block; t.lds = g.lds; t.passes += g.passes;
-            } else if (it != t.sgraphs.end() && it->second.warm) {
-                // second call with this key: capture (function attributes and first-use statics of the launchers are set by now)
-                Tls::SearchGraph& g = it->second;
-                g.last_use = ++t.sg_clock;
-                g.warm = false;                              // one attempt: a key whose capture fails stays eager
-                const uint64_t epoch0 = g_buf_epoch;
-                const int passes0 = t.passes;
-                bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-                int rc_cap = RMU_OK;
-                if (ok) {
-                    rc_cap = enqueue_block();
-                    hipGraph_t cg = nullptr;
-                    ok = hipStreamEndCapture(s, &cg) == hipSuccess && cg != nullptr && rc_cap == RMU_OK && epoch0 == g_buf_epoch;
-                    if (ok) ok = hipGraphInstantiate(&g.exec, cg, nullptr, nullptr, 0) == hipSuccess;
-                    if (ok) g.graph = cg;
-                    else { if (cg) (void)hipGraphDestroy(cg); g.exec = nullptr; }
-                }
-                (void)hipGetLastError();
-                if (rc_cap) return rc_cap;
-                if (ok) {
-                    g.screened = screened; g.grid = t.grid; g.block = t.block; g.lds = t.lds; g.passes = t.passes - passes0;
-                    HIP_TRY(hipGraphLaunch(g.exec, s));      // (a capture records, it does not run)
-                } else {
-                    t.passes = passes0;
-                    if ((rc = enqueue_block())) return rc;
-                }
-            } else {
-                if (it == t.sgraphs.end()) {
-                    if (t.sgraphs.size() >= 16) {            // full: the least recently used goes (none of them may still be running)
-                        (void)hipDeviceSynchronize();
-                        auto victim = t.sgraphs.begin();
-                        for (auto j = t.sgraphs.begin(); j != t.sgraphs.end(); ++j)
-                            if (j->second.last_use < victim->second.last_use) victim = j;
-                        if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
-                        if (victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
-                        t.sgraphs.erase(victim);
-                    }
-                    Tls::SearchGraph g;
-                    g.warm = true; g.last_use = ++t.sg_clock;
-                    t.sgraphs.emplace(key, g);
-                }
-                if ((rc = enqueue_block())) return rc;
-            }
         }
         // workspace is reused by the next query block (and host outputs must land): drain per block.  With a caller stream,
         // device outputs and a single block nothing here waits: the work is merely ordered on that stream.

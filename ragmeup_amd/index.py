@@ -152,8 +152,8 @@ class FlatIndex:
             if qq.ndim == 1:
                 qq = qq[None]
             nq = qq.shape[0]
-            if out is not None:                  # caller-owned result tensors (a serving loop: a search whose every address repeats is
-                out_s, out_r = out               # replayed from a captured hipGraph by librmu from its third call on)
+            if out is not None:                  # caller-owned result tensors (a serving loop's)
+                out_s, out_r = out
                 if (out_s.shape != (nq, k) or out_r.shape != (nq, k) or out_s.dtype != torch.float32 or out_r.dtype != torch.int64
                         or not out_s.is_contiguous() or not out_r.is_contiguous() or out_s.device != qq.device or out_r.device != qq.device):
                     raise ValueError("out must be (float32 [nq, k], int64 [nq, k]) contiguous tensors on the queries' device")

@@ -136,8 +136,7 @@ class ShardedSearcher:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             # the local lists live in buffers the searcher keeps per (batch, k): every step is ordered on `side`, so the next local scan
-            # overwrites them only after this step's pack has read them -- and a local search whose addresses repeat is replayed from a
-            # captured hipGraph inside librmu (rmu_index_search)
+            # overwrites them only after this step's pack has read them (no allocator traffic per step)
             key = (int(q.shape[0]), int(k))
             loc = self._local.get(key)
             if loc is None or loc[0].device != q.device:

@@ -918,11 +918,11 @@ def test_every_switchable_screening_kernel_returns_the_exact_answers(env):
 
 
 @pytest.mark.gpu
-def test_repeated_searches_replay_a_captured_graph_and_stay_exact(rmu):
-    """Round 5: a screened / deep-k search whose every address and size repeats (device queries, caller-owned result tensors, unchanged
-    index) is captured into a hipGraph on its second call and replayed from the third.  The replays must return what the eager call
-    returned, see rows deleted between two replays (tombstones are poisoned in place: same launches, other bytes), and a changed index
-    (more rows) or other query values in the SAME tensor must be answered from the new state -- always the exact scan's bits."""
+def test_repeated_searches_into_caller_owned_tensors_stay_exact(rmu):
+    """FlatIndex.search(out=(scores, rows)): a serving loop's pre-allocated result tensors.  Repeated searches with identical addresses must
+    return what the first returned, see rows deleted in between (tombstones are poisoned in place), other query VALUES in the same tensor,
+    and a grown index -- always the exact scan's bits.  (Round 5 also captured such searches into a hipGraph and replayed them: bit-identical,
+    and measured NO faster -- 1.387 vs 1.372 ms at batch 32 over 10M rows, profiles/r05_search_graph_ab.txt -- so the capture was removed.)"""
     import torch
     x = O.make_corpus(300_000, seed=31)
     q, planted = O.make_queries(x, 200, seed=32)

@@ -26,7 +26,7 @@ qall /= qall.norm(dim=1, keepdim=True)
 del x
 for b in [int(v) for v in a.batches.split(",")]:
     q = qall[:b].contiguous()
-    out = (torch.empty((b, a.k), dtype=torch.float32, device=dev), torch.empty((b, a.k), dtype=torch.int64, device=dev))   # stable addresses: graph replay
+    out = (torch.empty((b, a.k), dtype=torch.float32, device=dev), torch.empty((b, a.k), dtype=torch.int64, device=dev))
     ref = None
     for cfg in a.cfgs.split(","):
         ratio, first = (int(v) for v in cfg.split(":"))
