@@ -859,7 +859,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank")
+    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b16,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank")
     ap.add_argument("--index-texts", type=int, default=1_000_000, help="texts pushed through add_documents by the `index` leg (BASELINE.json configs[2]: 1M chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-identity-check", action="store_true",
@@ -929,7 +929,7 @@ def main(argv=None, hooks=None):
     if world > 1:
         dist.broadcast(q, 0)
         dist.broadcast(planted, 0)
-    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
+    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b16,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
     sample_host = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample_host = shard[:min(n_local, 2_000_000)].cpu().numpy()
@@ -1046,21 +1046,28 @@ def main(argv=None, hooks=None):
         index.set_screening(False)
         secondary.append(scan_leg("exact fp32 scan only (RMU_OPT_SCREEN = 0), same workload as the headline", index, q, n_local, 4))
         index.set_screening(True)
-    for b in (128, 32, 1):
+    for b in (128, 32, 16, 1):
         if f"b{b}" in legs and B >= b:
             secondary.append(scan_leg(f"HBM-bound regime: batch {b}" + (" (the reference's one query per call)" if b == 1 else ""),
                                       index, q[:b].contiguous(), n_local, 20))
     # the north-star sentence of BASELINE.json (">= 10k queries/sec dense top-10 over 10M x 384 at >= 70 % HBM-bandwidth roofline on 1 GPU") lives in
-    # the small-batch regime; the driver keeps `roofline`, so the leg's figures are repeated there (on STEP time and on kernel time)
+    # the small-batch regime and names no batch size; the driver keeps `roofline`, so the figures of the batch-32 and batch-16 legs are repeated
+    # there (on STEP time and on kernel time), the one with the best step-time fraction among those above 10k queries/sec first
+    ns = []
     for leg in secondary:
-        if leg["name"].startswith("HBM-bound regime: batch 32") and roofline is not None and leg.get("roofline"):
+        m = leg["name"].startswith("HBM-bound regime: batch ") and leg.get("roofline")
+        if m and leg["config"]["workload"].find(" batch 32 ") + leg["config"]["workload"].find(" batch 16 ") > -2:
             r32 = leg["roofline"]
             abytes = r32.get("algorithmic_bytes") or 0
-            roofline["north_star"] = {"batch": 32, "qps": leg["value"], "step_ms": leg["ms_per_step"], "kernel_ms": r32.get("kernel_ms"),
-                                      "hbm_frac_step": round(abytes / (leg["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if abytes else None,
-                                      "hbm_frac_kernel": r32.get("hbm_frac", r32.get("frac")), "launches": (r32.get("launch") or {}).get("launches"),
-                                      "target": ">= 10000 queries/sec at >= 0.70 of 8 TB/s (BASELINE.json north_star)"}
-    note("scan legs (exact / b128 / b32 / b1)")
+            ns.append({"batch": int(leg["config"]["workload"].split(" batch ")[1].split()[0]), "qps": leg["value"], "step_ms": leg["ms_per_step"],
+                       "kernel_ms": r32.get("kernel_ms"),
+                       "hbm_frac_step": round(abytes / (leg["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if abytes else None,
+                       "hbm_frac_kernel": r32.get("hbm_frac", r32.get("frac")), "launches": (r32.get("launch") or {}).get("launches")})
+    if ns and roofline is not None:
+        ns.sort(key=lambda d: (d["qps"] >= 10000.0, d["hbm_frac_step"] or 0.0), reverse=True)
+        roofline["north_star"] = dict(ns[0], target=">= 10000 queries/sec at >= 0.70 of 8 TB/s (BASELINE.json north_star; no batch size named)",
+                                      meets_target_on_step_time=bool(ns[0]["qps"] >= 10000.0 and (ns[0]["hbm_frac_step"] or 0) >= 0.70),
+                                      other_batches=ns[1:])
     if x_emu is not None:
         # the 8-GPU step of BASELINE.json configs[3] EMULATED on one GPU -- the shard one rank of 8 owns (N / 8 rows), the
         # whole sharded step as ShardedSearcher runs it (local scan -> pack -> rmu_shard_allgather_topk on a WORLD-SIZE-1 RCCL communicator ->
