@@ -504,8 +504,9 @@ def leg_index(args) -> dict:
                              "note": "rmu_index_stat: re-allocations (x1.5 + D2D copy of corpus matrix and fp16 image) inside the timed passes and their wall "
                                      "time in ms -- no capacity is known up front, as with the reference's Milvus collection"},
            "reference_pattern_1000_doc_calls": {"chunks_per_sec": round(n / ref_s, 1), "seconds": round(ref_s, 3),
-                                                "note": "server/RAGHelper.py:423-434's loop; a call returns when its host half is done (ids, records, row numbers fixed); up to 8 GPU halves "
-                                                        "(forward + append) queue behind it and the worker runs whatever is queued as ONE forward -- every reader / writer of the index waits for them first"},
+                                                "note": "server/RAGHelper.py:423-434's loop on the default store (pipeline_inserts='auto'): the first call is synchronous, a call that follows within 0.25 s returns when its host half is done "
+                                                        "(ids, records, row numbers fixed); up to 8 GPU halves (forward + append) queue behind it and the worker runs whatever is queued as ONE forward -- every reader / "
+                                                        "writer of the index waits for them first; flush() ends the loop"},
            "encoder_only": {"chunks_per_sec": round(n / enc_s, 1), "seconds": round(enc_s, 3), "note": "encode_ids on pre-tokenised, device-resident 8192-chunk batches of the same texts"},
            "tokenizer_only": {"texts_per_sec": round(n / tok_s, 1), "seconds": round(tok_s, 3), "threads": os.cpu_count(), "note": "rmu_tok_encode (host C++), all hardware threads"},
            "end_to_end_over_encoder_only": round(enc_s / one_s, 3),
