@@ -8,6 +8,9 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "librmu.so")
+# A/B of two builds on one GPU box (tools/enc_ab.sh lib_prev:RMU_LIB=...): honoured only with RMU_TUNING=1, like every tuning switch
+if os.environ.get("RMU_TUNING") == "1" and os.environ.get("RMU_LIB"):
+    SO_PATH = os.path.abspath(os.environ["RMU_LIB"])
 
 RMU_OK = 0
 METRIC_IP, METRIC_COSINE, METRIC_L2SQ = 0, 1, 2

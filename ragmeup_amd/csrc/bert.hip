@@ -1538,7 +1538,9 @@ constexpr int W2_OFF = 3 * S1, RING = 3 * S1 + 2 * S2;
 constexpr int B1_OFF = RING;
 constexpr int XP_OFF = B1_OFF + FF * 4;             // 8 waves x 4 KiB: the fp32 partial of the partner's tile
 constexpr int PX_OFF = XP_OFF + 8 * 4096;           // 4 pairs x 2 tiles x 2 KiB: activated B fragments
-constexpr int LDS_BYTES = PX_OFF + 8 * 2048;
+constexpr int LN_OFF = PX_OFF + 8 * 2048;           // (round 5) gamma1 | beta1 | gamma2 | beta2 | b2, fp32: the two LayerNorms / the epilogue read them behind a barrier --
+                                                    // from LDS that is a ~100-cycle read, from global an exposed L2 round trip with nothing else on the CU
+constexpr int LDS_BYTES = LN_OFF + 5 * H * 4;      // (+ b2)
 constexpr int TSTR = H * 2 + 16;
 static_assert(LDS_BYTES <= 160 * 1024 && TOK * TSTR <= LDS_BYTES, "LDS");
 // DMA instructions per wave that may still be in flight when slab i must have landed (W1 slab = 2 per wave, W2 slab = 3; issue
@@ -1567,6 +1569,8 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
     using ffn::static_for; using ffn::ds_read16;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    // (round 5, measured and not kept: issuing the token / parameter loads BEFORE M = cu[batch] is known, to share one round trip -- the half
+    // of the grid that lies past M (the grid is sized by batch * max_len) then pays for loads it abandons: 3 186 vs 3 057 us per launch)
     const int M = cu[batch];
     const int m0 = blockIdx.x * TOK;
     if (m0 >= M) return;
@@ -1640,6 +1644,11 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         issue_stream_prologue();       // behind the token loads in the CU's in-order memory queue: LayerNorm 1 starts on the rows while the slabs land
     }
     for (int i = threadIdx.x; i < FF; i += 512) b1s[i] = b1[i];
+    float* lnp = (float*)(gsm + LN_OFF);
+    if (threadIdx.x < H) {
+        const int i = threadIdx.x;
+        lnp[i] = g1 ? g1[i] : 1.f; lnp[H + i] = bta1 ? bta1[i] : 0.f; lnp[2 * H + i] = g[i]; lnp[3 * H + i] = bta[i]; lnp[4 * H + i] = b2[i];
+    }
     if constexpr (OP) {
         // ---- the attention block's output projection, here instead of in a launch of its own: y = ctx . Wo^T + bo + h for this wave's
         // 32 tokens x ITS 192 features (the half s it needs as token fragments), then LayerNorm 1 -- the pre-LN sum never exists in memory,
@@ -1787,8 +1796,8 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int f0 = s * 192 + j * 16 + hh * 8;
-            const f32x4 ga = *(const f32x4*)(g1 + f0), gb = *(const f32x4*)(g1 + f0 + 4);
-            const f32x4 ba = *(const f32x4*)(bta1 + f0), bb = *(const f32x4*)(bta1 + f0 + 4);
+            const f32x4 ga = *(const f32x4*)(lnp + f0), gb = *(const f32x4*)(lnp + f0 + 4);
+            const f32x4 ba = *(const f32x4*)(lnp + H + f0), bb = *(const f32x4*)(lnp + H + f0 + 4);
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2096,7 +2105,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
                     const u32x2 rs2 = OP ? (qb ? u32x2{hv[2], hv[3]} : u32x2{hv[0], hv[1]}) : ((qb == hh) ? own : rcv);
                     const bf16x4 res = __builtin_bit_cast(bf16x4, rs2);
                     const int n = s * 192 + j * 32 + q * 8 + hh * 4;
-                    const f32x4 bv = *(const f32x4*)(b2 + n);
+                    const f32x4 bv = *(const f32x4*)(lnp + 4 * H + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float yv = bf2f((bf16)(bf2f((bf16)(acc2[j][4 * q + e] + bv[e])) + bf2f(res[e])));
@@ -2126,7 +2135,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = s * 192 + j * 32 + q * 8 + hh * 4;
-                const f32x4 ga = *(const f32x4*)(g + n), ba = *(const f32x4*)(bta + n);
+                const f32x4 ga = *(const f32x4*)(lnp + 2 * H + n), ba = *(const f32x4*)(lnp + 3 * H + n);
                 bf16x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (bf16)((acc2[j][4 * q + e] - mu) * rs * ga[e] + ba[e]);
