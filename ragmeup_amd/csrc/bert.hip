@@ -454,7 +454,27 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail reloads: the ring is reused below
+    // (round 5) The epilogue's global reads -- the bias and, for EPI_RESID, the residual rows this lane will add -- are requested HERE, in
+    // front of the drain of the ring's tail reloads: they used to be two more dependent round trips behind it (bias -> staging -> residual
+    // -> store), exposed whenever the co-resident workgroup was in its own epilogue.
+    f32x4 bvp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bvp[i] = *(const f32x4*)(bias + n0 + wn * 64 + i * 16 + (lane >> 4) * 4);
+    bf16x8 rvp[8];
+    if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+            const int row = r8 * 8 + (lane >> 3), u = lane & 7;
+            const int m = min(m0 + wm * 64 + row, M - 1);          // (rows >= M are never stored)
+            int64_t roff = (int64_t)m * N + n0 + wn * 64 + u * 8;
+            if (dbg & 256) {                       // the residual is a TILED activation (1-KiB blocks of 16 tokens x 32 features, see k_ffn3's store)
+                const int col = n0 + wn * 64 + u * 8, r = m & 15;
+                roff = ((int64_t)(m >> 4) * (N / 32) + (col >> 5)) * 512 + r * 32 + ((((col >> 3) & 3) ^ tswz(r)) * 8);
+            }
+            rvp[r8] = *(const bf16x8*)(resid + roff);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail reloads (and the reads above): the ring is reused below
     __syncthreads();
     // epilogue.  A lane holds features n..n+3 (rows of D^T) of token m (column of D^T): written straight to HBM
     // that is 16 rows x 32 B per store instruction.  Instead each wave parks its 64 x 64 bf16 tile in LDS
@@ -468,7 +488,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nl = i * 16 + kg * 4;         // feature inside the wave tile
-            const f32x4 bv = *(const f32x4*)(bias + n0 + wn * 64 + nl);
+            const f32x4 bv = bvp[i];
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bv[e];
@@ -492,12 +512,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
             bf16x8 o = *(const bf16x8*)(tile + row * TSTR + u * 16);
             const int64_t off = (int64_t)m * N + n0 + wn * 64 + u * 8;
             if (EPI == EPI_RESID) {
-                int64_t roff = off;
-                if (dbg & 256) {                   // the residual is a TILED activation (1-KiB blocks of 16 tokens x 32 features, see k_ffn3's store)
-                    const int col = n0 + wn * 64 + u * 8, r = m & 15;
-                    roff = ((int64_t)(m >> 4) * (N / 32) + (col >> 5)) * 512 + r * 32 + ((((col >> 3) & 3) ^ tswz(r)) * 8);
-                }
-                const bf16x8 rv = *(const bf16x8*)(resid + roff);
+                const bf16x8 rv = rvp[r8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (bf16)(bf2f(o[e]) + bf2f(rv[e]));
             }
