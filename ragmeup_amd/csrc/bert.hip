@@ -279,6 +279,88 @@ __global__ __launch_bounds__(256) void k_embed_ln(const int* __restrict__ ids, c
     }
 }
 
+// The same for BULK batches (round 5): k_embed_ln gives every (sequence, position) SLOT a wave -- half of them padding that exits after one
+// round trip -- and a live wave walks a chain of three dependent round trips (offsets -> ids -> embedding rows) for ONE token: latency x
+// occupancy, 0.65 ms per 1.04 M tokens.  Here a workgroup takes a SEQUENCE: its waves walk the positions four at a time (ids by scalar loads,
+// the twelve row pieces of four tokens in flight together, the four LayerNorms' butterflies interleaved as in k_layernorm); no wave is ever
+// started for padding.  Same arithmetic per row as k_embed_ln (a + p + t, two-pass statistics over the same butterfly): identical output.
+__global__ __launch_bounds__(256) void k_embed_ln_seq(const int* __restrict__ ids, const int* __restrict__ type_ids,
+                                                      const int* __restrict__ cu, int batch, int max_len,
+                                                      const float* __restrict__ wemb, const float* __restrict__ pemb,
+                                                      const float* __restrict__ temb, const float* __restrict__ g,
+                                                      const float* __restrict__ bta, float eps, int vocab, int type_vocab,
+                                                      bf16* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    if (L <= 0) return;
+    const bool act = lane < 48;
+    const int c0 = (act ? lane : 0) * 8;
+    f32x4 g0 = {}, g1 = {}, b0 = {}, b1 = {};
+    if (act) { g0 = *(const f32x4*)(g + c0); g1 = *(const f32x4*)(g + c0 + 4); b0 = *(const f32x4*)(bta + c0); b1 = *(const f32x4*)(bta + c0 + 4); }
+    const int* idr = ids + (int64_t)b * max_len;
+    const int* ttr = type_ids ? type_ids + (int64_t)b * max_len : nullptr;
+    for (int p0 = w * 4; p0 < L; p0 += 16) {
+        int id[4], tt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pos = min(p0 + u, L - 1);            // (rows past the sequence are computed on the last token and not stored)
+            id[u] = min(max(idr[pos], 0), vocab - 1);
+            tt[u] = ttr ? min(max(ttr[pos], 0), type_vocab - 1) : 0;
+        }
+        float v[4][8], sm[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pos = min(p0 + u, L - 1);
+            const float* we = wemb + (int64_t)id[u] * H + c0;
+            const float* pe = pemb + (int64_t)pos * H + c0;
+            const float* te = temb + (int64_t)tt[u] * H + c0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 a = {}, p = {}, t = {};
+                if (act) { a = *(const f32x4*)(we + 4 * hf); p = *(const f32x4*)(pe + 4 * hf); t = *(const f32x4*)(te + 4 * hf); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[u][4 * hf + i] = a[i] + p[i] + t[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sm[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sm[u] += v[u][i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sm[u] += __shfl_xor(sm[u], o);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sm[u] *= (1.0f / H);
+            q[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = act ? v[u][i] - sm[u] : 0.f; q[u] = fmaf(d, d, q[u]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] += __shfl_xor(q[u], o);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float rs = rsqrtf(q[u] * (1.0f / H) + eps);
+            if (act && p0 + u < L) {
+                bf16x8 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = (bf16)((v[u][i] - sm[u]) * rs * g0[i] + b0[i]);
+                    o[4 + i] = (bf16)((v[u][4 + i] - sm[u]) * rs * g1[i] + b1[i]);
+                }
+                *(bf16x8*)(out + ((int64_t)t0 + p0 + u) * H + c0) = o;
+            }
+        }
+    }
+}
+
 // out = LayerNorm(y) (y already holds GEMM + bias + residual); a wave takes LN_ROWS consecutive tokens with all their loads in
 // flight before the first reduction (one row per wave left the kernel latency-bound at ~4 TB/s of its 1.6 GB)
 constexpr int LN_ROWS = 4;
@@ -2082,6 +2164,8 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
             }
         });
     }
+    // (measured, round 5: moving this drain behind the epilogue's statistics -- it only has to precede the tile writes -- changes nothing:
+    // 3 077 / 3 083 vs 3 065 / 3 092 us per launch)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the tail reloads: the LDS becomes the output tile
     __syncthreads();
     char* tile = gsm;
@@ -4010,6 +4094,12 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
                            m->cfg.type_vocab, m->h, (const int*)lens, m->cu);
     } else {
         hipLaunchKernelGGL(k_cu_seqlens, dim3(1), dim3(batch <= 64 ? 64 : batch <= 256 ? 256 : 1024), 0, s, (const int*)lens, batch, max_len, m->cu);
+        // bulk batches: a workgroup per sequence (k_embed_ln_seq); RMU_EMBED_SEQ=0: a wave per (sequence, position) slot as before
+        static const bool embed_seq = !(rmu_env("RMU_EMBED_SEQ") && atoi(rmu_env("RMU_EMBED_SEQ")) == 0);
+        if (embed_seq && batch >= 512)
+            hipLaunchKernelGGL(k_embed_ln_seq, dim3((unsigned)batch), dim3(256), 0, s, (const int*)ids, (const int*)type_ids, (const int*)m->cu, batch, max_len,
+                               m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size, m->cfg.type_vocab, m->h);
+        else
         hipLaunchKernelGGL(k_embed_ln<false>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, (const int*)ids, (const int*)type_ids,
                            (const int*)m->cu, batch, max_len, m->wemb, m->pemb, m->temb, m->elng, m->elnb, eps, m->cfg.vocab_size,
                            m->cfg.type_vocab, m->h);
