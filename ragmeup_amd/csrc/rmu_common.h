@@ -103,7 +103,9 @@ inline const char* rmu_env(const char* name) {
         const bool o = t != nullptr && atoi(t) == 1;
         if (!o && environ) {
             for (char** e = environ; *e; ++e)
-                if (!strncmp(*e, "RMU_", 4) && strncmp(*e, "RMU_TUNING=", 11) && strncmp(*e, "RMU_SCREEN=", 11) && strncmp(*e, "RMU_GRAPH=", 10)) {
+                // (RMU_BENCH_* / RMU_REFERENCE_DIR belong to bench.py and the tests, not to the library)
+                if (!strncmp(*e, "RMU_", 4) && strncmp(*e, "RMU_TUNING=", 11) && strncmp(*e, "RMU_SCREEN=", 11) && strncmp(*e, "RMU_GRAPH=", 10) &&
+                    strncmp(*e, "RMU_BENCH_", 10) && strncmp(*e, "RMU_REFERENCE_DIR=", 18)) {
                     fprintf(stderr, "librmu: %.*s is set but ignored: tuning switches are honoured only with RMU_TUNING=1 (DESIGN.md 6.1)\n",
                             (int)(strchr(*e, '=') ? strchr(*e, '=') - *e : (long)strlen(*e)), *e);
                     break;
