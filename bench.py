@@ -13,9 +13,11 @@ screening ladder -> merges -> exact fp32 re-score of 32 candidates per query, re
 `value` is timed with nothing but the product path inside the bracket (no per-launch events); the dominant kernel's
 launch durations (roofline) are measured afterwards, on the same inputs, with hipEvents on the stream the kernels run on.
 At N = 1 the same run also reports, under "secondary", every other BASELINE.json configuration (C1 on the GPU path, C2, C3, C5) with its own roofline and
-CPU figure: the exact fp32 scan (API switch), the HBM-bound batch sizes 1 / 32 / 128, config 2 (1M rows), config 3
-(chunk embedding) and config 5 (dense top-100 -> cross-encoder rerank -> top-10), and the CPU baselines of config 1 timed on
-this box's host cores (count stated).  Inputs are generated on the device and are resident in HBM before any timed region.
+CPU figure: the exact fp32 scan (API switch), the HBM-bound batch sizes 1 / 16 / 32 / 128 (the best of 16 / 32 above 10k queries/sec is
+repeated as `roofline.north_star`, on step and on kernel time), the EMULATED 8-way shard step (`emu8`, `roofline.emulated_shard_8`), config 2
+(1M rows), config 3 (chunk embedding) and config 5 (dense top-100 -> cross-encoder rerank -> top-10), config 1 on the GPU path with its
+TEXT-IN recall@10 against transformers fp32 (`recall_at_10_text_in`), and the CPU baselines of config 1 timed on this box's host cores
+(count stated).  Inputs are generated on the device and are resident in HBM before any timed region.
 The oracle is used only for the cpu_baseline legs and the recall check (never inside a timed region).
 """
 from __future__ import annotations
