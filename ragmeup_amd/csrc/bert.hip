@@ -553,7 +553,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm(const bf16* __restrict__ A, c
                 const int col = n0 + wn * 64 + u * 8, r = m & 15;
                 roff = ((int64_t)(m >> 4) * (N / 32) + (col >> 5)) * 512 + r * 32 + ((((col >> 3) & 3) ^ tswz(r)) * 8);
             }
-            rvp[r8] = *(const bf16x8*)(resid + roff);
+            rvp[r8] = __builtin_nontemporal_load((const bf16x8*)(resid + roff));
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail reloads (and the reads above): the ring is reused below
@@ -1737,7 +1737,7 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
         const int tok = min(m0 + 32 * p + r31, M - 1);
         const bf16* row = x + (int64_t)tok * H + s * 192 + hh * 8;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) hf[j] = *(const bf16x8*)(row + j * 16);
+        for (int j = 0; j < 12; ++j) hf[j] = *(const bf16x8*)(row + j * 16);   // (non-temporal here: +3.5 % -- the out-proj launch has just written these rows)
         issue_stream_prologue();       // behind the token loads in the CU's in-order memory queue: LayerNorm 1 starts on the rows while the slabs land
     }
     for (int i = threadIdx.x; i < FF; i += 512) b1s[i] = b1[i];
@@ -2867,8 +2867,8 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
     bf16x8 qf[2] = {bf16x8{}, bf16x8{}};
     if (w < nkt) {
         const int q = min(w * 32 + c31, L - 1);
-        qf[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
-        qf[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
+        qf[0] = __builtin_nontemporal_load((const bf16x8*)(base + (int64_t)q * rs + hh * 8));
+        qf[1] = __builtin_nontemporal_load((const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8));
     }
     // ---- stage K (row-major, swizzled) and V^T (transposed, key-permuted); rows [L, 32 nkt) are zero ------------------------
     for (int p0 = 0; p0 < nkt * 128; p0 += 512) {  // 2 x 256 pieces of 16 B per iteration: both loads in flight
@@ -2879,8 +2879,8 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
             kv[u2] = uint4{0u, 0u, 0u, 0u};
             vv[u2] = uint4{0u, 0u, 0u, 0u};
             if (r < L) {
-                kv[u2] = *(const uint4*)(base + (int64_t)r * rs + koff + u * 8);
-                vv[u2] = *(const uint4*)(base + (int64_t)r * rs + voff + u * 8);
+                { typedef u32 u32x4n __attribute__((ext_vector_type(4))); const u32x4n t4 = __builtin_nontemporal_load((const u32x4n*)(base + (int64_t)r * rs + koff + u * 8)); kv[u2] = uint4{t4[0], t4[1], t4[2], t4[3]}; }
+                { typedef u32 u32x4n __attribute__((ext_vector_type(4))); const u32x4n t4 = __builtin_nontemporal_load((const u32x4n*)(base + (int64_t)r * rs + voff + u * 8)); vv[u2] = uint4{t4[0], t4[1], t4[2], t4[3]}; }
             }
         }
 #pragma unroll
@@ -2909,8 +2909,8 @@ __global__ __launch_bounds__(256, 4) void k_attn3(const bf16* __restrict__ qkv, 
         bf16x8 qn[2] = {qf[0], qf[1]};
         if (qt + 4 < nkt) {                         // next tile's Q in flight while this tile computes
             const int q = min((qt + 4) * 32 + c31, L - 1);
-            qn[0] = *(const bf16x8*)(base + (int64_t)q * rs + hh * 8);
-            qn[1] = *(const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8);
+            qn[0] = __builtin_nontemporal_load((const bf16x8*)(base + (int64_t)q * rs + hh * 8));
+            qn[1] = __builtin_nontemporal_load((const bf16x8*)(base + (int64_t)q * rs + 16 + hh * 8));
         }
         // ---- pass 1: row maximum (log2 domain: log2(e) / sqrt(d) is folded into W_q).  Run-time loops over the key tiles (the
         // last one, whose accumulator starts from the padding mask, peeled): unrolled over KT hipcc kept every K fragment of
