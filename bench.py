@@ -308,8 +308,47 @@ def leg_embed(args) -> dict:
            "tokens_per_sec": round(float(lens.sum()) / (ms * 1e-3), 1), "roofline": encoder_roofline(fl / (ms * 1e-3) / 1e12, ("embed", 8192, 0))}
     if not args.no_cpu_baseline:
         leg["cpu_baseline"] = cpu_encoder_baseline(head=False)
+        leg["gpu_framework_baseline"] = gpu_framework_encoder_baseline(ids, lens)
     enc.close()
     return leg
+
+
+def gpu_framework_encoder_baseline(ids, lens, n=4096, batch=256) -> dict:
+    """SURVEY.md 8d's optional second baseline: what the reference itself would run with device='cuda' (RAGHelper_local.py:111) -- stock
+    transformers BertModel on THIS GPU through PyTorch-ROCm (hipBLASLt GEMMs, torch's attention), bf16 weights and activations, the chunks
+    sorted by length and padded per mini-batch as sentence-transformers' encode does (batch 256 instead of its default 32: in its favour),
+    mean pooling + normalisation on the device.  A reported figure beside the hand-written kernels', not a target."""
+    try:
+        from transformers import BertConfig, BertModel
+        cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_attention_heads=12, intermediate_size=1536,
+                         max_position_embeddings=512, layer_norm_eps=1e-12)
+        torch.manual_seed(0)
+        model = BertModel(cfg, add_pooling_layer=False).eval().to("cuda", dtype=torch.bfloat16)
+        n = min(n, len(lens))
+        order = np.argsort(-np.asarray(lens[:n]), kind="stable")
+        batches = []
+        for b0 in range(0, n, batch):
+            sel = order[b0:b0 + batch]
+            lm = int(lens[sel].max())
+            ii = torch.as_tensor(ids[sel, :lm].astype(np.int64)).cuda()
+            ll = torch.as_tensor(lens[sel].astype(np.int64)).cuda()
+            batches.append((ii, (torch.arange(lm, device="cuda")[None] < ll[:, None]).long()))
+
+        def one_pass():
+            with torch.no_grad():
+                for ii, mask in batches:
+                    h = model(input_ids=ii, attention_mask=mask).last_hidden_state.float()
+                    mk = mask.unsqueeze(-1).float()
+                    torch.nn.functional.normalize((h * mk).sum(1) / mk.sum(1).clamp(min=1e-9), dim=1)
+
+        ms = timed(one_pass, steps=3, warmup=2)
+        del model
+        torch.cuda.empty_cache()
+        return {"value": round(n / (ms * 1e-3), 1), "unit": "chunks/sec", "kind": "framework",
+                "sample": f"{n} of the leg's chunks, transformers {__import__('transformers').__version__} BertModel bf16 on this GPU via PyTorch-ROCm {torch.__version__}, "
+                          f"length-sorted mini-batches of {batch} padded to their longest ({ms:.1f} ms per pass)"}
+    except Exception as e:   # noqa: BLE001 - an optional figure
+        return {"value": None, "error": repr(e)[:200]}
 
 
 def leg_c1(args) -> dict:
