@@ -221,6 +221,16 @@ __global__ void k_l2_aug_queries(float* q, int dpad, int dim, int64_t n, float* 
     if (lane == 0) { qn2[r] = s; row[dim] = 1.0f; }
 }
 
+// L2 index with a screening image: nrm[r] = -2048 |x_r|^2 (the accumulator start of scan_screen_lean3_kernel's L2 form: the stored -|x|^2
+// column times 2^11, exact) and norm2[r] = |x_r|^2 for the |x|max statistic
+__global__ void k_l2_nrm(const float* __restrict__ x, int dpad, int dim, int64_t n, float* __restrict__ nrm, float* __restrict__ norm2) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float v = x[r * (int64_t)dpad + dim];
+    if (nrm) nrm[r] = 2048.0f * v;
+    norm2[r] = -v;
+}
+
 // max over rows of |x|^2 (non-negative floats order like their bit patterns)
 __global__ void k_max_norm2(const float* __restrict__ norm2, int64_t n, unsigned* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,6 +421,7 @@ struct rmu_index {
     int64_t n = 0, cap = 0, n_live = 0;
     float* x = nullptr;
     char* split = nullptr;          // fp16(64 x) image of x (screening pass), 768 B per row; nullptr = disabled
+    float* nrm = nullptr;           // RMU_METRIC_L2SQ with an image: -2048 |x|^2 per row (NaN past the last row); exists iff split does
     float xnorm_max = 0.f;          // max row norm (bounds the screening error)
     float dx_max = 0.f;             // max row norm of (x - screening image): the measured rounding error
     unsigned stat_host[2] = {0, 0}; // landing pair of update_image_stats (|x|^2 max, |dx|^2 max of the rows just added)
@@ -461,12 +472,19 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
     idx->cap = cap;
     // screening image (+50% corpus memory): 384-wide rows only; RMU_SCREEN=0 disables
     static const bool screen_on = !(rmu_env_kill("RMU_SCREEN") && atoi(rmu_env_kill("RMU_SCREEN")) == 0);
-    if (screen_on && idx->dpad == 384 && dim == 384) {
+    // (round 5) ... and the native L2 index at dim 384 (rows 768 floats apart: 384 + the -|x|^2 column, padded), with the row norms beside it
+    const bool l2 = metric == RMU_METRIC_L2SQ;
+    if (screen_on && dim == 384 && (idx->dpad == 384 || l2)) {
         if (hipMalloc((void**)&idx->split, (size_t)(cap + kSlackRows) * RMU_IMG_ROW_BYTES) != hipSuccess) {
             idx->split = nullptr;   // not fatal: exact path only
             (void)hipGetLastError();
+        } else if (l2 && hipMalloc((void**)&idx->nrm, (size_t)(cap + kSlackRows) * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(idx->split);
+            idx->split = nullptr; idx->nrm = nullptr;
         } else {
             (void)hipMemsetAsync(idx->split, 0, (size_t)(cap + kSlackRows) * RMU_IMG_ROW_BYTES, g_tls.stream);
+            if (idx->nrm) (void)hipMemsetAsync(idx->nrm, 0xFF, (size_t)(cap + kSlackRows) * sizeof(float), g_tls.stream);   // NaN: never a candidate
             (void)hipStreamSynchronize(g_tls.stream);
         }
     }
@@ -481,8 +499,10 @@ extern "C" int rmu_index_free(rmu_index_t* idx) {
         (void)hipDeviceSynchronize();
         if (idx->x) (void)hipFree(idx->x);
         if (idx->split) (void)hipFree(idx->split);
+        if (idx->nrm) (void)hipFree(idx->nrm);
         idx->x = nullptr;
         idx->split = nullptr;
+        idx->nrm = nullptr;
     }
     delete idx;
     return RMU_OK;
@@ -535,17 +555,31 @@ static int grow(rmu_index* idx, int64_t need) {
     HIP_TRY(hipStreamSynchronize(s));
     if (idx->split) {
         char* ns = nullptr;
+        float* nn = nullptr;
         const size_t rowb = RMU_IMG_ROW_BYTES;
-        if (hipMalloc((void**)&ns, (size_t)(cap + kSlackRows) * rowb) == hipSuccess) {
+        bool got = hipMalloc((void**)&ns, (size_t)(cap + kSlackRows) * rowb) == hipSuccess;
+        if (got && idx->nrm && hipMalloc((void**)&nn, (size_t)(cap + kSlackRows) * sizeof(float)) != hipSuccess) {
+            (void)hipFree(ns);
+            got = false;
+        }
+        if (got) {
             HIP_TRY(hipMemsetAsync(ns + idx->n * rowb, 0, (size_t)(cap + kSlackRows - idx->n) * rowb, s));
             if (idx->n) HIP_TRY(hipMemcpyAsync(ns, idx->split, (size_t)idx->n * rowb, hipMemcpyDeviceToDevice, s));
+            if (nn) {
+                HIP_TRY(hipMemsetAsync(nn + idx->n, 0xFF, (size_t)(cap + kSlackRows - idx->n) * sizeof(float), s));
+                if (idx->n) HIP_TRY(hipMemcpyAsync(nn, idx->nrm, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
             HIP_TRY(hipStreamSynchronize(s));
             (void)hipFree(idx->split);
+            if (idx->nrm) (void)hipFree(idx->nrm);
             idx->split = ns;
+            idx->nrm = nn;
         } else {
             (void)hipGetLastError();
             (void)hipFree(idx->split);   // no room for the screening image: exact path only from now on
+            if (idx->nrm) (void)hipFree(idx->nrm);
             idx->split = nullptr;
+            idx->nrm = nullptr;
         }
     }
     (void)hipFree(idx->x);
@@ -558,22 +592,34 @@ static int grow(rmu_index* idx, int64_t need) {
 // ENQUEUES only (two reductions into one 8-byte device pair + one 8-byte copy to idx->stat_host): the caller's own final
 // stream synchronisation covers it, then fold_image_stats() folds the pair into the index -- one host round trip per
 // rmu_index_add instead of three (the reference inserts in 1000-document calls, server/RAGHelper.py:423-434).
-static int update_image_stats(rmu_index_t* idx, const float* dst, int64_t n, hipStream_t s) {
+static int update_image_stats(rmu_index_t* idx, const float* dst, int64_t n, hipStream_t s, float* nrm_out = nullptr) {
     Buf& nb = g_tls.nrm;
     if (nb.ensure((size_t)n * sizeof(float) + 16)) return fail(RMU_E_OOM, "rmu_index_add: norm workspace");
     unsigned* mx = (unsigned*)((char*)nb.p + (size_t)n * sizeof(float));
     HIP_TRY(hipMemsetAsync(mx, 0, 2 * sizeof(unsigned), s));
-    if (idx->metric != RMU_METRIC_COSINE) {
+    if (idx->metric == RMU_METRIC_L2SQ) {      // |x|^2 is the augmented column (k_l2_aug_rows), not the norm of the augmented row
+        hipLaunchKernelGGL(k_l2_nrm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, idx->dpad, idx->dim, n, nrm_out, (float*)nb.p);
+        hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
+    } else if (idx->metric != RMU_METRIC_COSINE) {
         hipLaunchKernelGGL(k_row_norm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, const_cast<float*>(dst), idx->dpad, n, 0, (float*)nb.p);
         hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx);
     }
-    int rc = rmu_img_err_launch(dst, n, (float*)nb.p, s);
+    int rc = rmu_img_err_launch(dst, n, (float*)nb.p, s, idx->dpad);
     if (rc) return fail(rc, "rmu_index_add: image error");
     hipLaunchKernelGGL(k_max_norm2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)nb.p, n, mx + 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(idx->stat_host, mx, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     idx->stat_pending = true;
     return RMU_OK;
+}
+
+// rows [r0, r0 + n) of idx->x (final form: normalised / augmented) -> screening image (+ row norms of an L2 index) + statistics.  Enqueues only.
+static int build_image(rmu_index_t* idx, int64_t r0, int64_t n, hipStream_t s) {
+    if (!idx->split) return RMU_OK;
+    const float* rows = idx->x + r0 * (int64_t)idx->dpad;
+    int rc = rmu_split_launch(rows, idx->split + (size_t)r0 * RMU_IMG_ROW_BYTES, n, s, idx->dpad, 64.0f);
+    if (rc) return fail(rc, "rmu_index_add: split image");
+    return update_image_stats(idx, rows, n, s, idx->nrm ? idx->nrm + r0 : nullptr);
 }
 
 // after the stream that ran update_image_stats was synchronised
@@ -621,12 +667,8 @@ extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int
         hipLaunchKernelGGL(k_l2_aug_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dst, idx->dpad, idx->dim, n);
         HIP_TRY(hipGetLastError());
     }
-    if (idx->split) {
-        rc = rmu_split_launch(dst, idx->split + (size_t)idx->n * RMU_IMG_ROW_BYTES, n, s);
-        if (rc) return fail(rc, "rmu_index_add: split image");
-        rc = update_image_stats(idx, dst, n, s);
-        if (rc) return rc;
-    }
+    rc = build_image(idx, idx->n, n, s);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     fold_image_stats(idx);
     idx->alive.resize((size_t)(idx->n + n), 1);
@@ -866,8 +908,7 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
         const int64_t nr = std::min<int64_t>(chunk, h.n - r0);
         ok = fread(host.data(), rowb, (size_t)nr, f) == (size_t)nr;
         if (ok && hipMemcpy((char*)idx->x + r0 * rowb, host.data(), (size_t)nr * rowb, hipMemcpyHostToDevice) != hipSuccess) ok = false;
-        if (ok && idx->split) ok = rmu_split_launch((const float*)((const char*)idx->x + r0 * rowb), idx->split + r0 * RMU_IMG_ROW_BYTES, nr, s) == RMU_OK;
-        if (ok && idx->split) ok = update_image_stats(idx, (const float*)((const char*)idx->x + r0 * rowb), nr, s) == RMU_OK;
+        if (ok) ok = build_image(idx, r0, nr, s) == RMU_OK;
         if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
         if (ok) fold_image_stats(idx);
     }
@@ -955,7 +996,8 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
         ScanLaunch& S = lv[(size_t)l];
         S = ScanLaunch{};
         S.x = (const float*)idx->split; S.row0 = l ? bounds[(size_t)l - 1] : 0; S.n_rows = bounds[(size_t)l] - S.row0;
-        S.dpad = dpad; S.nq = (int)nb; S.k = kp;
+        S.dpad = 384; S.nq = (int)nb; S.k = kp;       // (the image's geometry; an L2 index keeps its fp32 rows 768 floats apart)
+        S.nrm = idx->nrm;
         if (rmu_screen_plan(&S) != RMU_OK) return fail(RMU_E_INVALID, "rmu_index_search: screening geometry");
         slots += S.parts;
     }
@@ -975,7 +1017,8 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
     static const int nofilter = rmu_env("RMU_SCREEN_NOFILTER") != nullptr ? 2 : 0;
     const int sflags = share | nofilter;
     HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
-    int rc = rmu_split_launch(qdev, t.qsplit.p, nb, s);
+    // (an L2 index holds its queries as (2q, 1): the image is fp16(64 q) all the same)
+    int rc = rmu_split_launch(qdev, t.qsplit.p, nb, s, dpad, idx->metric == RMU_METRIC_L2SQ ? 32.0f : 64.0f);
     if (rc) return fail(rc, "rmu_index_search: query conversion");
     u64* base = (u64*)t.partial.p;
     int cursor = 0;     // slot index: [merged keys of the ranges so far][this range's parts] ...
@@ -1014,7 +1057,8 @@ static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
     // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays for the
     // ladder's launches and merges per batch, which only pays off on a large enough corpus
     const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || min_nq_set;
-    return idx->split && idx->screen_enabled && idx->dpad == 384 && idx->dim == 384 && idx->metric != RMU_METRIC_L2SQ &&
+    const bool geom = idx->dim == 384 && (idx->metric == RMU_METRIC_L2SQ ? idx->nrm != nullptr : idx->dpad == 384);
+    return idx->split && idx->screen_enabled && geom &&
            nb >= screen_min_nq && screen_pays && k <= 32 && idx->n > 0 && idx->xnorm_max > 0.f &&
            idx->xnorm_max < 500.f;   // fp16(64*x) must not overflow
 }
@@ -1164,7 +1208,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip); queries failing the
             // sufficiency test are appended to the list fb_i (count in flag[0])
             rc = rmu_rescore_launch((const u64*)t.ckeys.p, screen_kp(k), idx->x, qdev, nb, k, idx->xnorm_max, idx->dx_max, row_base, d_s, d_r,
-                                    (int*)t.flag.p, (int64_t*)t.fb_i.p, nullptr, s);
+                                    (int*)t.flag.p, (int64_t*)t.fb_i.p, nullptr, s, dpad, l2 ? (const float*)t.qn.p : nullptr);
             if (rc) return fail(rc, "rmu_index_search: re-score launch");
             t.grid = lastg.grid; t.block = 256; t.lds = lastg.lds_bytes; t.passes += nl;
             if (lim_small > 0 || mid_n > small_n) {
@@ -1278,6 +1322,7 @@ extern "C" int rmu_index_screen_candidates(rmu_index_t* idx, const float* q_host
     hipStream_t s = t.stream;
     std::shared_lock<std::shared_mutex> lk(idx->mu);
     if (!idx->split || idx->dim != 384 || idx->n <= 0) return fail(RMU_E_INVALID, "rmu_index_screen_candidates: index has no screening image");
+    if (idx->metric == RMU_METRIC_L2SQ) return fail(RMU_E_INVALID, "rmu_index_screen_candidates: inner-product / cosine indexes only");
     const int kp = kScreenKp;
     if (t.q.ensure((size_t)nq * 384 * sizeof(float)) || t.flag.ensure((size_t)(nq + 1) * sizeof(int)) || t.fb_i.ensure((size_t)nq * sizeof(int64_t)) ||
         t.out_s.ensure((size_t)nq * kp * sizeof(float)) || t.out_r.ensure((size_t)nq * kp * sizeof(int64_t)) || t.nrm.ensure((size_t)nq * sizeof(float)))

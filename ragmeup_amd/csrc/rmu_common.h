@@ -157,6 +157,8 @@ struct ScanLaunch {
     // screening scan, K-split form only (kv == 1; scan_screen.hip): candidate slots in global memory, [parts][nq][RMU_KS_CAP] keys.  Needs no
     // initialisation (the slot counts live in registers); contents are dead once the launch has written its partials
     u64* gcand;
+    // screening scan of an RMU_METRIC_L2SQ index: -2048 |x|^2 per image row (indexed like the image: row0 is added); nullptr = inner product
+    const float* nrm;
 };
 #define RMU_KS_CAP 48     /* K' <= 40 kept candidates + 8 free slots between compactions (one key per lane in the rank: <= 64) */
 
@@ -169,14 +171,16 @@ int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u
                              hipStream_t s);
 // fp16 screening path (scan_screen.hip)
 #define RMU_IMG_ROW_BYTES 768                          /* fp16(64 x) image of a 384-d row */
-int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s);      // fp32 [n,384] -> fp16 image
+int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s, int stride = 384,
+                     float scale = 64.0f);                                             // fp32 [n, 384 of stride] -> fp16(scale x) image
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s);                             // x/q = split images, k = K'
 int rmu_screen_lds_bytes(int qg);
 int rmu_screen_plan(ScanLaunch* p);                      // geometry of one screening launch (k = K' <= 32)
-int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s);       // |x - image|^2 per row
+int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s, int stride = 384);   // |x - image|^2 per row
+// stride = floats between rows of x AND of q; qn2_l2 (RMU_METRIC_L2SQ: |q|^2 per query; x and q in the L2 index's augmented form) or null
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
                        int64_t row_base, float* out_s, int64_t* out_r, int* flagged /* [0] = count */, int64_t* flagged_list,
-                       float* eps_out /* or null */, hipStream_t s);
+                       float* eps_out /* or null */, hipStream_t s, int stride = 384, const float* qn2_l2 = nullptr);
 // shard lists [parts][nq, k]: part p's scores start at scores + p * stride_s (floats), rows at rows + p * stride_r (int64);
 // smaller_better: distances (RMU_METRIC_L2SQ) instead of similarities
 int rmu_merge_lists_launch(const float* scores, const int64_t* rows, int parts, int64_t stride_s, int64_t stride_r, int64_t nq, int k,

@@ -74,23 +74,24 @@ static_assert(ScreenCfg<1>::LDS_BYTES <= 160 * 1024 && ScreenCfg<2>::LDS_BYTES <
 
 extern __shared__ __attribute__((aligned(16))) char ssm[];
 
-// fp32 rows [n, 384] -> screening image [n, 768 B]; one thread per group of 8 k
-__global__ void k_split_rows(const float* __restrict__ src, char* __restrict__ dst, int64_t n_groups) {
+// fp32 rows [n, 384 of `stride` floats] -> screening image [n, 768 B] = fp16(scale * x); one thread per group of 8 k.  scale = 64, or 32 for the
+// L2 index's queries, which are stored doubled (rmu_api.hip: k_l2_aug_queries)
+__global__ void k_split_rows(const float* __restrict__ src, char* __restrict__ dst, int64_t n_groups, int stride, float scale) {
     const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gidx >= n_groups) return;
-    const float* s = src + gidx * 8;
+    const float* s = src + (gidx / (SD / 8)) * stride + (gidx % (SD / 8)) * 8;
     f16x8 hi;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) hi[e] = (_Float16)(s[e] * 64.0f);
+    for (int e = 0; e < 8; ++e) hi[e] = (_Float16)(s[e] * scale);
     *(f16x8*)(dst + gidx * 16) = hi;
 }
 
 // err2[r] = |x_r - h_r / 64|^2: the measured rounding error of the screening image, one wave per row
-__global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, int64_t n, float* __restrict__ err2) {
+__global__ __launch_bounds__(256) void k_img_err(const float* __restrict__ x, int64_t n, float* __restrict__ err2, int stride) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
-    const float* row = x + r * SD;
+    const float* row = x + r * stride;
     float s = 0.f;
     for (int c = lane; c < SD; c += 64) {
         const float d = row[c] - (float)(_Float16)(row[c] * 64.0f) * (1.0f / 64.0f);
@@ -1286,10 +1287,18 @@ struct Lean3Cfg {
     static constexpr int CAP = RMU_KS_CAP;
     static constexpr int RING_BYTES = NR * S_SLOT;
     static constexpr int GT_OFF = RING_BYTES;
-    static constexpr int LDS_BYTES = GT_OFF + NW * 256;
+    static constexpr int NRM_OFF = GT_OFF + NW * 256;      // L2 form: -2048 |x|^2 of the rows of the six ring tiles (32 floats per tile)
+    static constexpr int LDS_BYTES = NRM_OFF + 6 * S_RT * 4;
 };
 
-template <int EXP = 0, int NWV = 8, int NT = 0>
+// L2N = 1 (round 5): the index ranks by 2 q.x - |x|^2 (RMU_METRIC_L2SQ).  The image has no k-slot left for the norm (384 fp16 = the 24 MFMA
+// steps exactly), so it enters as the chain's C operand: a.nrm[row] = -2048 |x|^2 (fp32, built at add time from the exact scan's own
+// -|x|^2 column) initialises the accumulator of the tile's first MFMA -- acc = 4096 (q~.x~ - |x|^2 / 2), the approximate HALF score; filter,
+// thresholds, candidate keys and merges never know.  A lane's 16 accumulator rows (4h + 8i + c) are four 16-byte LDS reads, issued half a
+// tile ahead between two fragment reads (the lgkmcnt of the four steps behind them counts them in); the norms of a PAIR of tiles are one
+// 256-byte LDS-DMA by wave 0, issued two pairs ahead next to the threshold refresh (older than the pieces the pair barrier's vmcnt leaves
+// in flight, like the refresh).  +4 KiB-reads per 24 on the LDS return path; the fp16 image bytes are unchanged.
+template <int EXP = 0, int NWV = 8, int NT = 0, int L2N = 0>
 __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanLaunch a) {
     using C = Lean3Cfg<NWV>;
     constexpr bool DBG = (EXP & 4) != 0;
@@ -1402,6 +1411,26 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
         if (EXP & 2) return;
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1));
     };
+    auto frag_wait_nrm = [&](f16x8& f) {                   // the four norm reads sit between this fragment's read and the newest ones
+        if (EXP & 2) return;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1 + 4));
+    };
+    // L2 form: row norms of the ring tiles
+    const float* np = L2N ? a.nrm + a.row0 + t0 * S_RT + lane : nullptr;     // one float per lane = the 64 rows of a pair of tiles
+    const u32 nrm_ad = lds_addr(ssm + C::NRM_OFF) + (u32)h * 16u;
+    f32x4 zq[4] = {};
+    auto issue_nrm = [&](auto PI, const float* src) {      // PI = ring position of the pair's first tile
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ssm + C::NRM_OFF + decltype(PI)::value * S_RT * 4), 4, 0, 0);
+    };
+    auto read_nrm = [&](auto PI) {                         // this lane's 16 accumulator rows of the tile at ring position PI: rows 4h + 8i + (0..3)
+        constexpr int o = decltype(PI)::value * S_RT * 4;
+        f32x4 &z0 = zq[0], &z1 = zq[1], &z2 = zq[2], &z3 = zq[3];      // (asm operands alone do not capture in a generic lambda)
+        const u32 ad = nrm_ad;
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3)
+                     : "v"(ad), "n"(o), "n"(o + 32), "n"(o + 64), "n"(o + 96));
+    };
     u32 d_slow = 0, d_comp = 0, d_app = 0;
     unsigned long long d_clk_slow = 0, d_clk_bar = 0, d_clk_vm = 0, d_clk_all = DBG ? clock64() : 0;
     // keep the best K' of query lane jj's slot (sorted), raise its threshold, publish it (VMEM as inline asm: see scan_screen_ks_kernel)
@@ -1461,6 +1490,13 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
     using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
     if (ntiles > 0) {
         refresh_gthr();
+        if (L2N) {                                        // (older than every piece: complete at the first counted wait)
+            if (w == 0) {
+                issue_nrm(I0{}, np);
+                issue_nrm(I2{}, np + 2 * S_RT);
+            }
+            np += 4 * S_RT;
+        }
         {
             const char* b0 = tp - 4 * S_RT * IMGB;        // dma_off carries the in-loop look-ahead of four tiles
 #pragma unroll
@@ -1474,6 +1510,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NIW) : "memory");   // tiles 0, 1, 2 (and the thresholds)
         __builtin_amdgcn_s_barrier();
+        if (L2N && (NWV == 8 || wave_live)) read_nrm(I0{});   // (in front of the fragment prefetch: step 0's counted wait covers it)
 #pragma unroll
         for (int m = 0; m < S_PRE; ++m) {
             if (!(EXP & 2)) asm volatile("ds_read_b128 %0, %1" : "=v"(fr[m]) : "v"(ab[m]));
@@ -1508,8 +1545,13 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
                 if (NWV == 8 || wave_live) {
                 if (gs == 18 && !(a.share_thr & 2) && !(EXP & 8) && __builtin_expect(__ballot(mx > thr_s) != 0, 0))
                     slow_path(prev, lane_r0 + (int64_t)(tl - 1) * S_RT, 0xffffu);
-                frag_wait(fr[gs % S_PRE]);
-                if (gs == 0) {
+                if (L2N && gs >= 13 && gs <= 16) frag_wait_nrm(fr[gs % S_PRE]);
+                else frag_wait(fr[gs % S_PRE]);
+                if (gs == 0 && L2N) {
+                    const f32x16 z = {zq[0][0], zq[0][1], zq[0][2], zq[0][3], zq[1][0], zq[1][1], zq[1][2], zq[1][3],
+                                      zq[2][0], zq[2][1], zq[2][2], zq[2][3], zq[3][0], zq[3][1], zq[3][2], zq[3][3]};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], z, 0, 0, 0);
+                } else if (gs == 0) {
                     const f32x16 z = {};
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[gs % S_PRE], qh[gs], z, 0, 0, 0);
                 } else {
@@ -1519,9 +1561,14 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
                 if (gs >= 1 && gs <= 8 && !(EXP & 8)) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(prev[2 * gs - 2]), "v"(prev[2 * gs - 1]));
                 if (t + S_PRE < S_CS) read_frag(fr[gs % S_PRE], std::integral_constant<int, cur * S_SLOT + ((t + S_PRE) >> 2) * 128>{}, t + S_PRE);
                 else read_frag(fr[gs % S_PRE], std::integral_constant<int, nxt * S_SLOT + ((t + S_PRE - S_CS) >> 2) * 128>{}, t + S_PRE - S_CS);
+                if (L2N && gs == 12) read_nrm(std::integral_constant<int, (P + 1) % 6>{});        // the NEXT tile's norms (landed: see the kernel's header)
                 }
                 if (gs % (S_TS / C::NIW) == 1) issue_part(std::integral_constant<int, (P + 4) % 6>{}, tp, gs / (S_TS / C::NIW));   // steps 1, 9, 17 | 1, 5, .., 21
                 if (gs == 4 && P % 2 == 0) refresh_gthr();
+                if (L2N && gs == 4 && P % 2 == 0) {       // norms of the pair two pairs ahead, into the slots of the pair that has just been left
+                    if (w == 0) issue_nrm(std::integral_constant<int, (P + 4) % 6>{}, np);
+                    np += 2 * S_RT;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             };
             step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
@@ -2477,12 +2524,20 @@ __global__ __launch_bounds__(256) void scan_screen_g4_kernel(const ScanLaunch a)
 // exact fp32 re-score of the K' candidates of each query, in the exact kernel's summation order:
 // for t in 0..47, c in 0..3: acc = fma(x[8t+c], q[8t+c], acc); acc = fma(x[8t+4+c], q[8t+4+c], acc)
 // (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain; lanes < 32 hold k = 8t+c, lanes >= 32 hold k = 8t+4+c).
+// L2 (RMU_METRIC_L2SQ; rows and queries `stride` = 768 floats apart, rows carry -|x|^2 in column 384, queries are (2q, 1): rmu_api.hip): the exact
+// scan's chain runs on over the pad columns -- exact zeros except k = 384, the first term of step t = 48: S = fma(-|x|^2, 1, chain(2q, x)); the
+// reported score is max(|q|^2 - S, 0) as in the exact path's merge (topk_merge.hip).  The candidates' approximate scores are HALF scores
+// (q~.x~ - |x|^2 / 2: see scan_screen_lean3_kernel), the sufficiency test runs in those units: the image errors bound the q.x part as before,
+// the norm is the SAME stored number on both sides, and the roundings that see it -- the screening chain starts at 2048 |x|^2 instead of 0
+// (<= 408 roundings relative to |x||q| + |x|^2 / 2: 1.22e-5 |x|^2), the exact chain's last step rounds 2 q.x - |x|^2 once -- add 1.5e-5 |x|max^2.
+template <bool L2>
 __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, int kp, const float* __restrict__ x,
                                                  const float* __restrict__ q, int64_t nq, int k, float xnorm_max, float dx_max,
                                                  int64_t row_base, float* __restrict__ out_s, int64_t* __restrict__ out_r,
                                                  int* __restrict__ flagged /* [0] = number of queries that failed the test */,
                                                  int64_t* __restrict__ flagged_list /* their indices, in arrival order */,
-                                                 float* __restrict__ eps_out /* optional [nq]: EPS(q) */) {
+                                                 float* __restrict__ eps_out /* optional [nq]: EPS(q) */, int stride,
+                                                 const float* __restrict__ qn2_l2 /* L2: |q|^2 per query */) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
@@ -2490,8 +2545,8 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
     const bool valid = ck != 0ull;
     const float sa = valid ? rmu_key_score(ck) : -INFINITY;     // approximate score (sorted descending over lanes)
     const u32 row = valid ? rmu_key_row(ck) : 0u;
-    const float* qv = q + qi * SD;
-    const float* xv = x + (int64_t)row * SD;
+    const float* qv = q + qi * stride;
+    const float* xv = x + (int64_t)row * stride;
     float acc = 0.f, qn2 = 0.f, dq2 = 0.f;
     for (int t = 0; t < SD / 8; ++t) {
         const f32x4 qa = *(const f32x4*)(qv + 8 * t), qb = *(const f32x4*)(qv + 8 * t + 4);
@@ -2500,20 +2555,23 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
         for (int c = 0; c < 4; ++c) {
             acc = fmaf(xa[c], qa[c], acc);
             acc = fmaf(xb[c], qb[c], acc);
-            qn2 = fmaf(qa[c], qa[c], qn2);
-            qn2 = fmaf(qb[c], qb[c], qn2);
-            const float da = qa[c] - (float)(_Float16)(qa[c] * 64.0f) * (1.0f / 64.0f);
-            const float db = qb[c] - (float)(_Float16)(qb[c] * 64.0f) * (1.0f / 64.0f);
+            const float ua = L2 ? 0.5f * qa[c] : qa[c], ub = L2 ? 0.5f * qb[c] : qb[c];      // the query itself (the L2 index stores 2q)
+            qn2 = fmaf(ua, ua, qn2);
+            qn2 = fmaf(ub, ub, qn2);
+            const float da = ua - (float)(_Float16)(ua * 64.0f) * (1.0f / 64.0f);
+            const float db = ub - (float)(_Float16)(ub * 64.0f) * (1.0f / 64.0f);
             dq2 = fmaf(da, da, dq2);
             dq2 = fmaf(db, db, dq2);
         }
     }
+    if (L2) acc = fmaf(xv[SD], qv[SD], acc);
     // sufficiency test on the approximate scores
     const int nvalid = __builtin_popcountll(__ballot(valid));
     const float tau = __shfl(sa, k - 1);                        // k-th best approximate score (or -inf)
     const float smin = __shfl(sa, kp - 1);                      // worst kept candidate
     const float qn = sqrtf(qn2) * 1.0001f, dq = sqrtf(dq2) * 1.0001f;
-    const float eps = dx_max * qn + xnorm_max * dq + dx_max * dq + 5.0e-5f * xnorm_max * qn;   // see the header
+    const float eps = dx_max * qn + xnorm_max * dq + dx_max * dq + 5.0e-5f * xnorm_max * qn +   // see the header
+                      (L2 ? 1.5e-5f * xnorm_max * xnorm_max : 0.f);
     const bool complete = nvalid < kp;                           // every live row was a candidate
     // eps must be finite: a query with |q_i| >= ~1000 overflows fp16(64 q), its approximate scores are inf/NaN and rows
     // scoring NaN are never appended (so even `complete` proves nothing) -- such a query always goes to the exact scan
@@ -2528,21 +2586,22 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
     rank_keys<1>(key, (u32)(kp < 64 ? kp : 64), rank);
     // keys of invalid lanes are 0 and rank below every valid one
     if (valid && rank[0] < (u32)k) {
-        out_s[qi * k + rank[0]] = acc + 0.0f;
+        out_s[qi * k + rank[0]] = L2 ? fmaxf(qn2_l2[qi] - (acc + 0.0f), 0.f) : acc + 0.0f;
         out_r[qi * k + rank[0]] = (int64_t)row + row_base;
     }
     if (lane < k && lane >= nvalid) {
-        out_s[qi * k + lane] = -INFINITY;
+        out_s[qi * k + lane] = L2 ? INFINITY : -INFINITY;
         out_r[qi * k + lane] = -1;
     }
 }
 
 }  // namespace
 
-int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s) {
+int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s, int stride, float scale) {
     const int64_t groups = n_rows * (SD / 8);
     if (groups <= 0) return RMU_OK;
-    hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, (char*)dst, groups);
+    if (stride < SD) return RMU_E_INVALID;
+    hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, (char*)dst, groups, stride, scale);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
@@ -2669,37 +2728,27 @@ static int screen_launch_g4(const ScanLaunch* p, hipStream_t s) {
 }
 #endif
 
+template <int EXP, int NWV, int NT, int L2N>
+static int screen_launch_lean3(const ScanLaunch* p, hipStream_t s) {
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<EXP, NWV, NT, L2N>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, Lean3Cfg<NWV>::LDS_BYTES);
+    if (attr_rc != hipSuccess) return RMU_E_HIP;
+    hipLaunchKernelGGL((scan_screen_lean3_kernel<EXP, NWV, NT, L2N>), dim3(p->grid), dim3(64 * NWV), Lean3Cfg<NWV>::LDS_BYTES, s, *p);
+    return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+}
+
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     if (p->kv == 4) {
         if (!p->gcand) return RMU_E_INVALID;
+        const bool l2 = p->nrm != nullptr;                // RMU_METRIC_L2SQ: the row norms enter the chain as its C operand
         if (p->wq == 4) {                                 // one query tile
-            if (p->nt) {
-                static const hipError_t rc4 = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                  Lean3Cfg<4>::LDS_BYTES);
-                if (rc4 != hipSuccess) return RMU_E_HIP;
-                hipLaunchKernelGGL((scan_screen_lean3_kernel<0, 4, 1>), dim3(p->grid), dim3(256), Lean3Cfg<4>::LDS_BYTES, s, *p);
-            } else {
-                static const hipError_t rc4 = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0, 4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                  Lean3Cfg<4>::LDS_BYTES);
-                if (rc4 != hipSuccess) return RMU_E_HIP;
-                hipLaunchKernelGGL((scan_screen_lean3_kernel<0, 4, 0>), dim3(p->grid), dim3(256), Lean3Cfg<4>::LDS_BYTES, s, *p);
-            }
-            return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+            if (p->nt) return l2 ? screen_launch_lean3<0, 4, 1, 1>(p, s) : screen_launch_lean3<0, 4, 1, 0>(p, s);
+            return l2 ? screen_launch_lean3<0, 4, 0, 1>(p, s) : screen_launch_lean3<0, 4, 0, 0>(p, s);
         }
-        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                              Lean3Cfg<8>::LDS_BYTES);
-        if (attr_rc != hipSuccess) return RMU_E_HIP;
 #ifdef RMU_DEBUG_KERNELS
-        if (p->dbg) {
-            static const hipError_t attr_d = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                 Lean3Cfg<8>::LDS_BYTES);
-            if (attr_d != hipSuccess) return RMU_E_HIP;
-            hipLaunchKernelGGL((scan_screen_lean3_kernel<4>), dim3(p->grid), dim3(512), Lean3Cfg<8>::LDS_BYTES, s, *p);
-            return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
-        }
+        if (p->dbg && !l2) return screen_launch_lean3<4, 8, 0, 0>(p, s);
 #endif
-        hipLaunchKernelGGL((scan_screen_lean3_kernel<0>), dim3(p->grid), dim3(512), Lean3Cfg<8>::LDS_BYTES, s, *p);
-        return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
+        return l2 ? screen_launch_lean3<0, 8, 0, 1>(p, s) : screen_launch_lean3<0, 8, 0, 0>(p, s);
     }
 #ifndef RMU_DEBUG_KERNELS
     return RMU_E_INVALID;                      // rmu_screen_plan hands the product library kv == 4 only
@@ -2802,16 +2851,22 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
 #endif
 }
 
-int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s) {
+int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t s, int stride) {
     if (n_rows <= 0) return RMU_OK;
-    hipLaunchKernelGGL(k_img_err, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, x, n_rows, err2);
+    if (stride < SD) return RMU_E_INVALID;
+    hipLaunchKernelGGL(k_img_err, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, x, n_rows, err2, stride);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
-                       int64_t row_base, float* out_s, int64_t* out_r, int* flagged, int64_t* flagged_list, float* eps_out, hipStream_t s) {
-    if (kp < k || kp > 64) return RMU_E_INVALID;
-    hipLaunchKernelGGL(k_rescore, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
-                       out_s, out_r, flagged, flagged_list, eps_out);
+                       int64_t row_base, float* out_s, int64_t* out_r, int* flagged, int64_t* flagged_list, float* eps_out, hipStream_t s,
+                       int stride, const float* qn2_l2) {
+    if (kp < k || kp > 64 || stride < SD || (qn2_l2 && stride < SD + 1)) return RMU_E_INVALID;
+    if (qn2_l2)
+        hipLaunchKernelGGL(k_rescore<true>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
+                           out_s, out_r, flagged, flagged_list, eps_out, stride, qn2_l2);
+    else
+        hipLaunchKernelGGL(k_rescore<false>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
+                           out_s, out_r, flagged, flagged_list, eps_out, stride, qn2_l2);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }

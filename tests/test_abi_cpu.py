@@ -93,7 +93,8 @@ def test_the_library_reads_tuning_switches_only_behind_the_master_switch():
 def test_the_product_library_carries_only_the_kernels_it_takes():
     """the superseded forms of the screening kernel (scan_screen_kernel, scan_screen_lean_kernel,
     scan_screen_lean2_kernel, the K-split / 128-queries-per-wave experiments) and the round-1/2 encoder kernels are instantiated in debug
-    builds only; the product library's symbol table names scan_screen_lean3_kernel (three instantiations) and nothing else of that family."""
+    builds only; the product library's symbol table names scan_screen_lean3_kernel (three geometries, each in its inner-product and its
+    L2 form -- round 5) and nothing else of that family."""
     import re
     import shutil
     import subprocess
@@ -102,7 +103,7 @@ def test_the_product_library_carries_only_the_kernels_it_takes():
     out = subprocess.run([nm, "-C", _native.SO_PATH], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     screen = sorted(set(re.findall(r"scan_screen\w*kernel<[^>]*>", out.stdout)))
-    assert screen == ["scan_screen_lean3_kernel<0, 4, 0>", "scan_screen_lean3_kernel<0, 4, 1>", "scan_screen_lean3_kernel<0, 8, 0>"], screen
+    assert screen == [f"scan_screen_lean3_kernel<0, {g}, {l2}>" for g in ("4, 0", "4, 1", "8, 0") for l2 in (0, 1)], screen
     for gone in ("k_ffn_fused", "k_attention<", "k_attn4", "k_gemm_mid"):
         assert gone not in out.stdout, gone
 

@@ -715,6 +715,75 @@ def test_l2_metric_on_unnormalised_rows(rmu, d, nq, k):
     idx.close(); ip.close()
 
 
+@pytest.mark.parametrize("n,nq,k", [(60_000, 200, 10), (60_000, 1024, 24), (60_000, 7, 32), (41_003, 130, 1), (300_000, 384, 10), (262_144 + 17, 129, 27)])
+def test_l2_metric_on_the_screening_path(rmu, n, nq, k, tmp_path):
+    """(round 5) The native L2 index at dim 384 screens like the inner-product index: the fp16 image scores q.x, the row's -|x|^2 / 2 starts
+    the MFMA chain as its C operand (scan_screen_lean3_kernel<.., L2N = 1>), the fp32 re-score repeats the exact L2 scan's chain.  Raw vectors
+    with norms 0.2 .. 12 (the ranking differs from the inner product's); distances and ids BIT-IDENTICAL to the exact L2 scan; ids equal
+    to the fp64 oracle's under the tie rule; tombstones, growth in pieces, save / load (the image and the norms are rebuilt)."""
+    from ragmeup_amd import _native as N
+    rng = np.random.default_rng(500 + k)
+    x = (rng.standard_normal((n, 384)) * rng.uniform(0.02, 0.6, (n, 1))).astype(np.float32)
+    src = rng.permutation(n)[:nq]
+    q = (x[src] + 0.002 * rng.standard_normal((nq, 384))).astype(np.float32)
+    idx = rmu.FlatIndex(384, metric=N.METRIC_L2SQ, capacity_hint=64)
+    idx.set_screen_min_batch(1)
+    for lo in range(0, n, 25_000):
+        idx.add(x[lo:lo + 25_000])
+    dist, r = idx.search(q, k)
+    assert idx.last_screened() != 0, "expected the screening path"
+    if n >= 262_144:
+        assert idx.last_geometry()["launches"] >= 3, "expected a multi-launch ladder"
+    assert (np.diff(dist, axis=1) >= 0).all() and (dist >= 0).all()
+    assert (r[:, 0] == src).all()
+    idx.set_screening(False)
+    d2, r2 = idx.search(q, k)
+    assert idx.last_screened() == 0
+    assert np.array_equal(r2, r) and np.array_equal(d2, dist)                      # bit-identical to the exact L2 scan
+    idx.set_screening(True)
+    sub = slice(0, 64)
+    os_, or_ = O.flat_search(q[sub], x, k + 4, metric=O.METRIC_L2SQ)
+    scale = float(np.abs(os_).max())
+    assert_topk_parity(-dist[sub], r[sub], os_, or_, score_tol=2e-6 * scale + 1e-4, tie_tol=1e-6 * scale)
+    ip = rmu.FlatIndex(384)
+    ip.add(x)
+    assert (ip.search(q, max(k, 10))[1][:, :k] != r).any()                          # not the inner product's ranking
+    ip.close()
+    dead = np.unique(r[:, 0])
+    idx.remove_rows(dead)
+    d3, r3 = idx.search(q, k)
+    assert idx.last_screened() != 0 and not np.isin(r3, dead).any()
+    idx.set_screening(False)
+    d4, r4 = idx.search(q, k)
+    assert np.array_equal(r4, r3) and np.array_equal(d4, d3)
+    path = str(tmp_path / "l2s.rmu")
+    idx.save(path)
+    back = rmu.FlatIndex.load(path)
+    back.set_screen_min_batch(1)
+    d5, r5 = back.search(q, k)
+    assert back.last_screened() != 0 and np.array_equal(r5, r3) and np.array_equal(d5, d3)
+    idx.close(); back.close()
+
+
+def test_l2_screening_falls_back_on_dense_ties(rmu):
+    """41 copies of one row: the query next to it fails the sufficiency test and is answered by the exact L2 scan -- ascending row ids among
+    the ties, distances as the exact path reports them; the other queries stay on the screened path."""
+    from ragmeup_amd import _native as N
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((20_000, 384)) * rng.uniform(0.02, 0.3, (20_000, 1))).astype(np.float32)
+    xd = np.concatenate([x, np.repeat(x[77:78], 40, axis=0)])
+    q = np.concatenate([x[77:78], (x[rng.permutation(20_000)[:199]] + 0.01 * rng.standard_normal((199, 384))).astype(np.float32)])
+    idx = rmu.FlatIndex(384, metric=N.METRIC_L2SQ)
+    idx.add(xd)
+    d, r = idx.search(q, 10)
+    assert -8 <= idx.last_screened() <= -1            # the tied query for certain; short rows near the origin may flag a neighbour or two
+    assert list(r[0]) == [77] + list(range(20_000, 20_009))
+    os_, or_ = O.flat_search(q, xd, 14, metric=O.METRIC_L2SQ)
+    scale = float(np.abs(os_).max())
+    assert_topk_parity(-d, r, os_, or_, score_tol=2e-6 * scale + 1e-4, tie_tol=1e-6 * scale)
+    idx.close()
+
+
 def test_l2_metric_save_load_merge_and_limits(rmu, tmp_path):
     from ragmeup_amd import _native as N
     from ragmeup_amd.index import topk_merge
