@@ -36,7 +36,8 @@ extern "C" {
 #define RMU_METRIC_IP 0     /* larger = better */
 #define RMU_METRIC_COSINE 1 /* rows are stored L2-normalised, queries normalised per call */
 #define RMU_METRIC_L2SQ 2   /* squared L2 distance on the stored (un-normalised) rows, smaller = better (Milvus "L2");
-                             * dim <= 767 (rows carry -|x|^2 in one pad column: 384-d rows are stored 768 wide) */
+                             * dim <= 767 (rows carry -|x|^2 in one pad column: 384-d rows are stored 768 wide; at dim 384 the index also keeps the
+                             * fp16 screening image and one fp32 norm per row) */
 
 /* flags for rmu_index_search / rmu_topk_merge */
 #define RMU_F_Q_DEVICE 1u   /* query pointer is a device address */
@@ -123,7 +124,7 @@ int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch
 int rmu_index_save(rmu_index_t* idx, const char* path);
 int rmu_index_load(rmu_index_t** out, const char* path);
 
-/* Exact top-k of every query against all live rows (dim 384, k <= 32: fp16 screening + exact fp32 re-score under a
+/* Exact top-k of every query against all live rows (dim 384, k <= 32, any metric: fp16 screening + exact fp32 re-score under a
  * per-query sufficiency test; otherwise, and for every query that fails the test, the exact fp32 fused scan -- the
  * returned ids and scores are those of the exact scan either way; the failing queries are re-run by launches that are
  * predicated on the device, so the call never waits on the host for a decision and, given a caller stream with device

@@ -781,7 +781,7 @@ def test_l2_screening_falls_back_on_dense_ties(rmu):
     os_, or_ = O.flat_search(q, xd, 14, metric=O.METRIC_L2SQ)
     # |q|^2 - (2 q.x - |x|^2) cancels at a duplicate: the fp32 chain's error scales with |q||x| (up to 35 here), not with the distance
     scale = float((q.astype(np.float64) ** 2).sum(1).max())
-    assert_topk_parity(-d, r, os_, or_, score_tol=5e-5 * scale + 1e-4, tie_tol=2e-6 * scale)
+    assert_topk_parity(-d, r, os_, or_, score_tol=2e-4 * scale, tie_tol=2e-6 * scale)      # (384 roundings of 2^-24 |q||x| each way)
     idx.set_screening(False)
     d2, r2 = idx.search(q, 10)
     assert np.array_equal(r2, r) and np.array_equal(d2, d)
