@@ -15,7 +15,7 @@ launch durations (roofline) are measured afterwards, on the same inputs, with hi
 At N = 1 the same run also reports, under "secondary", every other BASELINE.json configuration (C1 on the GPU path, C2, C3, C5) with its own roofline and
 CPU figure: the exact fp32 scan (API switch), the HBM-bound batch sizes 1 / 16 / 32 / 128 (the best of 16 / 32 above 10k queries/sec is
 repeated as `roofline.north_star`, on step and on kernel time), the EMULATED 8-way shard step (`emu8`, `roofline.emulated_shard_8`), config 2
-(1M rows), config 3 (chunk embedding) and config 5 (dense top-100 -> cross-encoder rerank -> top-10), config 1 on the GPU path with its
+(1M rows; `l2`: the same rows and queries on the native squared-L2 index, screened since round 5), config 3 (chunk embedding) and config 5 (dense top-100 -> cross-encoder rerank -> top-10), config 1 on the GPU path with its
 TEXT-IN recall@10 against transformers fp32 (`recall_at_10_text_in`), and the CPU baselines of config 1 timed on this box's host cores
 (count stated).  Inputs are generated on the device and are resident in HBM before any timed region.
 The oracle is used only for the cpu_baseline legs and the recall check (never inside a timed region).
@@ -901,7 +901,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b16,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank")
+    ap.add_argument("--legs", default="all", help="secondary legs at N=1: all | none | comma list of exact,b1,b16,b32,b128,emu8,c1,mmr,chat,c2,l2,embed,index,rerank")
     ap.add_argument("--index-texts", type=int, default=1_000_000, help="texts pushed through add_documents by the `index` leg (BASELINE.json configs[2]: 1M chunks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-identity-check", action="store_true",
@@ -971,7 +971,7 @@ def main(argv=None, hooks=None):
     if world > 1:
         dist.broadcast(q, 0)
         dist.broadcast(planted, 0)
-    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b16,b32,b128,emu8,c1,mmr,chat,c2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
+    legs = set() if (args.legs == "none" or world > 1) else set("exact,b1,b16,b32,b128,emu8,c1,mmr,chat,c2,l2,embed,index,rerank".split(",") if args.legs == "all" else args.legs.split(","))
     sample_host = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sample_host = shard[:min(n_local, 2_000_000)].cpu().numpy()
@@ -1150,6 +1150,22 @@ def main(argv=None, hooks=None):
         q2 = x1m[:B] + 0.1 * torch.randn((B, D), generator=gq, dtype=torch.float32, device=device)
         q2 /= q2.norm(dim=1, keepdim=True)
         secondary.append(scan_leg("C2 1M x 384, batch 1024 (BASELINE.json configs[1])", i2, q2.contiguous(), x1m.shape[0], 20))
+        if "l2" in legs:
+            # the same rows and queries on the NATIVE squared-L2 index (Milvus' default metric_type, RAGHelper.py:388-394): screened like the
+            # inner-product index since round 5 (the row norm enters the fp16 MFMA chain as its C operand); on unit-norm rows both metrics
+            # rank alike, so the ids must agree with the inner-product index's and |q - x|^2 with 2 - 2 q.x
+            ip_s, ip_r = i2.search(q2, K)
+            l2i = FlatIndex(D, _native.METRIC_L2SQ, capacity_hint=x1m.shape[0], device=local_rank)
+            l2i.add(x1m)
+            leg2 = scan_leg("native squared-L2 index (metric_type=\"L2\") on C2's rows and queries, batch 1024", l2i, q2.contiguous(), x1m.shape[0], 20)
+            leg2["config"]["workload"] = leg2["config"]["workload"].replace("inner product", "squared L2 distance")
+            d2, r2 = l2i.search(q2, K)
+            leg2["vs_inner_product_step"] = round(leg2["ms_per_step"] / secondary[-1]["ms_per_step"], 3)
+            leg2["ids_equal_to_inner_product_index"] = round(float((r2 == ip_r).float().mean()), 5)
+            leg2["max_abs_dist_minus_2_minus_2ip"] = float((d2 - (2.0 - 2.0 * ip_s)).abs().max())
+            leg2["screened"] = l2i.last_screened()
+            secondary.append(leg2)
+            l2i.close()
         i2.close()
 
     # ---- CPU baselines + recall on a bounded sample ------------------------------------------------------
