@@ -105,7 +105,8 @@ struct MergeOut {
     float* scores;        // [nq, k] final scores, or null
     int64_t* rows;        // [nq, k] final rows (+ row_base)
     int64_t row_base;
-    int l2_out;           // scores = max(qnorm2[q] - s, 0), smaller = better (RMU_METRIC_L2SQ)
+    int l2_out;           // scores = max(qnorm2[qo] - s, 0), smaller = better (RMU_METRIC_L2SQ); qnorm2 is indexed like the OUTPUT rows
+                          // (the batch's queries: a conditional re-run of the flagged queries scatters into them)
     const float* qnorm2;
     const int64_t* scatter;   // optional: query i writes output row scatter[i] (patching re-run queries into the batch)
 };
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(1024) void merge_wg_kernel(const u64* __restrict__ 
                 r = -1;
             } else {
                 sc = rmu_key_score(key);
-                if (o.l2_out) sc = fmaxf(o.qnorm2[q] - sc, 0.f);
+                if (o.l2_out) sc = fmaxf(o.qnorm2[qo] - sc, 0.f);
                 r = (int64_t)rmu_key_row(key) + o.row_base;
             }
             o.scores[qo * k + e] = sc;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void merge_select_kernel(const u64* __restri
                 r = -1;
             } else {
                 sc = rmu_key_score(key);
-                if (o.l2_out) sc = fmaxf(o.qnorm2[q] - sc, 0.f);
+                if (o.l2_out) sc = fmaxf(o.qnorm2[qo] - sc, 0.f);
                 r = (int64_t)rmu_key_row(key) + o.row_base;
             }
             o.scores[qo * k + e] = sc;
