@@ -531,35 +531,58 @@ class MI355XVectorStore(VectorStore):
     # ---- insert (RAGHelper.py:431, :525) ------------------------------------------------------------------
     def add_texts(self, texts: Iterable[str], metadatas: Optional[list[dict]] = None, ids: Optional[list[str]] = None,
                   **kw) -> list[str]:
-        texts = list(texts)
+        return self._add(list(texts), lambda: metadatas, ids)
+
+    def _add(self, texts: list, metas_fn, ids) -> list[str]:
         if not texts:
             return []
-        metadatas = metadatas or [{} for _ in texts]
-        if ids is None:
-            import uuid
-            ids = [str(uuid.uuid4()) for _ in texts]
-        ids = [str(i) for i in ids]
-        if len(ids) != len(texts) or len(metadatas) != len(texts):
+        if ids is not None and len(ids) != len(texts):
             raise ValueError("texts, metadatas and ids must have equal lengths")
-        # upsert semantics of the replaced stores: one row per pk -- inside a batch the LAST occurrence wins
-        last = {pk: i for i, pk in enumerate(ids)}
-        if len(last) == len(ids):                    # the usual case (md5 ids of distinct chunks): nothing to drop
-            keep = range(len(ids))
-            sel_texts, sel_ids = texts, ids
-        else:
-            keep = sorted(last.values())
-            sel_texts, sel_ids = [texts[i] for i in keep], [ids[i] for i in keep]
+        # The indexing path's one big call (RAGHelper.py:423-434 with everything in one batch; BASELINE.json configs[2]): the embedding of ALL
+        # texts starts before any Python bookkeeping -- metadata lists, str(ids), the duplicate-id check, the record copies, the pk map: 0.7 s
+        # per 1M documents that used to sit serially in front of and behind a 2.7 s forward (tokenizer and encoder run in librmu.so with the
+        # GIL released).  Ids repeated inside the batch (rare: md5 ids of distinct chunks) drop their earlier rows from the result afterwards.
+        early = pool = None
+        emb = self._embeddings
+        if len(texts) > max(4096, int(getattr(emb, "pipeline_block", 0) or 0)):
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmu-embed")
+            early = pool.submit(self._embed_docs_for_index, texts)
         try:
-            return self._add_texts_body(texts, metadatas, ids, keep, sel_texts, sel_ids)
+            metadatas = metas_fn() or [{} for _ in texts]
+            if ids is None:
+                import uuid
+                ids = [str(uuid.uuid4()) for _ in texts]
+            ids = [str(i) for i in ids]
+            if len(ids) != len(texts) or len(metadatas) != len(texts):
+                raise ValueError("texts, metadatas and ids must have equal lengths")
+            # upsert semantics of the replaced stores: one row per pk -- inside a batch the LAST occurrence wins
+            if len(set(ids)) == len(ids):                # the usual case (md5 ids of distinct chunks): nothing to drop
+                keep = range(len(ids))
+                sel_texts, sel_ids = texts, ids
+            else:
+                keep = sorted({pk: i for i, pk in enumerate(ids)}.values())
+                sel_texts, sel_ids = [texts[i] for i in keep], [ids[i] for i in keep]
+            return self._add_texts_body(texts, metadatas, ids, keep, sel_texts, sel_ids, early)
         finally:
+            if pool is not None:
+                pool.shutdown(wait=True)                 # (a failed validation above still waits for the forward it started)
             self._last_add_end = time.monotonic()
 
-    def _add_texts_body(self, texts, metadatas, ids, keep, sel_texts, sel_ids) -> list[str]:
-        if self._add_pipelined(sel_texts, sel_ids, lambda: [dict(metadatas[i]) for i in keep]):
+    def _add_texts_body(self, texts, metadatas, ids, keep, sel_texts, sel_ids, early=None) -> list[str]:
+        new_map = None
+        if early is not None:                            # the forward of ALL texts is already running (see _add)
+            sel_metas = [dict(metadatas[i]) for i in keep]
+            n0_guess = len(self._texts)                  # (read without the lock: only used if it still holds under it)
+            new_map = dict(zip(sel_ids, range(n0_guess, n0_guess + len(sel_ids))))
+            vecs = early.result()
+            if len(sel_ids) != len(texts):
+                vecs = vecs[list(keep)]                  # ids repeated inside the batch: the last occurrence's row stays
+        elif self._add_pipelined(sel_texts, sel_ids, lambda: [dict(metadatas[i]) for i in keep]):
             return list(ids)
         # The host records are prepared WHILE the GPU embeds (both the tokenizer and the encoder run in librmu.so with the GIL
         # released): on the indexing path (one big call) the Python bookkeeping would otherwise sit serially behind every embedding.
-        if len(sel_texts) >= 4096:
+        elif len(sel_texts) >= 4096:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=1) as pool:
                 fut = pool.submit(self._embed_docs_for_index, sel_texts)
@@ -599,14 +622,20 @@ class MI355XVectorStore(VectorStore):
                 self._index.remove_rows(stale)
                 for r in stale:
                     self._alive[r] = False
-            old_rows.update(zip(sel_ids, range(n0, n0 + len(sel_ids))))
+            if new_map is not None and n0 == n0_guess:   # built while the GPU embedded
+                if old_rows:
+                    old_rows.update(new_map)
+                else:
+                    self._pk_to_row = new_map
+            else:
+                old_rows.update(zip(sel_ids, range(n0, n0 + len(sel_ids))))
             self._dirty = True
             if self.auto_persist is True:
                 self.persist()
         return list(ids)
 
     def add_documents(self, documents: list[Document], ids: Optional[list[str]] = None, **kw) -> list[str]:
-        return self.add_texts([d.page_content for d in documents], [d.metadata for d in documents], ids=ids, **kw)
+        return self._add([d.page_content for d in documents], lambda: [d.metadata for d in documents], ids)
 
     # ---- delete (server.py:373-377) -----------------------------------------------------------------------
     _EXPR = re.compile(r"""^\s*(\w+)\s*==\s*(['"])(.*)\2\s*$""")

@@ -285,6 +285,57 @@ def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, capsys)
         MI355XVectorStore._collections.clear()
 
 
+class CountingEmbeddings:
+    """Cheap deterministic vectors; records which thread embedded and how many texts each call saw."""
+
+    def __init__(self, fail=False):
+        self.calls, self.fail = [], fail
+
+    def embed_documents(self, texts):
+        self.calls.append((threading.current_thread().name, len(texts)))
+        if self.fail:
+            raise RuntimeError("encoder lost")
+        v = np.zeros((len(texts), 384), np.float32)
+        for i, t in enumerate(texts):
+            v[i, hash(t) % 384] = 1.0
+        return v
+
+    def embed_query(self, t):
+        return self.embed_documents([t])[0]
+
+
+def test_one_big_call_embeds_before_the_bookkeeping_and_keeps_the_upsert_rules(tmp_path):
+    """(round 5) More than 4096 texts in ONE call -- the indexing path -- start the embedding of ALL texts on a worker thread before ids,
+    metadata and the pk map are touched.  Same results as the serial path: ids repeated inside the batch keep the LAST occurrence's text
+    and vector; a length mismatch raises ValueError and leaves the store empty (the forward it started is waited for); a failing embedding
+    raises and leaves nothing behind; a second big call upserts the first one's ids."""
+    MI355XVectorStore._collections.clear()
+    emb = CountingEmbeddings()
+    st = FakeStore.from_documents([], emb, drop_old=True, connection_args={"uri": str(tmp_path / "d.db")}, collection_name="big")
+    n = 5000
+    docs = [Document(page_content=f"text {i}", metadata={"source": f"s{i // 50}"}) for i in range(n)]
+    ids = [f"id{i}" for i in range(n)]
+    ids[10] = ids[4000]                                   # the same pk twice: row 4000's text wins
+    got = st.add_documents(docs, ids=ids)
+    assert got == ids and len(st) == n - 1 and len(st._index) == n - 1
+    assert emb.calls == [(emb.calls[0][0], n)] and emb.calls[0][0].startswith("rmu-embed")      # everything, once, on the worker
+    r = st._pk_to_row["id4000"]
+    assert st._texts[r] == "text 4000" and st._index.x[r, hash("text 4000") % 384] == 1.0
+    assert "text 10" not in st._texts and st._pk_to_row == {pk: i for i, pk in enumerate(st._pks)}
+    with pytest.raises(ValueError):
+        st.add_texts([f"t{i}" for i in range(4100)], metadatas=[{}] * 3)
+    assert len(st) == n - 1 and len(emb.calls) == 2       # the forward had started; nothing of it was kept
+    # upsert by a second big call: the old rows die, the map follows
+    st.add_texts([f"new {i}" for i in range(4200)], ids=[f"id{i}" for i in range(4200)])
+    assert len(st) == n and st._texts[st._pk_to_row["id7"]] == "new 7" and st._texts[st._pk_to_row["id4999"]] == "text 4999"      # (id10 is new)
+    assert sum(st._alive) == n and len(st._index) == (n - 1) + 4200 and st._index.alive.sum() == n
+    bad = FakeStore.from_documents([], CountingEmbeddings(fail=True), drop_old=True, connection_args={"uri": str(tmp_path / "e.db")}, collection_name="bad")
+    with pytest.raises(RuntimeError, match="encoder lost"):
+        bad.add_texts([f"t{i}" for i in range(4100)])
+    assert len(bad) == 0 and not bad._texts and not bad._pk_to_row
+    MI355XVectorStore._collections.clear()
+
+
 def test_add_texts_upsert_duplicates_and_failed_add(store):
     """duplicate ids inside one batch leave ONE live row (the last wins); a failing index.add loses nothing and
     leaves host records and index in step; host records exist before the rows become searchable."""
