@@ -497,7 +497,7 @@ def leg_index(args) -> dict:
     enc = BertEncoder(bert_weights(0, False), layers=6)
     tok = WordPieceTokenizer(vp)
     emb = MI355XEmbeddings(encoder=enc, tokenizer=tok, max_seq_length=256)
-    # tokenizer alone (host threads = hardware concurrency)
+    # tokenizer alone (its thread pool: min(hardware threads, 64))
     t0 = time.perf_counter()
     tid, _, tlen = tok.encode(texts, None, 256)
     tok_s = time.perf_counter() - t0
@@ -549,7 +549,7 @@ def leg_index(args) -> dict:
                                                         "(ids, records, row numbers fixed); up to 8 GPU halves (forward + append) queue behind it and the worker runs whatever is queued as ONE forward -- every reader / "
                                                         "writer of the index waits for them first; flush() ends the loop"},
            "encoder_only": {"chunks_per_sec": round(n / enc_s, 1), "seconds": round(enc_s, 3), "note": "encode_ids on pre-tokenised, device-resident 8192-chunk batches of the same texts"},
-           "tokenizer_only": {"texts_per_sec": round(n / tok_s, 1), "seconds": round(tok_s, 3), "threads": os.cpu_count(), "note": "rmu_tok_encode (host C++), all hardware threads"},
+           "tokenizer_only": {"texts_per_sec": round(n / tok_s, 1), "seconds": round(tok_s, 3), "threads": min(os.cpu_count() or 1, 64), "note": "rmu_tok_encode (host C++), its pool of min(hardware threads, 64)"},
            "end_to_end_over_encoder_only": round(enc_s / one_s, 3),
            "roofline": encoder_roofline(fl / one_s / 1e12)}
     if not args.no_cpu_baseline:

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/rmu.h"
+#include "rmu_common.h"
 #include "wordpiece_tables.h"
 
 extern "C" void rmu_set_error_(const char* msg);
@@ -357,7 +358,10 @@ class TokPool {
             static bool hooked = false;
             if (!hooked) { pthread_atfork(nullptr, nullptr, [] { slot().store(nullptr); }); hooked = true; }   // threads do not survive fork
             const int hw = (int)std::thread::hardware_concurrency();
-            p = new TokPool(std::max(0, std::min(hw, 256) - 1));
+            // 64 threads at most (round 5): the greedy longest-match loop is memory-latency bound -- 32 threads tokenise 1M texts no slower than
+            // 256 do -- and a pool as wide as the machine starves the thread that feeds the GPU while the next block is tokenised (the
+            // vector store's insert pipeline: 0.83-0.85 of the encoder-only rate with 255 helpers, 0.89 with 63; tools/idx_ab.sh)
+            p = new TokPool(std::max(0, std::min(hw, 64) - 1));
             slot().store(p, std::memory_order_release);
         }
         return *p;
@@ -367,7 +371,8 @@ class TokPool {
         std::shared_ptr<Job> j;
         try { j = std::make_shared<Job>(); j->fn = fn; } catch (...) { return false; }
         j->n = n; j->grain = grain;
-        const int helpers = std::min<int>((int)workers_.size(), (n + grain - 1) / grain - 1);
+        static const int cap = rmu_env("RMU_TOK_THREADS") ? std::max(1, atoi(rmu_env("RMU_TOK_THREADS"))) - 1 : 1 << 30;   // (tuning: helpers per job)
+        const int helpers = std::min<int>(std::min<int>((int)workers_.size(), cap), (n + grain - 1) / grain - 1);
         if (helpers > 0) {
             { std::lock_guard<std::mutex> lk(mu_); current_ = j; ++gen_; }
             if (helpers * 2 >= (int)workers_.size()) cv_.notify_all();
