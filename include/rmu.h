@@ -212,7 +212,10 @@ int rmu_bert_free(rmu_bert_t* m);
  * Rounding and batch shape: activations are bf16, and which kernels serve a call depends on batch * max_len (<= 256 tokens: the
  * small-batch GEMMs; <= 16384: the GEMM pair; above: the fused FFN kernel) -- a sequence's result is bit-identical across
  * calls that take the same kernels and equal up to bf16 rounding noise (|d| < 2e-3 on unit vectors, cosine > 0.9999)
- * otherwise: a query embedded alone reproduces the vector its text got at indexing time to that noise, not bit for bit. */
+ * otherwise: a query embedded alone reproduces the vector its text got at indexing time to that noise, not bit for bit.
+ * hip_stream != 0: the forward is left in flight on that stream (inputs and out_dev must stay valid until it has run); the model's next
+ * call on any OTHER stream -- stream 0 and the host-path entry points included -- is ordered behind it on the device (one workspace per
+ * model), so a caller may queue the next block's forward while this one runs. */
 int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens,
                     int batch, int max_len, int mode, float* out_dev, int64_t out_stride,
                     uint64_t hip_stream);

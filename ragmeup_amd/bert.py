@@ -204,12 +204,25 @@ class BertEncoder:
                                               scores.ctypes.data, vecs.ctypes.data if vecs is not None else None), "rmu_bert_search_mmr")
         return (rows[:B], scores[:B], vecs[:B]) if want_vectors else (rows[:B], scores[:B])
 
-    def encode_ids(self, ids, lens, type_ids=None, mode: int = 0, out=None):
+    def encode_ids(self, ids, lens, type_ids=None, mode: int = 0, out=None, stream=None):
         """ids [B, L] int (numpy or torch, padded), lens [B].  mode = MODE_MEAN / MODE_CLS (| NO_NORMALIZE) -> [B, 384] fp32
         (torch CUDA); MODE_CE -> [B] fp32 logits; MODE_TOKENS -> [sum(min(lens, L)), 384] fp32, sequences packed in batch order.
-        `out` may be a pre-allocated CUDA tensor (e.g. a slice of a corpus matrix)."""
+        `out` may be a pre-allocated CUDA tensor (e.g. a slice of a corpus matrix).
+        `stream` (a torch.cuda.Stream; inputs must be int32 CUDA tensors that are complete, `out` given): the forward is ENQUEUED on that
+        stream and the call returns with it in flight -- the caller synchronises (or records an event) before reading `out` or reusing the
+        inputs.  The library orders this model's next call on any other stream behind it."""
         torch = self._torch
         with self._lock:
+            if stream is not None:
+                ok = (all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous() for t in (ids, lens))
+                      and type_ids is None and out is not None)
+                if not ok:
+                    raise ValueError("encode_ids(stream=...): ids / lens must be contiguous int32 CUDA tensors, no type ids, `out` given")
+                B, L = ids.shape
+                stride = 1 if (mode & 0xff) == MODE_CE else out.stride(0)
+                N.check(self._lib.rmu_bert_encode(self._h, ids.data_ptr(), None, lens.data_ptr(), int(B), int(L), int(mode), out.data_ptr(),
+                                                  int(stride), int(stream.cuda_stream)), "rmu_bert_encode")
+                return out
             return self._encode_ids_locked(ids, lens, type_ids, mode, out)
 
     def _stage_in(self, a, slot: str, min_cap: int = 1 << 16):

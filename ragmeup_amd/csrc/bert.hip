@@ -3603,6 +3603,12 @@ struct rmu_bert {
     std::vector<rmu_bert*> clones;
     std::mutex clones_mu;
     bool is_clone = false;
+    // A forward that rmu_bert_encode left IN FLIGHT on a caller's stream still owns this context's workspace.  Its end is marked with an
+    // event; whatever this context enqueues next on ANOTHER stream (the library's own for stream-0 and host-path calls, or a second caller
+    // stream) waits for that event on the device first.  (round 5: MI355XEmbeddings queues block i + 1's forward behind block i's.)
+    hipEvent_t tail_ev = nullptr;
+    hipStream_t tail_stream = nullptr;
+    bool tail_set = false;
 };
 static constexpr size_t MAX_CLONES = 3;
 // rmu_bert_encode_host / rmu_bert_search_mmr carry up to HOST_TOKENS tokens (batch * max_len): one query, or the <= 14 (query, passage)
@@ -3658,7 +3664,21 @@ extern "C" int rmu_bert_free(rmu_bert_t* m) {
     if (m->d_in) (void)hipFree(m->d_in);
     if (m->d_out) (void)hipFree(m->d_out);
     if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->tail_ev) (void)hipEventDestroy(m->tail_ev);
     delete m;
+    return RMU_OK;
+}
+
+// (m->mu held) see rmu_bert::tail_ev
+static int order_behind_tail(rmu_bert* m, hipStream_t s) {
+    if (m->tail_set && m->tail_stream != s && hipStreamWaitEvent(s, m->tail_ev, 0) != hipSuccess) return RMU_E_HIP;
+    return RMU_OK;
+}
+static int mark_tail(rmu_bert* m, hipStream_t s) {
+    if (!m->tail_ev && hipEventCreateWithFlags(&m->tail_ev, hipEventDisableTiming) != hipSuccess) { m->tail_ev = nullptr; return RMU_E_HIP; }
+    if (hipEventRecord(m->tail_ev, s) != hipSuccess) return RMU_E_HIP;
+    m->tail_stream = s;
+    m->tail_set = true;
     return RMU_OK;
 }
 
@@ -3754,7 +3774,18 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
 // busy -- the model itself, queued.  `lk` holds the chosen context's mutex on return.
 static rmu_bert* acquire_ctx(rmu_bert* m, std::unique_lock<std::mutex>& lk) {
     lk = std::unique_lock<std::mutex>(m->mu, std::try_to_lock);
-    if (lk.owns_lock()) return m;
+    if (lk.owns_lock()) {
+        // free to lock is not free to run: a bulk forward left in flight on a caller's stream (rmu_bert_encode) still owns the workspace, and
+        // a query would queue behind it on the device -- it takes a clone instead, as it does when the model is locked
+        bool busy = false;
+        if (m->tail_set) {
+            busy = hipEventQuery(m->tail_ev) == hipErrorNotReady;
+            (void)hipGetLastError();             // (not-ready is an answer, not an error to be found by a later check)
+            if (!busy) m->tail_set = false;
+        }
+        if (!busy) return m;
+        lk.unlock();
+    }
     {
         std::lock_guard<std::mutex> g(m->clones_mu);
         for (rmu_bert* c : m->clones) {
@@ -4306,9 +4337,16 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     rc = ensure_ws(m, (int64_t)batch * max_len, batch);
     if (rc) return bfail(rc, "rmu_bert_encode: workspace");
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
+    if ((rc = order_behind_tail(m, s))) return bfail(rc, "rmu_bert_encode: ordering behind the forward in flight");
     enqueue_forward(m, ids, type_ids, lens, batch, max_len, mode, out_dev, out_stride, s);
     B_TRY(hipGetLastError());
-    if (!hip_stream) B_TRY(hipStreamSynchronize(s));
+    if (!hip_stream) {
+        B_TRY(hipStreamSynchronize(s));
+        m->tail_set = false;                     // (everything this context ever enqueued has finished)
+    } else if ((rc = mark_tail(m, s))) {
+        (void)hipStreamSynchronize(s);           // no event: fall back to "complete on return"
+        m->tail_set = false;
+    }
     return RMU_OK;
 }
 
@@ -4340,6 +4378,7 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
     const size_t out_floats = kind == RMU_BERT_CE_LOGIT ? (size_t)batch : (size_t)rows_out * H;
     const size_t in_bytes = (size_t)(2 * cap + batch) * 4;
     hipStream_t s = m->stream;
+    if ((rc = order_behind_tail(m, s))) return bfail(rc, std::string(who) + ": ordering behind the forward in flight");
     auto enqueue_all = [&]() {
         (void)hipMemcpyAsync(m->d_in, m->h_in, in_bytes, hipMemcpyHostToDevice, s);
         enqueue_forward(m, m->d_in, type_ids ? m->d_in + cap : nullptr, m->d_in + 2 * cap, batch, max_len, mode, m->d_out, kind == RMU_BERT_CE_LOGIT ? 1 : H, s);

@@ -213,6 +213,23 @@ def test_block_pipeline_uploads_and_two_threads_on_one_encoder(bi, tmp_path):
     [t.join() for t in th]
     # ... and is bit-identical for the same blocks, whichever thread ran them and whatever ran beside them
     assert np.array_equal(got["a"], piped_a) and np.array_equal(got["b"], piped_b)
+    # (round 5) the blocks' forwards are left in flight on a stream of their own, one queued behind the other: queries that arrive meanwhile
+    # (host path: the model's context when nothing is in flight on it, else a clone) and a synchronous bulk call from another thread (ordered
+    # behind the forward in flight by the library) return what they return alone
+    q_texts = [ta[3], tb[5], ta[100]]
+    alone = [np.asarray(emb.embed_query(t), np.float32) for t in q_texts]
+    ids_s, _, lens_s = emb._tokenize_arrays(ta[:300])
+    bulk_alone = bi[0].encode_ids(ids_s, lens_s, None, 0).cpu().numpy()
+    t = threading.Thread(target=run, args=("a2", ta))
+    t.start()
+    seen, bulk_seen = [], []
+    while t.is_alive():
+        seen.append([np.asarray(emb.embed_query(x), np.float32) for x in q_texts])
+        bulk_seen.append(bi[0].encode_ids(ids_s, lens_s, None, 0).cpu().numpy())
+    t.join()
+    assert np.array_equal(got["a2"], piped_a) and seen
+    assert all(np.array_equal(a, b) for row in seen for a, b in zip(row, alone))
+    assert all(np.array_equal(b, bulk_alone) for b in bulk_seen)
 
 
 def test_embeddings_4096_chunk_sample_vs_transformers(bi):
