@@ -259,6 +259,42 @@ class BertEncoder:
         self._side.synchronize()
         return outs
 
+    def upload_rows(self, id_parts, len_parts, width: int, slot: str, min_cap: int = 1 << 16):
+        """Several HOST id arrays [n_i, L_i] (row order) + their length arrays -> ONE device int32 [sum n_i, width] (columns past L_i zero) and
+        the lengths [sum n_i], written part by part into the pinned staging pair `slot` -- what `upload` does for one array, without the
+        concatenated host copy in front of it.  Complete on return; valid until `slot` is used again."""
+        torch = self._torch
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        n = int(sum(a.shape[0] for a in id_parts))
+        with torch.cuda.stream(self._side):
+            pair_i = self._stage_pair(f"{slot}.0", n * width, min_cap)
+            pair_l = self._stage_pair(f"{slot}.1", n, 1 << 16)
+            hv = pair_i[0][:n * width].numpy().reshape(n, width)
+            hl = pair_l[0][:n].numpy()
+            lo = 0
+            for a, ln in zip(id_parts, len_parts):
+                m, w = a.shape[0], min(a.shape[1], width)
+                np.copyto(hv[lo:lo + m, :w], a[:, :w], casting="unsafe")
+                if w < width:
+                    hv[lo:lo + m, w:] = 0
+                np.copyto(hl[lo:lo + m], ln, casting="unsafe")
+                lo += m
+            pair_i[1][:n * width].copy_(pair_i[0][:n * width], non_blocking=True)
+            pair_l[1][:n].copy_(pair_l[0][:n], non_blocking=True)
+        self._side.synchronize()
+        return pair_i[1][:n * width].view(n, width), pair_l[1][:n]
+
+    def _stage_pair(self, slot: str, n: int, min_cap: int):
+        """(pinned host int32, device int32) staging tensors of at least n elements under the name `slot` (see _stage_in)"""
+        torch = self._torch
+        st = self._stage.get(slot)
+        if st is None or st[0].numel() < n:
+            cap = max(n + n // 4, min_cap)
+            st = (torch.empty(cap, dtype=torch.int32).pin_memory(), torch.empty(cap, dtype=torch.int32, device=self.device))
+            self._stage[slot] = st
+        return st
+
     def _encode_ids_locked(self, ids, lens, type_ids, mode, out):
         torch = self._torch
         lens_host = None if torch.is_tensor(lens) else np.asarray(lens)

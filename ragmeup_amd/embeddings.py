@@ -288,6 +288,30 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
             return None
         return self._tokenize(list(texts))
 
+    def enqueue_token_arrays(self, parts: list, round_no: int):
+        """The GPU half, left IN FLIGHT: `parts` = the (ids, lens) pairs of `tokenize_for_index` of one or more calls, in row order ->
+        (torch CUDA [n, 384] fp32, event that marks its end), or None when these rows have to take `embed_token_arrays_device` (no native
+        encoder, more tokens than one forward).  The ids are written part by part into the pinned staging slot `add<round_no & 1>` (no
+        concatenated host copy in between): a caller keeps at most two rounds going and waits for round r before it starts round r + 2."""
+        import torch
+        if not isinstance(getattr(self, "encoder", None), BertEncoder) or not self.one_forward or not parts:
+            return None
+        cut = [np.minimum(np.asarray(ln, dtype=np.int32), min(a.shape[1], self.max_seq_length)) for a, ln in parts]
+        n = int(sum(a.shape[0] for a, _ in parts))
+        Lmax = max(1, max(int(c.max(initial=1)) for c in cut))
+        if n == 0 or n * Lmax > self.token_budget or n > 65535:
+            return None
+        enc = self.encoder
+        fwd = getattr(enc, "_fwd_stream", None)
+        if fwd is None:
+            fwd = enc._fwd_stream = torch.cuda.Stream(enc.device)
+        ids_d, lens_d = enc.upload_rows([a for a, _ in parts], cut, Lmax, slot=f"add{round_no & 1}", min_cap=self.token_budget)
+        out = torch.empty((n, 384), dtype=torch.float32, device=enc.device)
+        enc.encode_ids(ids_d, lens_d, None, mode=self._mode, out=out, stream=fwd)
+        done = torch.cuda.Event()
+        done.record(fwd)
+        return out, done
+
     def embed_token_arrays_device(self, ids: np.ndarray, lens: np.ndarray):
         """The GPU half: token arrays of `tokenize_for_index` -> torch CUDA [n, 384] fp32 (what `embed_documents_device` returns)."""
         return self.embed_id_arrays(ids, lens)
