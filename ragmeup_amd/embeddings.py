@@ -283,10 +283,14 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         """The HOST half of `embed_documents_device` for one pipeline block (<= pipeline_block texts): (ids, lens) numpy arrays, or
         None when this object is not backed by the native tokenizer + encoder.  MI355XVectorStore runs it for call i + 1 while the
         GPU half of call i (`embed_token_arrays_device` + the index append) is still in flight."""
-        from .tokenizer import WordPieceTokenizer
-        if not isinstance(getattr(self, "encoder", None), BertEncoder) or not isinstance(getattr(self, "tokenizer", None), WordPieceTokenizer):
+        if not self.can_tokenize_for_index():
             return None
         return self._tokenize(list(texts))
+
+    def can_tokenize_for_index(self) -> bool:
+        """Whether `tokenize_for_index` / `embed_token_arrays_device` are available: the native tokenizer AND the native encoder."""
+        from .tokenizer import WordPieceTokenizer
+        return isinstance(getattr(self, "encoder", None), BertEncoder) and isinstance(getattr(self, "tokenizer", None), WordPieceTokenizer)
 
     def enqueue_token_arrays(self, parts: list, round_no: int):
         """The GPU half, left IN FLIGHT: `parts` = the (ids, lens) pairs of `tokenize_for_index` of one or more calls, in row order ->

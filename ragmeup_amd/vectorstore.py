@@ -558,13 +558,14 @@ class MI355XVectorStore(VectorStore):
         for it in items:
             it[4].set_result(None)
 
-    def _add_pipelined(self, sel_texts, sel_ids, sel_metas_fn) -> bool:
+    def _add_pipelined(self, sel_texts, sel_ids, sel_metas_fn, force: bool = False) -> bool:
         emb = self._embeddings
         if (self.pipeline_inserts is False or self.auto_persist is True or not hasattr(emb, "tokenize_for_index")
                 or not (128 <= len(sel_texts) <= getattr(emb, "pipeline_block", 0)) or not self._can_pipeline()):
             return False
-        if self.pipeline_inserts == "auto" and not self._pending and time.monotonic() - self._last_add_end > self.pipeline_window:
+        if not force and self.pipeline_inserts == "auto" and not self._pending and time.monotonic() - self._last_add_end > self.pipeline_window:
             return False                                 # not inside an insert loop: this call is synchronous and raises its own failures
+        # (force: a block of one big call -- the call itself waits for its blocks and raises their failures)
         tok = emb.tokenize_for_index(sel_texts)          # the previous call's GPU half may still be running: this is the overlap
         if tok is None:
             return False
@@ -611,18 +612,49 @@ class MI355XVectorStore(VectorStore):
             seen.update(ids[lo:lo + cls._GIL_PIECE])
         return len(seen) == len(ids)
 
-    def _add(self, texts: list, metas_fn, ids) -> list[str]:
+    def _blockwise_ok(self, n: int) -> int:
+        """Pipeline block size if a call of n texts can run as a sequence of pipelined block inserts (native tokenizer + encoder, the index
+        callable from the worker, nothing that forbids deferring), else 0."""
+        emb = self._embeddings
+        blk = int(getattr(emb, "pipeline_block", 0) or 0)
+        if (blk < 128 or n <= blk or self.pipeline_inserts is False or self.auto_persist is True or not hasattr(emb, "tokenize_for_index")
+                or not self._can_pipeline()):
+            return 0
+        can = getattr(emb, "can_tokenize_for_index", None)
+        return blk if (can is None or can()) else 0
+
+    def _add(self, texts: list, metas_fn, ids, _force_pipeline: bool = False) -> list[str]:
         if not texts:
             return []
         if ids is not None and len(ids) != len(texts):
             raise ValueError("texts, metadatas and ids must have equal lengths")
+        blk = 0 if _force_pipeline else self._blockwise_ok(len(texts))
+        if blk:
+            # One big call = the reference's insert loop (RAGHelper.py:423-434) in pipeline-block-sized steps: block i + 1 is tokenised and its
+            # records are written while the forward of block i runs, and the worker puts the next forward behind the current one -- measured
+            # 0.94 of the encoder-only rate against 0.85 for "embed everything, then do the bookkeeping" (DESIGN.md 4.6).  The call returns
+            # when every block is in the index and raises a failed block's error itself.  Like the replaced stores' batched insert (Milvus
+            # inserts `batch_size` rows at a time) it is not atomic: blocks in front of a failing one stay inserted, the failing block and the
+            # ones behind it are rolled back.  Ids repeated across blocks follow the upsert rule (the last occurrence lives).
+            metadatas = metas_fn()
+            if metadatas is not None and len(metadatas) != len(texts):
+                raise ValueError("texts, metadatas and ids must have equal lengths")
+            out: list[str] = []
+            try:
+                for lo in range(0, len(texts), blk):
+                    hi = min(lo + blk, len(texts))
+                    out += self._add(texts[lo:hi], (lambda lo=lo, hi=hi: None if metadatas is None else metadatas[lo:hi]),
+                                     None if ids is None else ids[lo:hi], _force_pipeline=True)
+            finally:
+                self.flush()
+            return out
         # The indexing path's one big call (RAGHelper.py:423-434 with everything in one batch; BASELINE.json configs[2]): the embedding of ALL
         # texts starts before any Python bookkeeping -- metadata lists, str(ids), the duplicate-id check, the record copies, the pk map: 0.7 s
         # per 1M documents that used to sit serially in front of and behind a 2.7 s forward (tokenizer and encoder run in librmu.so with the
         # GIL released).  Ids repeated inside the batch (rare: md5 ids of distinct chunks) drop their earlier rows from the result afterwards.
         early = pool = None
         emb = self._embeddings
-        if len(texts) > max(4096, int(getattr(emb, "pipeline_block", 0) or 0)):
+        if not _force_pipeline and len(texts) > max(4096, int(getattr(emb, "pipeline_block", 0) or 0)):
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rmu-embed")
             early = pool.submit(self._embed_docs_for_index, texts)
@@ -641,13 +673,13 @@ class MI355XVectorStore(VectorStore):
             else:
                 keep = sorted({pk: i for i, pk in enumerate(ids)}.values())
                 sel_texts, sel_ids = [texts[i] for i in keep], [ids[i] for i in keep]
-            return self._add_texts_body(texts, metadatas, ids, keep, sel_texts, sel_ids, early)
+            return self._add_texts_body(texts, metadatas, ids, keep, sel_texts, sel_ids, early, _force_pipeline)
         finally:
             if pool is not None:
                 pool.shutdown(wait=True)                 # (a failed validation above still waits for the forward it started)
             self._last_add_end = time.monotonic()
 
-    def _add_texts_body(self, texts, metadatas, ids, keep, sel_texts, sel_ids, early=None) -> list[str]:
+    def _add_texts_body(self, texts, metadatas, ids, keep, sel_texts, sel_ids, early=None, force_pipeline=False) -> list[str]:
         new_map = None
         if early is not None:                            # the forward of ALL texts is already running (see _add)
             sel_metas = [dict(metadatas[i]) for i in keep]
@@ -658,7 +690,7 @@ class MI355XVectorStore(VectorStore):
             vecs = early.result()
             if len(sel_ids) != len(texts):
                 vecs = vecs[list(keep)]                  # ids repeated inside the batch: the last occurrence's row stays
-        elif self._add_pipelined(sel_texts, sel_ids, lambda: [dict(metadatas[i]) for i in keep]):
+        elif self._add_pipelined(sel_texts, sel_ids, lambda: [dict(metadatas[i]) for i in keep], force_pipeline):
             return list(ids)
         # The host records are prepared WHILE the GPU embeds (both the tokenizer and the encoder run in librmu.so with the GIL
         # released): on the indexing path (one big call) the Python bookkeeping would otherwise sit serially behind every embedding.

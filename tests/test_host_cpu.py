@@ -585,6 +585,50 @@ def test_insert_calls_queue_and_run_as_one_forward_and_nothing_can_tell():
     assert pip.similarity_search("newer text number 120 w ", k=1)[0].page_content.startswith("newer ")
 
 
+def test_one_big_call_runs_as_pipelined_blocks_and_raises_its_own_failure():
+    """(round 5) A call of more texts than one pipeline block IS the insert loop, in block-sized steps: its blocks go through the same two
+    halves, the call returns with everything in the index (nothing pending), the store equals the one the serial path builds; ids repeated
+    across blocks follow the upsert rule; a block that fails is raised BY THE CALL -- the blocks in front of it stay, it and the ones behind
+    it are rolled back (the replaced stores' batched insert is not atomic either); pipeline_inserts=False keeps the single forward."""
+    emb = TokenEmbeddings()
+    emb.pipeline_block = 500
+    docs, pks = _docs(0, 2300), [str(i) for i in range(2300)]
+    one = FakeStore(embeddings=emb, collection_name="serial", auto_persist=False)            # (FakeStore cannot pipeline: the serial path)
+    one.add_documents(docs, ids=pks)
+    assert emb.forwards == []
+    big = PipeStore(embeddings=emb, collection_name="big", auto_persist=False, pipeline_inserts="auto")
+    assert big.add_documents(docs, ids=pks) == pks
+    assert not big._pending and len(big._index) == len(big._texts) == 2300 and sum(emb.forwards) == 2300 and max(emb.forwards) <= 500
+    assert big._pks == one._pks and np.array_equal(big._index.x, one._index.x) and big._pk_to_row == one._pk_to_row
+    # ids repeated across (and inside) blocks: the last occurrence lives
+    rep = list(pks[:1200])
+    rep[700], rep[3] = rep[20], rep[4]
+    up = PipeStore(embeddings=emb, collection_name="up", auto_persist=False)
+    up.add_documents(docs[:1200], ids=rep)
+    assert len(up) == 1198 and up._texts[up._pk_to_row["20"]] == docs[700].page_content and up._texts[up._pk_to_row["4"]] == docs[4].page_content
+    assert "700" not in up._pk_to_row and "3" not in up._pk_to_row
+    # the third block's forward fails: raised by the call; blocks 0-1 stay, blocks 2.. are rolled back, the store stays usable
+    emb.forwards.clear(); emb.fail_on = 3
+    bad = PipeStore(embeddings=emb, collection_name="bad", auto_persist=False)
+    bad.pipeline_depth = 1                                       # (one half at a time: blocks are not coalesced, so "the third forward" is block 2)
+    with pytest.raises(RuntimeError, match="device lost"):
+        bad.add_documents(docs, ids=pks)
+    emb.fail_on = None
+    assert not bad._pending and len(bad) == len(bad._index) == len(bad._texts) == 1000 and "999" in bad._pk_to_row and "1000" not in bad._pk_to_row
+    bad.add_documents(docs[1000:], ids=pks[1000:])
+    assert len(bad) == 2300 and np.array_equal(bad._index.x, one._index.x)
+    # a length mismatch is refused before anything is inserted
+    with pytest.raises(ValueError):
+        bad.add_texts([d.page_content for d in docs], metadatas=[{}] * 7)
+    assert len(bad) == 2300
+    # pipeline_inserts=False: one forward through embed_documents, as before
+    emb.forwards.clear()
+    off = PipeStore(embeddings=emb, collection_name="off", auto_persist=False, pipeline_inserts=False)
+    off.add_documents(docs, ids=pks)
+    assert emb.forwards == [] and len(off) == 2300 and np.array_equal(off._index.x, one._index.x)
+    del emb.pipeline_block
+
+
 def test_a_failing_gpu_half_rolls_back_its_call_and_every_call_queued_behind_it():
     emb = TokenEmbeddings()
     pip = PipeStore(embeddings=emb, collection_name="pip", auto_persist=False)
