@@ -87,6 +87,11 @@ int rmu_index_set_option(rmu_index_t* idx, int option, int64_t value);
 #define RMU_STAT_GROW_MS 3
 #define RMU_STAT_LIVE_ROWS 4
 int rmu_index_stat(rmu_index_t* idx, int what, double* out);
+/* Make room for `rows` rows in all (grow-only; at most ONE re-allocation, none if the capacity is there).  A re-allocation waits for
+ * everything in flight on the device before the old matrix is freed: a caller that knows how many rows are coming -- or that is about to
+ * leave work in flight (the insert pipeline's worker, between two forwards) -- pays for it at a moment of its choosing instead of inside
+ * an rmu_index_add behind a forward.  Serves: RAGHelper.py:423-434's insert loop (the collection grows batch by batch). */
+int rmu_index_reserve(rmu_index_t* idx, int64_t rows);
 
 /* Append n rows ([n, dim] fp32 row-major, host or device).  *first_row = row id of vecs[0].
  * Serves: RAGHelper.py:431, :525 (db.add_documents -> add_texts -> insert). */

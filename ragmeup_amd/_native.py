@@ -26,7 +26,7 @@ MAX_DIM = 768
 # every symbol include/rmu.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "rmu_init", "rmu_last_error", "rmu_version",
-    "rmu_index_create", "rmu_index_free", "rmu_index_size", "rmu_index_dim", "rmu_index_metric", "rmu_index_set_option", "rmu_index_stat", "rmu_index_add",
+    "rmu_index_create", "rmu_index_free", "rmu_index_size", "rmu_index_dim", "rmu_index_metric", "rmu_index_set_option", "rmu_index_stat", "rmu_index_reserve", "rmu_index_add",
     "rmu_index_remove_rows", "rmu_index_get_rows", "rmu_index_save", "rmu_index_load", "rmu_index_mmr", "rmu_index_search_mmr", "rmu_index_search", "rmu_topk_merge",
     "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing", "rmu_last_screened",
     "rmu_comm_unique_id", "rmu_comm_init", "rmu_comm_free", "rmu_comm_world", "rmu_shard_allgather_topk", "rmu_index_screen_candidates",
@@ -58,6 +58,7 @@ def _declare(lib):
     lib.rmu_index_metric.argtypes = [vp, c.POINTER(i32)]
     lib.rmu_index_set_option.argtypes = [vp, i32, i64]
     lib.rmu_index_stat.argtypes = [vp, i32, c.POINTER(c.c_double)]
+    lib.rmu_index_reserve.argtypes = [vp, i64]
     lib.rmu_comm_unique_id.argtypes = [vp]
     lib.rmu_comm_init.argtypes = [c.POINTER(vp), vp, i32, i32]
     lib.rmu_comm_free.argtypes = [vp]

@@ -588,6 +588,15 @@ static int grow(rmu_index* idx, int64_t need) {
     return RMU_OK;
 }
 
+extern "C" int rmu_index_reserve(rmu_index_t* idx, int64_t rows) {
+    if (!idx || rows < 0) return fail(RMU_E_INVALID, "rmu_index_reserve: bad argument");
+    if (rows > 0xFFFFFFF0ll) return fail(RMU_E_INVALID, "rmu_index_reserve: row ids are 32-bit inside the scan");
+    int rc = g_tls.ensure_stream();
+    if (rc) return fail(rc, "rmu_index_reserve: stream");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    return grow(idx, rows);           // (rmu_index_add's geometric policy: a caller that reserves round by round does not re-allocate every round)
+}
+
 // after `n` rows at `dst` were converted into the screening image: |x|max and the measured image error |dx|max of those rows.
 // ENQUEUES only (two reductions into one 8-byte device pair + one 8-byte copy to idx->stat_host): the caller's own final
 // stream synchronisation covers it, then fold_image_stats() folds the pair into the index -- one host round trip per

@@ -78,6 +78,11 @@ class FlatIndex:
             out[name] = float(v.value) if name == "grow_ms" else int(v.value)
         return out
 
+    def reserve(self, rows: int):
+        """Make room for `rows` rows in all (grow-only; see rmu_index_reserve): a re-allocation waits for the device, so a caller that is
+        about to leave work in flight does it first."""
+        N.check(self._lib.rmu_index_reserve(self._h, int(rows)), "rmu_index_reserve")
+
     # -- mutation ----------------------------------------------------------------------------------
     def add(self, vecs) -> int:
         """Append rows; returns the row id of the first one."""
