@@ -627,6 +627,28 @@ class MI355XVectorStore(VectorStore):
         can = getattr(emb, "can_tokenize_for_index", None)
         return blk if (can is None or can()) else 0
 
+    def _add_blockwise(self, n: int, texts_of, metas_of, ids, blk: int) -> list[str]:
+        """One big call = the reference's insert loop (RAGHelper.py:423-434) in pipeline-block-sized steps: block i + 1 is tokenised and its
+        records are written while the forward of block i runs, and the worker puts the next forward behind the current one -- measured 0.90-0.94
+        of the encoder-only rate against 0.85 for "embed everything, then do the bookkeeping" (DESIGN.md 4.6).  The call returns when every
+        block is in the index and raises a failed block's error itself.  Like the replaced stores' batched insert (Milvus inserts
+        `batch_size` rows at a time) it is not atomic: blocks in front of a failing one stay inserted, the failing block and the ones behind
+        it are rolled back.  Ids repeated across blocks follow the upsert rule (the last occurrence lives).  texts_of / metas_of(lo, hi):
+        the block's texts and metadata -- taken block by block, so not even those lists are built in front of the first forward."""
+        out: list[str] = []
+        try:
+            with self._lock:                             # the collection's final size is known: one re-allocation, before anything is in flight
+                self._drain()
+                self._ensure_index(int(self._embeddings.encoder.HIDDEN))
+                if hasattr(self._index, "reserve"):
+                    self._index.reserve(len(self._texts) + n)
+            for lo in range(0, n, blk):
+                hi = min(lo + blk, n)
+                out += self._add(texts_of(lo, hi), (lambda lo=lo, hi=hi: metas_of(lo, hi)), None if ids is None else ids[lo:hi], _force_pipeline=True)
+        finally:
+            self.flush()
+        return out
+
     def _add(self, texts: list, metas_fn, ids, _force_pipeline: bool = False) -> list[str]:
         if not texts:
             return []
@@ -634,29 +656,10 @@ class MI355XVectorStore(VectorStore):
             raise ValueError("texts, metadatas and ids must have equal lengths")
         blk = 0 if _force_pipeline else self._blockwise_ok(len(texts))
         if blk:
-            # One big call = the reference's insert loop (RAGHelper.py:423-434) in pipeline-block-sized steps: block i + 1 is tokenised and its
-            # records are written while the forward of block i runs, and the worker puts the next forward behind the current one -- measured
-            # 0.94 of the encoder-only rate against 0.85 for "embed everything, then do the bookkeeping" (DESIGN.md 4.6).  The call returns
-            # when every block is in the index and raises a failed block's error itself.  Like the replaced stores' batched insert (Milvus
-            # inserts `batch_size` rows at a time) it is not atomic: blocks in front of a failing one stay inserted, the failing block and the
-            # ones behind it are rolled back.  Ids repeated across blocks follow the upsert rule (the last occurrence lives).
             metadatas = metas_fn()
             if metadatas is not None and len(metadatas) != len(texts):
                 raise ValueError("texts, metadatas and ids must have equal lengths")
-            out: list[str] = []
-            try:
-                with self._lock:                         # the collection's final size is known: one re-allocation, before anything is in flight
-                    self._drain()
-                    self._ensure_index(int(self._embeddings.encoder.HIDDEN))
-                    if hasattr(self._index, "reserve"):
-                        self._index.reserve(len(self._texts) + len(texts))
-                for lo in range(0, len(texts), blk):
-                    hi = min(lo + blk, len(texts))
-                    out += self._add(texts[lo:hi], (lambda lo=lo, hi=hi: None if metadatas is None else metadatas[lo:hi]),
-                                     None if ids is None else ids[lo:hi], _force_pipeline=True)
-            finally:
-                self.flush()
-            return out
+            return self._add_blockwise(len(texts), lambda lo, hi: texts[lo:hi], lambda lo, hi: None if metadatas is None else metadatas[lo:hi], ids, blk)
         # The indexing path's one big call (RAGHelper.py:423-434 with everything in one batch; BASELINE.json configs[2]): the embedding of ALL
         # texts starts before any Python bookkeeping -- metadata lists, str(ids), the duplicate-id check, the record copies, the pk map: 0.7 s
         # per 1M documents that used to sit serially in front of and behind a 2.7 s forward (tokenizer and encoder run in librmu.so with the
@@ -756,6 +759,12 @@ class MI355XVectorStore(VectorStore):
         return list(ids)
 
     def add_documents(self, documents: list[Document], ids: Optional[list[str]] = None, **kw) -> list[str]:
+        blk = self._blockwise_ok(len(documents))
+        if blk:
+            if ids is not None and len(ids) != len(documents):
+                raise ValueError("texts, metadatas and ids must have equal lengths")
+            return self._add_blockwise(len(documents), lambda lo, hi: [d.page_content for d in documents[lo:hi]],
+                                       lambda lo, hi: [d.metadata for d in documents[lo:hi]], ids, blk)
         return self._add([d.page_content for d in documents], lambda: [d.metadata for d in documents], ids)
 
     # ---- delete (server.py:373-377) -----------------------------------------------------------------------
