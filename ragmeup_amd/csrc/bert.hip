@@ -3591,7 +3591,7 @@ struct rmu_bert {
     // small-batch host path (rmu_bert_encode_host): one captured graph per (batch, max_len, mode, token types) shape -- H2D of the
     // ids, the ~45 launches of a forward, D2H of the result -- replayed with ONE hipGraphLaunch.  All addresses inside are
     // the fixed staging buffers below, so a replay needs no node updates.
-    struct SmallGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool warm = false; uint64_t last_use = 0; };
+    struct SmallGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; bool warm = false; bool no_graph = false; uint64_t last_use = 0; };
     std::map<uint64_t, SmallGraph> graphs;
     uint64_t graph_clock = 0;                      // bumps per host call: the least recently used graph goes when the cache is full
     int32_t *h_in = nullptr, *d_in = nullptr;      // [ids | type ids | lens], pinned host / device
@@ -4397,30 +4397,55 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
     }
     rmu_bert::SmallGraph& g = m->graphs[key];
     g.last_use = ++m->graph_clock;
-    if (use_graph && g.exec) {
-        B_TRY(hipGraphLaunch(g.exec, s));
-    } else if (use_graph && g.warm) {
+    auto clear_errors = [] { for (int i = 0; i < 8 && hipGetLastError() != hipSuccess; ++i) {} };
+    // Whatever state a failed capture / instantiation / replay left behind: end the capture if the stream is still in one, drop the pieces,
+    // clear the thread's error, and never capture this shape on this context again -- the call falls back to the eager launches.  (Seen once
+    // in the round's runs: four threads on clone contexts + a bulk encode, a capture reported "operation failed due to a previous error
+    // during capture" and the call failed with it.  A graph is an optimisation: losing it must not cost the call its result.)
+    auto abandon_graph = [&]() {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            hipGraph_t junk = nullptr;
+            (void)hipStreamEndCapture(s, &junk);
+            if (junk) (void)hipGraphDestroy(junk);
+        }
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+        g.warm = false;
+        g.no_graph = true;
+        clear_errors();
+    };
+    const bool may_graph = use_graph && !g.no_graph;
+    bool launched = false;
+    clear_errors();                                    // (an error some earlier call of this thread left behind is not this call's)
+    if (may_graph && g.exec) {
+        if (hipGraphLaunch(g.exec, s) == hipSuccess) launched = true;
+        else abandon_graph();
+    } else if (may_graph && g.warm) {
         // second call of this shape: capture (every function attribute / first-use static of the launchers is set by now)
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             enqueue_all();
             ok = hipStreamEndCapture(s, &g.graph) == hipSuccess && g.graph != nullptr;
             if (ok) ok = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) ok = hipGraphLaunch(g.exec, s) == hipSuccess;
         }
-        if (ok) {
-            B_TRY(hipGraphLaunch(g.exec, s));
-        } else {                                        // no graph for this shape: stay eager (and do not try again)
-            (void)hipGetLastError();
-            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-            if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
-            g.warm = false;
-            enqueue_all();
-        }
-    } else {
-        enqueue_all();
-        if (use_graph) g.warm = true;
+        if (ok) launched = true;
+        else abandon_graph();                          // no graph for this shape: stay eager (and do not try again)
     }
-    B_TRY(hipGetLastError());
+    if (!launched) {
+        enqueue_all();
+        if (may_graph && !g.no_graph) g.warm = true;
+    }
+    if (hipGetLastError() != hipSuccess) {
+        // one more attempt, eagerly, on a stream known to be out of capture and drained (the launches are idempotent: the same inputs to the
+        // same outputs); only a second failure is the call's
+        abandon_graph();
+        (void)hipStreamSynchronize(s);
+        clear_errors();
+        enqueue_all();
+        B_TRY(hipGetLastError());
+    }
     return RMU_OK;
 }
 
