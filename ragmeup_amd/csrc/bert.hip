@@ -4334,6 +4334,7 @@ extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t*
     int rc = check_encode_args(m, ids, lens, out_dev, batch, max_len, mode, out_stride);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(m->mu);
+    (void)hipGetLastError();                     // (an error some earlier call of this thread left behind -- the caller's framework polls events -- is not this call's)
     rc = ensure_ws(m, (int64_t)batch * max_len, batch);
     if (rc) return bfail(rc, "rmu_bert_encode: workspace");
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m->stream;
@@ -4422,14 +4423,21 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
         if (hipGraphLaunch(g.exec, s) == hipSuccess) launched = true;
         else abandon_graph();
     } else if (may_graph && g.warm) {
-        // second call of this shape: capture (every function attribute / first-use static of the launchers is set by now)
-        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            enqueue_all();
-            ok = hipStreamEndCapture(s, &g.graph) == hipSuccess && g.graph != nullptr;
-            if (ok) ok = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) == hipSuccess;
-            if (ok) ok = hipGraphLaunch(g.exec, s) == hipSuccess;
+        // second call of this shape: capture (every function attribute / first-use static of the launchers is set by now).  ONE capture at a
+        // time in the process: two threads capturing on their clone contexts at the same moment failed together once ("invalid argument" in
+        // one, "operation failed due to a previous error during capture" in the other) although both captures are thread-local
+        static std::mutex capture_mu;
+        bool ok;
+        {
+            std::lock_guard<std::mutex> cap(capture_mu);
+            ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                enqueue_all();
+                ok = hipStreamEndCapture(s, &g.graph) == hipSuccess && g.graph != nullptr;
+                if (ok) ok = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) == hipSuccess;
+            }
         }
+        if (ok) ok = hipGraphLaunch(g.exec, s) == hipSuccess;
         if (ok) launched = true;
         else abandon_graph();                          // no graph for this shape: stay eager (and do not try again)
     }
