@@ -3649,7 +3649,7 @@ static int conv_bf16(bf16* dst, const void* src, size_t n, float scale, hipStrea
 
 extern "C" int rmu_bert_free(rmu_bert_t* m) {
     if (!m) return RMU_OK;
-    (void)hipDeviceSynchronize();
+    (void)RMU_DEVICE_SYNC();
     for (rmu_bert* c : m->clones) (void)rmu_bert_free(c);      // (their `owned` lists are empty: workspaces, staging, graphs, stream)
     m->clones.clear();
     for (void* p : m->owned) (void)hipFree(p);
@@ -3822,9 +3822,12 @@ static void drop_graphs(rmu_bert* m) {       // the captured launches hold works
 static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
     if (tokens > m->ws_tokens || batch + 1 > m->ws_batch) drop_graphs(m);
     if (tokens > m->ws_tokens) {
-        (void)hipDeviceSynchronize();
-        for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->st1, (void*)m->st2})
-            if (p) (void)hipFree(p);
+        if (m->h) {                                   // (a fresh context -- a clone's first call -- has nothing in flight and nothing to free)
+            std::lock_guard<std::mutex> cap(rmu_capture_mutex());      // hipFree synchronises the device as well
+            (void)hipDeviceSynchronize();
+            for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->st1, (void*)m->st2})
+                if (p) (void)hipFree(p);
+        }
         m->h = m->h1 = m->y = m->qkv = m->ctx = m->mid = nullptr;
         m->st1 = m->st2 = nullptr;
         m->ws_tokens = 0;
@@ -3838,8 +3841,11 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
         m->ws_tokens = t;
     }
     if (batch + 1 > m->ws_batch) {
-        (void)hipDeviceSynchronize();
-        if (m->cu) (void)hipFree(m->cu);
+        if (m->cu) {
+            std::lock_guard<std::mutex> cap(rmu_capture_mutex());
+            (void)hipDeviceSynchronize();
+            (void)hipFree(m->cu);
+        }
         m->cu = nullptr; m->ws_batch = 0;
         const int nb = batch + batch / 8 + 64;
         if (hipMalloc((void**)&m->cu, (size_t)nb * sizeof(int)) != hipSuccess) return RMU_E_OOM;
@@ -4415,6 +4421,17 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
         g.warm = false;
         g.no_graph = true;
         clear_errors();
+        st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {      // still capturing: this stream is lost
+            clear_errors();
+            hipStream_t ns = nullptr;
+            if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
+                (void)hipStreamDestroy(m->stream);
+                m->stream = ns;
+                s = ns;
+            }
+            clear_errors();
+        }
     };
     const bool may_graph = use_graph && !g.no_graph;
     bool launched = false;
@@ -4426,10 +4443,9 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
         // second call of this shape: capture (every function attribute / first-use static of the launchers is set by now).  ONE capture at a
         // time in the process: two threads capturing on their clone contexts at the same moment failed together once ("invalid argument" in
         // one, "operation failed due to a previous error during capture" in the other) although both captures are thread-local
-        static std::mutex capture_mu;
         bool ok;
         {
-            std::lock_guard<std::mutex> cap(capture_mu);
+            std::lock_guard<std::mutex> cap(rmu_capture_mutex());      // (also: never beside a device-wide synchronisation, rmu_common.h)
             ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 enqueue_all();

@@ -496,7 +496,7 @@ extern "C" int rmu_index_free(rmu_index_t* idx) {
     if (!idx) return RMU_OK;
     {
         std::unique_lock<std::shared_mutex> lk(idx->mu);
-        (void)hipDeviceSynchronize();
+        (void)RMU_DEVICE_SYNC();
         if (idx->x) (void)hipFree(idx->x);
         if (idx->split) (void)hipFree(idx->split);
         if (idx->nrm) (void)hipFree(idx->nrm);
@@ -547,7 +547,7 @@ static int grow(rmu_index* idx, int64_t need) {
         if (hipMalloc((void**)&nx, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float)) != hipSuccess)
             return fail(RMU_E_OOM, "rmu_index_add: hipMalloc for growth");
     }
-    HIP_TRY(hipDeviceSynchronize());  // nobody may still be scanning the old matrix
+    HIP_TRY(RMU_DEVICE_SYNC());  // nobody may still be scanning the old matrix
     hipStream_t s = g_tls.stream;     // same stream as the uploads that follow (see rmu_index_create)
     HIP_TRY(hipMemsetAsync(nx + idx->n * idx->dpad, 0, (size_t)(cap + kSlackRows - idx->n) * idx->dpad * sizeof(float), s));
     if (idx->n)
@@ -702,7 +702,7 @@ extern "C" int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int6
     Buf& b = g_tls.in_r;
     if (b.ensure(todo.size() * sizeof(int64_t))) return fail(RMU_E_OOM, "rmu_index_remove_rows: workspace");
     hipStream_t s = g_tls.stream;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(RMU_DEVICE_SYNC());
     HIP_TRY(hipMemcpyAsync(b.p, todo.data(), todo.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, idx->x, idx->dpad,
                        (const int64_t*)b.p, (int64_t)todo.size());

@@ -1,5 +1,6 @@
 // rmu_common.h -- shared device/host helpers for librmu.so (gfx950 only).
 #pragma once
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -119,6 +120,17 @@ inline const char* rmu_env(const char* name) {
 // RMU_GRAPH=0 (rmu_bert_encode_host never captures a hipGraph) -- are honoured with or without the master switch: they only ever select
 // the more conservative path.
 inline const char* rmu_env_kill(const char* name) { return getenv(name); }
+
+// A hipGraph capture (the host-path forwards of bert.hip, thread-local mode) and a DEVICE-WIDE synchronisation from another thread do not mix on
+// this runtime: the synchronisation reports "operation not permitted when stream is capturing", the capture is invalidated and its stream can
+// stay in capture mode (seen: query threads on clone contexts while another clone sized its workspace).  Captures are rare (once per shape and
+// context) and device-wide synchronisations are rarer: both take this mutex.
+inline std::mutex& rmu_capture_mutex() {
+    static std::mutex mu;
+    return mu;
+}
+// hipDeviceSynchronize that never overlaps a capture of this library
+#define RMU_DEVICE_SYNC() ([] { std::lock_guard<std::mutex> rmu_cap_(rmu_capture_mutex()); return hipDeviceSynchronize(); }())
 
 // ---- launch descriptors shared between rmu_api.hip and the kernel translation units -------------
 // Device-side launch predicate.  The screening path decides per query ON THE DEVICE whether the exact scan has to re-run
