@@ -602,7 +602,7 @@ class MI355XVectorStore(VectorStore):
     # ---- insert (RAGHelper.py:431, :525) ------------------------------------------------------------------
     def add_texts(self, texts: Iterable[str], metadatas: Optional[list[dict]] = None, ids: Optional[list[str]] = None,
                   **kw) -> list[str]:
-        return self._add(list(texts), lambda: metadatas, ids)
+        return self._add(list(texts), lambda: metadatas, None if ids is None else list(ids))
 
     # While a big call's forward runs on the worker thread, the bookkeeping on this one must not hold the GIL for long: ONE C-level call over
     # 1M ids (set(ids): 80 ms, dict(zip(..)): 200 ms) keeps the worker from issuing the next block's forward for that long -- the GPU idles.
@@ -759,6 +759,8 @@ class MI355XVectorStore(VectorStore):
         return list(ids)
 
     def add_documents(self, documents: list[Document], ids: Optional[list[str]] = None, **kw) -> list[str]:
+        documents = documents if isinstance(documents, list) else list(documents)
+        ids = None if ids is None else list(ids)
         blk = self._blockwise_ok(len(documents))
         if blk:
             if ids is not None and len(ids) != len(documents):
