@@ -65,12 +65,12 @@ struct Buf {
     void* p = nullptr;
     size_t cap = 0;
     void release() {
-        if (p && !g_runtime_down) (void)hipFree(p);
+        if (p && !g_runtime_down) (void)rmu_free(p);
         p = nullptr; cap = 0;
     }
     int ensure(size_t bytes) {
         if (bytes <= cap) return RMU_OK;
-        if (p) (void)hipFree(p);
+        if (p) (void)rmu_free(p);
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 4 + 256;
         if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return RMU_E_OOM; }
@@ -559,7 +559,7 @@ static int grow(rmu_index* idx, int64_t need) {
         const size_t rowb = RMU_IMG_ROW_BYTES;
         bool got = hipMalloc((void**)&ns, (size_t)(cap + kSlackRows) * rowb) == hipSuccess;
         if (got && idx->nrm && hipMalloc((void**)&nn, (size_t)(cap + kSlackRows) * sizeof(float)) != hipSuccess) {
-            (void)hipFree(ns);
+            (void)rmu_free(ns);
             got = false;
         }
         if (got) {
@@ -570,19 +570,19 @@ static int grow(rmu_index* idx, int64_t need) {
                 if (idx->n) HIP_TRY(hipMemcpyAsync(nn, idx->nrm, (size_t)idx->n * sizeof(float), hipMemcpyDeviceToDevice, s));
             }
             HIP_TRY(hipStreamSynchronize(s));
-            (void)hipFree(idx->split);
-            if (idx->nrm) (void)hipFree(idx->nrm);
+            (void)rmu_free(idx->split);
+            if (idx->nrm) (void)rmu_free(idx->nrm);
             idx->split = ns;
             idx->nrm = nn;
         } else {
             (void)hipGetLastError();
-            (void)hipFree(idx->split);   // no room for the screening image: exact path only from now on
-            if (idx->nrm) (void)hipFree(idx->nrm);
+            (void)rmu_free(idx->split);   // no room for the screening image: exact path only from now on
+            if (idx->nrm) (void)rmu_free(idx->nrm);
             idx->split = nullptr;
             idx->nrm = nullptr;
         }
     }
-    (void)hipFree(idx->x);
+    (void)rmu_free(idx->x);
     idx->x = nx;
     idx->cap = cap;
     return RMU_OK;

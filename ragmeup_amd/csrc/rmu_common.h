@@ -126,8 +126,13 @@ inline const char* rmu_env_kill(const char* name) { return getenv(name); }
 // stay in capture mode (seen: query threads on clone contexts while another clone sized its workspace).  Captures are rare (once per shape and
 // context) and device-wide synchronisations are rarer: both take this mutex.
 inline std::mutex& rmu_capture_mutex() {
-    static std::mutex mu;
-    return mu;
+    static std::mutex* mu = new std::mutex;      // (never destroyed: thread-local workspaces are released through it while the process winds down)
+    return *mu;
+}
+// hipFree waits for the device like hipDeviceSynchronize does: the same exclusion
+inline hipError_t rmu_free(void* p) {
+    std::lock_guard<std::mutex> rmu_cap_(rmu_capture_mutex());
+    return hipFree(p);
 }
 // hipDeviceSynchronize that never overlaps a capture of this library
 #define RMU_DEVICE_SYNC() ([] { std::lock_guard<std::mutex> rmu_cap_(rmu_capture_mutex()); return hipDeviceSynchronize(); }())
