@@ -107,3 +107,26 @@ def test_the_product_library_carries_only_the_kernels_it_takes():
     for gone in ("k_ffn_fused", "k_attention<", "k_attn4", "k_gemm_mid"):
         assert gone not in out.stdout, gone
 
+
+
+def test_device_wide_synchronisations_and_captures_share_one_mutex():
+    """(round 5) A hipDeviceSynchronize beside another thread's hipGraph capture invalidates the capture on this runtime (DESIGN.md 4.6,
+    profiles/r05_validation_notes.md): every device-wide synchronisation in the library's sources is RMU_DEVICE_SYNC() or sits right behind
+    a lock of rmu_capture_mutex(), and the capture takes the same mutex."""
+    import glob
+    import os
+    import re
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ragmeup_amd", "csrc")
+    bare = []
+    for path in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        lines = open(path, encoding="utf-8").read().split("\n")
+        for i, ln in enumerate(lines):
+            code = ln.split("//")[0]
+            if "hipDeviceSynchronize(" in code and "#define RMU_DEVICE_SYNC" not in code:
+                if not any("rmu_capture_mutex()" in prev for prev in lines[max(0, i - 2):i]):
+                    bare.append(f"{os.path.basename(path)}:{i + 1}")
+    assert not bare, bare
+    bert = open(os.path.join(src, "bert.hip"), encoding="utf-8").read()
+    cap = bert.index("hipStreamBeginCapture(")
+    assert "rmu_capture_mutex()" in bert[cap - 400:cap]
+    assert re.search(r"inline std::mutex& rmu_capture_mutex\(\)", open(os.path.join(src, "rmu_common.h"), encoding="utf-8").read())

@@ -78,3 +78,44 @@ def test_sufficiency_test_implies_containment():
         else:
             failed += 1
     assert passed >= 50 and failed >= 1            # both branches exercised (the cluster queries fail the test)
+
+
+# ---- the native L2 index (round 5): the row norm starts the screening chain as its C operand -------------------------------------------------
+def l2_screen_half_scores(x, q):
+    """scan_screen_lean3_kernel<.., L2N = 1>: acc starts at -2048 |x|^2 (fp32, the stored norm scaled exactly), then the 24 MFMA steps; the
+    candidate score is acc / 4096 = q~.x~ - |x|^2 / 2."""
+    n2 = (x.astype(np.float32) ** 2).sum(1, dtype=np.float32)              # the stored column (k_l2_aug_rows; any fp32 summation order)
+    hx, hq = image(x).astype(np.float32), image(q).astype(np.float32)
+    acc = np.broadcast_to((np.float32(-2048.0) * n2)[None, :], (q.shape[0], x.shape[0])).astype(np.float32).copy()
+    for k0 in range(0, x.shape[1], 16):
+        acc += (hq[:, k0:k0 + 16] @ hx[:, k0:k0 + 16].T).astype(np.float32)
+    return acc * np.float32(1.0 / 4096.0), n2
+
+
+def l2_exact_half_scores_fp32(x, q, n2):
+    """The exact L2 scan's chain: fp32 multiply-adds over (2q, x) in k order, then fma(-|x|^2, 1, .) -- halved (exact) for comparison."""
+    s2 = exact_scores_fp32(x, (2.0 * q).astype(np.float32))
+    full = (s2.astype(np.float64) - n2[None, :].astype(np.float64)).astype(np.float32)
+    return full * np.float32(0.5)
+
+
+def eps_l2(x, q):
+    xn = np.linalg.norm(x.astype(np.float64), axis=1).max()
+    return eps(x, q) + 1.5e-5 * xn * xn                                     # k_rescore<true> (scan_screen.hip)
+
+
+@pytest.mark.parametrize("name,x,q", [c for c in corpora() if c[0] != "norms 0.05..400"] + [
+    ("norms 0.05..30", (np.random.default_rng(5).standard_normal((2000, 384)) * np.random.default_rng(6).uniform(0.0025, 1.5, (2000, 1))).astype(np.float32),
+     (np.random.default_rng(7).standard_normal((30, 384)) * 0.7).astype(np.float32))], ids=lambda v: v if isinstance(v, str) else None)
+def test_l2_screen_error_bound_holds(name, x, q):
+    """|half score of the screen - half score of the exact L2 chain| <= EPS(q) + 1.5e-5 |x|max^2: the image errors bound the q.x part as for the
+    inner product; the norm is the same stored number on both sides and only the roundings that see it are new."""
+    ap, n2 = l2_screen_half_scores(x, q)
+    ex = l2_exact_half_scores_fp32(x, q, n2)
+    err = np.abs(ap.astype(np.float64) - ex.astype(np.float64))
+    bound = eps_l2(x, q)[:, None]
+    assert (err <= bound).all(), (name, float((err / bound).max()))
+    # and the ranking it protects is the L2 ranking: the exact half score orders rows like -|q - x|^2 up to fp32 rounding
+    d2 = ((q[:, None, :].astype(np.float64) - x[None, :200, :].astype(np.float64)) ** 2).sum(-1)
+    half = (q.astype(np.float64) ** 2).sum(1)[:, None] - 2.0 * ex[:, :200].astype(np.float64)
+    assert np.allclose(half, d2, rtol=0, atol=2e-4 * max(1.0, float(d2.max())))
