@@ -97,3 +97,72 @@ def test_the_24_pieces_of_a_tile_are_shared_out_exactly_once():
                 i, p = divmod(f, 24)
                 seen.add((i, p ^ ((i >> 1) & 7)))
         assert len(seen) == 32 * 24                                           # 32 rows x 24 units: every 16-byte unit of the chunk exactly once
+
+
+# ---- the L2 form's row norms (round 5): a second, tiny ring beside the image ring ----------------------------------------------------------------
+def l2_constants():
+    t = kernel_text()
+    assert "if (L2N && gs >= 13 && gs <= 16) frag_wait_nrm(fr[gs % S_PRE]);" in t
+    assert 'asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(S_PRE - 1 + 4));' in t
+    assert "if (L2N && gs == 12) read_nrm(std::integral_constant<int, (P + 1) % 6>{});" in t
+    assert "if (w == 0) issue_nrm(std::integral_constant<int, (P + 4) % 6>{}, np);" in t and "if (L2N && gs == 4 && P % 2 == 0) {" in t
+    assert "issue_nrm(I0{}, np);" in t and "issue_nrm(I2{}, np + 2 * S_RT);" in t and "np += 4 * S_RT;" in t and "np += 2 * S_RT;" in t
+    assert "if (L2N && (NWV == 8 || wave_live)) read_nrm(I0{});   // (in front of the fragment prefetch" in t
+    return {"read_step": 12, "wait_steps": (13, 16), "dma_step": 4}
+
+
+@pytest.mark.parametrize("nw", [8, 4])
+@pytest.mark.parametrize("ntiles", [1, 2, 3, 6, 7, 13, 40])
+def test_l2_norm_ring_lands_before_it_is_read_and_is_not_overwritten_while_readable(nw, ntiles):
+    """Wave 0's VMEM stream with the norm DMAs in it (one per PAIR of tiles, two pairs ahead, next to the threshold refresh): at the pair
+    barrier's vmcnt(NIW) the norms of this pair AND the next have landed (the first tile of the next pair is read for during this pair's
+    second tile), and the slot a new DMA lands in holds the norms of the pair that has just been left."""
+    c, l2 = constants(), l2_constants()
+    niw, steps = 24 // nw, 24
+    ops = [("R",), ("N", 0), ("N", 2)]                       # prologue: refresh, norms of tiles 0-1 and 2-3, then the image pieces of tiles 0..3
+    for t in range(c["prologue_tiles"]):
+        ops += [("P", t)] * niw
+    done = lambda n_out: ops[:max(0, len(ops) - n_out)]
+    norms_landed = lambda n_out: {o[1] + d for o in done(n_out) if o[0] == "N" for d in (0, 1)}
+    assert {0, 1, 2, 3} <= norms_landed(niw)                 # before the first barrier: z of tile 0 is read right behind it
+    read_at = {}                                             # tile -> tile during which its z is read (step 12), -1 = prologue
+    read_at[0] = -1
+    for tl in range(ntiles):
+        if tl % 2 == 0:
+            got = norms_landed(niw)
+            assert {tl, tl + 1, tl + 2, tl + 3} <= got, (tl, sorted(got))
+        for gs in range(steps):
+            if gs % (steps // niw) == 1:
+                ops.append(("P", tl + c["ahead"]))
+            if gs == l2["dma_step"] and tl % 2 == 0:
+                ops.append(("R",))
+                pair = tl + 4                                # norms of tiles tl + 4, tl + 5 -> ring positions of tiles tl - 2, tl - 1
+                assert (pair % 6, (pair + 1) % 6) == ((tl - 2) % 6, (tl - 1) % 6)
+                # every read of those positions' previous contents (z of tile tl - 2 and of tile tl - 1) happened before this pair's barrier
+                assert all(read_at.get(t, -2) < tl for t in (tl - 2, tl - 1) if t >= 0)
+                ops.append(("N", pair))
+            if gs == l2["read_step"]:
+                read_at[tl + 1] = tl                         # z of the NEXT tile
+                # it landed at or before this pair's barrier (tl + 1 belongs to this pair or is the first tile of the next one)
+                barrier_tile = tl & ~1
+                assert tl + 1 <= barrier_tile + 3
+
+
+def test_l2_norm_reads_are_counted_into_the_fragment_waits():
+    """LDS operations retire in order: with the four norm reads issued behind fragment read F(16) at step 12, the waits of steps 13..16 must
+    leave S_PRE - 1 + 4 operations outstanding to cover exactly their own fragment, and step 17's ordinary wait also covers the norms."""
+    c, l2 = constants(), l2_constants()
+    s_pre = c["s_pre"]
+    q = [("F", m) for m in range(s_pre)]                     # outstanding LDS reads in issue order (fragments 0..3 prefetched)
+    for gs in range(24):
+        allow = s_pre - 1 + (4 if l2["wait_steps"][0] <= gs <= l2["wait_steps"][1] else 0)
+        while len(q) > allow:
+            q.pop(0)
+        assert ("F", gs) not in q, gs                        # this step's fragment has landed
+        if gs == 17:
+            assert not any(o[0] == "N" for o in q)           # the norms are complete well before the next tile's first MFMA
+        q.append(("F", gs + s_pre))
+        if gs == l2["read_step"]:
+            q += [("N", i) for i in range(4)]
+        # never more than the counter can hold (lgkmcnt is 4 bits)
+        assert len(q) <= 15
