@@ -874,6 +874,121 @@ def cpu_search_baselines(q_host: np.ndarray, sample: np.ndarray, n_full: int, k:
     return {"batch": batch, "single": single, "rows": best_r.numpy()}
 
 
+# ---- the stdout contract: ONE line, <= 8 KB, nothing else on fd 1 ------------------------------------------------------
+LINE_BUDGET = 7168          # the driver's parser lost round 5's 23-KB line; tests/test_bench_cpu.py bounds this
+FULL_RECORD = "bench_secondary.json"   # every leg in full (rooflines, cpu baselines, notes), beside bench.py
+
+
+class _StdoutGuard:
+    """Everything any library writes to fd 1 while the bench runs (RCCL's "Librccl path" banner, amdgpu.ids warnings, C
+    printf) is sent to fd 2; `emit` restores fd 1 for the one JSON line."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, text: str):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)       # C-side buffers go where fd 1 points NOW (stderr)
+        except Exception:   # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        sys.stdout.write(text + "\n")
+        sys.stdout.flush()
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 1] + "~"
+
+
+def _compact_roofline(r, top=False):
+    if not r:
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes", "algorithmic_flops", "path",
+            "mfma_frac", "hbm_frac") if top else ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms")
+    o = {k: r[k] for k in keep if k in r}
+    if isinstance(o.get("traffic"), float):
+        o["traffic"] = int(o["traffic"])
+    if top:
+        o["kernel"] = _short(r.get("kernel", ""), 96)
+        if r.get("launch"):
+            o["launch"] = r["launch"]
+        if r.get("north_star"):
+            ns = dict(r["north_star"])
+            ns.pop("target", None)
+            ns["other_batches"] = [{k: b.get(k) for k in ("batch", "qps", "step_ms", "hbm_frac_step", "hbm_frac_kernel")} for b in ns.get("other_batches", [])]
+            o["north_star"] = ns
+        if r.get("emulated_shard_8"):
+            o["emulated_shard_8"] = r["emulated_shard_8"]
+    return o
+
+
+def compact_line(full: dict, budget: int = LINE_BUDGET) -> dict:
+    """The stdout line: the headline keys of the bench contract in full + a compact `secondary` (id, value, unit, ms_per_step,
+    roofline numbers, cpu_baseline value per leg).  Prose, kernel descriptions and per-leg detail stay in FULL_RECORD.  Legs' detail is
+    dropped in steps until the line fits the budget (it fits at the first step today; the ladder is the guarantee)."""
+    line = {k: v for k, v in full.items() if k not in ("secondary", "roofline", "cpu_baseline", "identical_check")}
+    line["config"] = dict(full.get("config") or {})
+    if "exchange" in line["config"]:
+        line["config"]["exchange"] = _short(line["config"]["exchange"], 64)
+    line["roofline"] = _compact_roofline(full.get("roofline"), top=True)
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = dict(cb, sample=_short(cb.get("sample", ""), 140)) if cb else None
+    extra_keys = ("recall_at_10_text_in", "parallel_efficiency", "projected_speedup_8_ranks", "emulated", "tokens_per_sec", "pairs_per_sec",
+                  "end_to_end_over_encoder_only", "vs_inner_product_step", "error")
+
+    def sec(level):
+        out = []
+        for leg in full.get("secondary") or []:
+            o = {"id": leg.get("id") or _short(leg.get("name", "?"), 40), "value": leg.get("value"), "unit": _short(leg.get("unit", ""), 16),
+                 "ms_per_step": leg.get("ms_per_step")}
+            r = _compact_roofline(leg.get("roofline"))
+            if r and level < 2:
+                o["roofline"] = r
+            elif r:
+                o["frac"], o["bound"] = r.get("frac"), r.get("bound")
+            c = leg.get("cpu_baseline")
+            if c:
+                o["cpu_baseline"] = {k: c.get(k) for k in (("value", "unit", "cores", "kind") if level < 1 else ("value", "cores"))}
+            if level < 2:
+                for k in extra_keys:
+                    if k in leg and not isinstance(leg[k], (dict, list)):
+                        o[k] = _short(leg[k], 120) if isinstance(leg[k], str) else leg[k]
+                d = leg.get("dense_top100")
+                if isinstance(d, dict):
+                    o["dense_top100"] = {k: v for k, v in d.items() if isinstance(v, (int, float)) or k in ("bound",)}
+            out.append(o)
+        return out
+
+    line["full_record"] = FULL_RECORD
+    for level in (0, 1, 2):
+        line["secondary"] = sec(level)
+        if len(json.dumps(line, allow_nan=False)) <= budget:
+            return line
+    line["secondary"] = [{"id": o["id"], "value": o["value"]} for o in line["secondary"]]
+    if len(json.dumps(line, allow_nan=False)) > budget:
+        line["secondary"] = []
+    return line
+
+
+def _denan(o):
+    """Strict JSON: non-finite floats become null."""
+    if isinstance(o, float):
+        return o if np.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: _denan(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_denan(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return _denan(o.item())
+    return o
+
+
 def _self_launch(n: int, argv: list, script: str | None = None) -> int:
     """`python bench.py --gpus N` started WITHOUT torch.distributed.run: re-exec as N ranks of one node (one process per GPU)
     and hand their output through -- rank 0 prints the JSON line."""
@@ -918,6 +1033,8 @@ def main(argv=None, hooks=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    t_start = time.perf_counter()
+    guard = _StdoutGuard()           # from here on fd 1 is stderr until rank 0 emits the line
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree", file=sys.stderr)
@@ -1065,7 +1182,7 @@ def main(argv=None, hooks=None):
 
     # ---- secondary legs (N = 1): the other BASELINE configurations, each with its own roofline -------
     secondary = []
-    t_leg = [time.perf_counter()]
+    t_leg = [t_start]
 
     def note(what):               # progress on stderr (the JSON line on stdout stays the only stdout output)
         now = time.perf_counter()
@@ -1087,12 +1204,12 @@ def main(argv=None, hooks=None):
 
     if "exact" in legs:
         index.set_screening(False)
-        secondary.append(scan_leg("exact fp32 scan only (RMU_OPT_SCREEN = 0), same workload as the headline", index, q, n_local, 4))
+        secondary.append(dict(scan_leg("exact fp32 scan only (RMU_OPT_SCREEN = 0), same workload as the headline", index, q, n_local, 4), id="exact"))
         index.set_screening(True)
     for b in (128, 32, 16, 1):
         if f"b{b}" in legs and B >= b:
-            secondary.append(scan_leg(f"HBM-bound regime: batch {b}" + (" (the reference's one query per call)" if b == 1 else ""),
-                                      index, q[:b].contiguous(), n_local, 20))
+            secondary.append(dict(scan_leg(f"HBM-bound regime: batch {b}" + (" (the reference's one query per call)" if b == 1 else ""),
+                                           index, q[:b].contiguous(), n_local, 20), id=f"b{b}"))
     # the north-star sentence of BASELINE.json (">= 10k queries/sec dense top-10 over 10M x 384 at >= 70 % HBM-bandwidth roofline on 1 GPU") lives in
     # the small-batch regime and names no batch size; the driver keeps `roofline`, so the figures of the batch-32 and batch-16 legs are repeated
     # there (on STEP time and on kernel time), the one with the best step-time fraction among those above 10k queries/sec first
@@ -1127,8 +1244,8 @@ def main(argv=None, hooks=None):
             rl = scan_roofline(ie, lambda: ie.search(q, K), n_emu, D, B, K, steps=5)
             ideal = ms_per_step / 8.0
             secondary.append({
-                "name": "emu8: the per-rank step of the 8-way row-sharded search (BASELINE.json configs[3]) EMULATED on one GPU", "emulated": True,
-                "value": round(B / (ms_emu * 1e-3), 1), "unit": "queries/sec (projected whole-job rate of 8 ranks = queries of a batch / one rank's step time)",
+                "id": "emu8", "name": "emu8: the per-rank step of the 8-way row-sharded search (BASELINE.json configs[3]) EMULATED on one GPU", "emulated": True,
+                "value": round(B / (ms_emu * 1e-3), 1), "unit": "queries/sec", "value_is": "projected whole-job rate of 8 ranks = queries of a batch / one rank's step time",
                 "ms_per_step": round(ms_emu, 4),
                 "config": {"workload": f"{n_emu}x{D} shard (1/8 of {N} rows), batch {B}, top-{K}; local scan + pack + world-1 ncclAllGather + device merge, stream-ordered",
                            "local_scan_only_ms": round(ms_local, 4), "exchange_and_merge_ms": round(ms_emu - ms_local, 4),
@@ -1142,7 +1259,7 @@ def main(argv=None, hooks=None):
                                                 "projected_speedup_8_ranks": round(ms_per_step / ms_emu, 2), "parallel_efficiency": round(ideal / ms_emu, 3)}
             comm1.close(); ie.close()
         except Exception as e:   # noqa: BLE001 - RCCL could not be bound on this box: say so instead of failing the bench
-            secondary.append({"name": "emu8", "emulated": True, "error": repr(e)[:300]})
+            secondary.append({"id": "emu8", "name": "emu8", "emulated": True, "error": repr(e)[:300]})
         del x_emu
         note("emu8")
     if "c2" in legs and x1m is not None:
@@ -1150,7 +1267,7 @@ def main(argv=None, hooks=None):
         i2.add(x1m)
         q2 = x1m[:B] + 0.1 * torch.randn((B, D), generator=gq, dtype=torch.float32, device=device)
         q2 /= q2.norm(dim=1, keepdim=True)
-        secondary.append(scan_leg("C2 1M x 384, batch 1024 (BASELINE.json configs[1])", i2, q2.contiguous(), x1m.shape[0], 20))
+        secondary.append(dict(scan_leg("C2 1M x 384, batch 1024 (BASELINE.json configs[1])", i2, q2.contiguous(), x1m.shape[0], 20), id="c2"))
         if "l2" in legs:
             # the same rows and queries on the NATIVE squared-L2 index (Milvus' default metric_type, RAGHelper.py:388-394): screened like the
             # inner-product index since round 5 (the row norm enters the fp16 MFMA chain as its C operand); on unit-norm rows both metrics
@@ -1165,7 +1282,7 @@ def main(argv=None, hooks=None):
             leg2["ids_equal_to_inner_product_index"] = round(float((r2 == ip_r).float().mean()), 5)
             leg2["max_abs_dist_minus_2_minus_2ip"] = float((d2 - (2.0 - 2.0 * ip_s)).abs().max())
             leg2["screened"] = l2i.last_screened()
-            secondary.append(leg2)
+            secondary.append(dict(leg2, id="l2"))
             l2i.close()
         i2.close()
 
@@ -1198,10 +1315,10 @@ def main(argv=None, hooks=None):
     note("c2 + cpu baselines")
     for name, fn in (("c1", leg_c1), ("mmr", leg_mmr), ("chat", leg_chat), ("embed", leg_embed), ("index", leg_index)):
         if name in legs:
-            secondary.append(fn(args))
+            secondary.append(dict(fn(args), id=name))
             note(name)
     if "rerank" in legs and x1m is not None:
-        secondary.append(leg_rerank(args, x1m))
+        secondary.append(dict(leg_rerank(args, x1m), id="rerank"))
         note("rerank")
 
     path = roofline["path"] if roofline else "unknown"
@@ -1222,15 +1339,14 @@ def main(argv=None, hooks=None):
         "identical_check": f"{nchk} queries x full shard, ids and scores bit-equal; default path answered by {'screen' if path_chk != 0 else 'exact'}",
         "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary, "host_cores": os.cpu_count(),
     }
-    # RCCL writes "Librccl path : ..." to the C stdout at communicator creation; with stdout redirected that sits in the C buffer until exit and
-    # would land BEHIND the JSON line.  Flush the C streams first: the JSON line is the last thing this process writes to stdout.
+    full = _denan(line)
     try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:   # noqa: BLE001
-        pass
-    sys.stdout.flush()
-    print(json.dumps(line), flush=True)
+        with open(os.path.join(ROOT, FULL_RECORD), "w") as f:
+            json.dump(full, f, indent=1, allow_nan=False)
+    except OSError as e:
+        print(f"[bench] could not write {FULL_RECORD}: {e}", file=sys.stderr)
+    print("[bench] full record: " + json.dumps(full, allow_nan=False), file=sys.stderr, flush=True)
+    guard.emit(json.dumps(compact_line(full), allow_nan=False))
     if world > 1:
         dist.destroy_process_group()
 
