@@ -3647,9 +3647,11 @@ static int conv_bf16(bf16* dst, const void* src, size_t n, float scale, hipStrea
     return RMU_OK;
 }
 
+static void quiesce(rmu_bert* m);
 extern "C" int rmu_bert_free(rmu_bert_t* m) {
+    RMU_ENTRY();
     if (!m) return RMU_OK;
-    (void)RMU_DEVICE_SYNC();
+    quiesce(m);                                  // this context's own work only -- never the whole device (rmu_common.h: captures)
     for (rmu_bert* c : m->clones) (void)rmu_bert_free(c);      // (their `owned` lists are empty: workspaces, staging, graphs, stream)
     m->clones.clear();
     for (void* p : m->owned) (void)hipFree(p);
@@ -3669,6 +3671,14 @@ extern "C" int rmu_bert_free(rmu_bert_t* m) {
     return RMU_OK;
 }
 
+// everything a context ever enqueued ran on its own stream or, left in flight by rmu_bert_encode, is marked by its tail event
+static void quiesce(rmu_bert* m) {
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->tail_set && m->tail_ev) (void)hipEventSynchronize(m->tail_ev);
+    m->tail_set = false;
+    (void)hipGetLastError();
+}
+
 // (m->mu held) see rmu_bert::tail_ev
 static int order_behind_tail(rmu_bert* m, hipStream_t s) {
     if (m->tail_set && m->tail_stream != s && hipStreamWaitEvent(s, m->tail_ev, 0) != hipSuccess) return RMU_E_HIP;
@@ -3683,6 +3693,7 @@ static int mark_tail(rmu_bert* m, hipStream_t s) {
 }
 
 extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const void* const* wptr, int n_weights) {
+    RMU_ENTRY();
     if (!out || !cfg || !wptr) return bfail(RMU_E_INVALID, "rmu_bert_create: null argument");
     if (cfg->hidden != H || cfg->heads != NH || cfg->ffn != FF || cfg->layers < 1 || cfg->layers > 48)
         return bfail(RMU_E_INVALID, "rmu_bert_create: this build supports hidden 384, 12 heads, ffn 1536");
@@ -3823,8 +3834,7 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
     if (tokens > m->ws_tokens || batch + 1 > m->ws_batch) drop_graphs(m);
     if (tokens > m->ws_tokens) {
         if (m->h) {                                   // (a fresh context -- a clone's first call -- has nothing in flight and nothing to free)
-            std::lock_guard<std::mutex> cap(rmu_capture_mutex());      // hipFree synchronises the device as well
-            (void)hipDeviceSynchronize();
+            quiesce(m);                               // the workspace's only users: this context's stream and the forward marked by its tail event
             for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->st1, (void*)m->st2})
                 if (p) (void)hipFree(p);
         }
@@ -3842,8 +3852,7 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
     }
     if (batch + 1 > m->ws_batch) {
         if (m->cu) {
-            std::lock_guard<std::mutex> cap(rmu_capture_mutex());
-            (void)hipDeviceSynchronize();
+            quiesce(m);
             (void)hipFree(m->cu);
         }
         m->cu = nullptr; m->ws_batch = 0;
@@ -4337,6 +4346,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
 
 extern "C" int rmu_bert_encode(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
                                int max_len, int mode, float* out_dev, int64_t out_stride, uint64_t hip_stream) {
+    RMU_ENTRY();
     int rc = check_encode_args(m, ids, lens, out_dev, batch, max_len, mode, out_stride);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(m->mu);
@@ -4445,7 +4455,7 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
         // one, "operation failed due to a previous error during capture" in the other) although both captures are thread-local
         bool ok;
         {
-            std::lock_guard<std::mutex> cap(rmu_capture_mutex());      // (also: never beside a device-wide synchronisation, rmu_common.h)
+            std::lock_guard<std::mutex> cap(rmu_capture_mutex());      // (one capture of this library at a time, rmu_common.h)
             ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 enqueue_all();
@@ -4475,6 +4485,7 @@ static int host_forward_locked(rmu_bert* m, const int32_t* ids, const int32_t* t
 
 extern "C" int rmu_bert_encode_host(rmu_bert_t* m, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch, int max_len,
                                     int mode, float* out_host, int64_t out_stride) {
+    RMU_ENTRY();
     int rc = check_encode_args(m, ids, lens, out_host, batch, max_len, mode, out_stride);
     if (rc) return rc;
     const int kind = mode & 0xff;
@@ -4503,6 +4514,7 @@ extern "C" int rmu_index_search_mmr_dev_(rmu_index_t* idx, const float* q_dev, i
 extern "C" int rmu_bert_search_mmr(rmu_bert_t* m, rmu_index_t* idx, const int32_t* ids, const int32_t* type_ids, const int32_t* lens, int batch,
                                    int max_len, int mode, int fetch_k, int k, double lambda_mult, int64_t row_base, int64_t* out_rows,
                                    float* out_scores, float* out_vecs) {
+    RMU_ENTRY();
     if (!idx || !out_rows) return bfail(RMU_E_INVALID, "rmu_bert_search_mmr: null argument");
     int rc = check_encode_args(m, ids, lens, out_rows, batch, max_len, mode, H);
     if (rc) return rc;

@@ -45,6 +45,7 @@ extern "C" const char* rmu_version(void) { return "librmu 0.1 gfx950"; }
 
 static int g_device = -1;
 extern "C" int rmu_init(int device_ordinal) {
+    RMU_ENTRY();
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device_ordinal < 0 || device_ordinal >= n) return fail(RMU_E_INVALID, "rmu_init: no such device");
@@ -99,7 +100,7 @@ struct Tls {
         if (hpin) (void)hipHostFree(hpin);
         hpin = nullptr; hpin_cap = 0;
         const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
-        if (hipHostMalloc((void**)&hpin, cap) != hipSuccess) return RMU_E_OOM;
+        if (hipHostMalloc((void**)&hpin, cap) != hipSuccess) { hpin = nullptr; (void)hipGetLastError(); return RMU_E_OOM; }
         hpin_cap = cap;
         return RMU_OK;
     }
@@ -138,16 +139,19 @@ struct Tls {
     // these per request: everything it owns goes back when the thread exits.
     ~Tls() {
         if (g_runtime_down) return;
+        RMU_ENTRY();
         if (pending) (void)hipEventSynchronize(pend_ev);
         if (pend_ev) (void)hipEventDestroy(pend_ev);
         if (stream) (void)hipStreamSynchronize(stream);
         for (Buf* b : {&q, &partial, &out_s, &out_r, &in_s, &in_r, &qn, &gthr, &mscratch, &qsplit, &ckeys, &flag, &nrm, &fbq, &fb_s,
-                       &fb_r, &fb_i, &mm_q, &mm_s, &mm_r, &mm_p})
+                       &fb_r, &fb_i, &mm_q, &mm_s, &mm_r, &mm_p, &gcand})
             b->release();
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : lev) (void)hipEventDestroy(e);
         if (hflag) (void)hipHostFree(hflag);
+        if (hpin) (void)hipHostFree(hpin);
+        hflag = nullptr; hpin = nullptr; hpin_cap = 0;
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -433,7 +437,46 @@ struct rmu_index {
     int64_t screen_min_nq = 0;      // RMU_OPT_SCREEN_MIN_NQ: > 0 = screen every batch of at least this many queries, whatever the corpus size
     std::vector<uint8_t> alive;
     std::shared_mutex mu;
+    // Streams on which scans of this index may still be running AFTER their call returned (a search handed a caller stream and device
+    // buffers only enqueues: rmu_index_search's `drained == false`).  One event per stream, re-recorded behind each such search.  A
+    // writer (growth, row removal, free) holds `mu` exclusively -- nothing new can start -- and waits for exactly these events instead of
+    // the whole device (round 6: hipDeviceSynchronize breaks hipGraph captures of other threads, rmu_common.h).
+    struct Reader { hipStream_t s; hipEvent_t ev; };
+    std::vector<Reader> readers;
+    std::mutex readers_mu;
 };
+
+// (shared lock held) the scans just enqueued on `s` stay in flight behind the caller's back
+static void mark_reader(rmu_index* idx, hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (st != hipStreamCaptureStatusNone) return;   // a search captured into the caller's graph: replays are the caller's to order against writers
+    std::lock_guard<std::mutex> g(idx->readers_mu);
+    for (auto& r : idx->readers)
+        if (r.s == s) { (void)hipEventRecord(r.ev, s); return; }
+    if (idx->readers.size() >= 64) {                // streams come and go (a thread per request): drop the marks whose work has ended
+        size_t w = 0;
+        for (auto& r : idx->readers) {
+            if (hipEventQuery(r.ev) == hipSuccess) (void)hipEventDestroy(r.ev);
+            else idx->readers[w++] = r;
+        }
+        (void)hipGetLastError();
+        idx->readers.resize(w);
+    }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); return; }
+    if (hipEventRecord(ev, s) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); (void)hipStreamSynchronize(s); return; }
+    idx->readers.push_back({s, ev});
+}
+// (exclusive lock held) host-side wait for every scan still in flight; `on` != nullptr: order stream `on` behind them instead (no host wait)
+static int wait_readers(rmu_index* idx, hipStream_t on = nullptr) {
+    std::lock_guard<std::mutex> g(idx->readers_mu);
+    for (auto& r : idx->readers) {
+        const hipError_t e = on ? hipStreamWaitEvent(on, r.ev, 0) : hipEventSynchronize(r.ev);
+        if (e != hipSuccess) return fail(RMU_E_HIP, std::string("waiting for the scans in flight: ") + hipGetErrorString(e));
+    }
+    return RMU_OK;
+}
 
 // The scans' LDS-DMA rings run past the last row: the exact scan reads whole 128-row tiles; the screening scan (scan_screen_lean3_kernel)
 // looks four 32-row tiles ahead of the tile it computes and does not clamp, i.e. it touches up to (ceil(n / 32) + 4) * 32 - n <= 159 rows
@@ -445,6 +488,7 @@ static int pad_dim(int d) { return d <= 192 ? 192 : (d <= 384 ? 384 : (d <= 768 
 static int pad_dim_metric(int d, int metric) { return pad_dim(metric == RMU_METRIC_L2SQ ? d + 1 : d); }
 
 extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t capacity_hint) {
+    RMU_ENTRY();
     if (!out) return fail(RMU_E_INVALID, "rmu_index_create: out is null");
     if (dim < 1 || dim > RMU_MAX_DIM) return fail(RMU_E_INVALID, "rmu_index_create: dim must be in [1, 768]");
     if (metric != RMU_METRIC_IP && metric != RMU_METRIC_COSINE && metric != RMU_METRIC_L2SQ)
@@ -493,16 +537,19 @@ extern "C" int rmu_index_create(rmu_index_t** out, int dim, int metric, int64_t 
 }
 
 extern "C" int rmu_index_free(rmu_index_t* idx) {
+    RMU_ENTRY();
     if (!idx) return RMU_OK;
     {
         std::unique_lock<std::shared_mutex> lk(idx->mu);
-        (void)RMU_DEVICE_SYNC();
+        (void)wait_readers(idx);          // scans still in flight on callers' streams (everything else ended under the shared lock)
         if (idx->x) (void)hipFree(idx->x);
         if (idx->split) (void)hipFree(idx->split);
         if (idx->nrm) (void)hipFree(idx->nrm);
         idx->x = nullptr;
         idx->split = nullptr;
         idx->nrm = nullptr;
+        for (auto& r : idx->readers) (void)hipEventDestroy(r.ev);
+        idx->readers.clear();
     }
     delete idx;
     return RMU_OK;
@@ -547,7 +594,10 @@ static int grow(rmu_index* idx, int64_t need) {
         if (hipMalloc((void**)&nx, (size_t)(cap + kSlackRows) * idx->dpad * sizeof(float)) != hipSuccess)
             return fail(RMU_E_OOM, "rmu_index_add: hipMalloc for growth");
     }
-    HIP_TRY(RMU_DEVICE_SYNC());  // nobody may still be scanning the old matrix
+    // nobody may still be scanning the old matrix when it is freed below: searches on internal streams ended under the shared lock, the
+    // ones left in flight on callers' streams are waited for one by one -- never the whole device (rmu_common.h: captures)
+    int wrc = wait_readers(idx);
+    if (wrc) { (void)rmu_free(nx); return wrc; }
     hipStream_t s = g_tls.stream;     // same stream as the uploads that follow (see rmu_index_create)
     HIP_TRY(hipMemsetAsync(nx + idx->n * idx->dpad, 0, (size_t)(cap + kSlackRows - idx->n) * idx->dpad * sizeof(float), s));
     if (idx->n)
@@ -589,6 +639,7 @@ static int grow(rmu_index* idx, int64_t need) {
 }
 
 extern "C" int rmu_index_reserve(rmu_index_t* idx, int64_t rows) {
+    RMU_ENTRY();
     if (!idx || rows < 0) return fail(RMU_E_INVALID, "rmu_index_reserve: bad argument");
     if (rows > 0xFFFFFFF0ll) return fail(RMU_E_INVALID, "rmu_index_reserve: row ids are 32-bit inside the scan");
     int rc = g_tls.ensure_stream();
@@ -649,6 +700,7 @@ static void fold_image_stats(rmu_index_t* idx) {
 }
 
 extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int is_device, int64_t* first_row) {
+    RMU_ENTRY();
     if (!idx || (!vecs && n > 0) || n < 0) return fail(RMU_E_INVALID, "rmu_index_add: bad argument");
     int rc = g_tls.ensure_stream();
     if (rc) return fail(rc, "rmu_index_add: stream");
@@ -687,6 +739,7 @@ extern "C" int rmu_index_add(rmu_index_t* idx, const float* vecs, int64_t n, int
 }
 
 extern "C" int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, int64_t* n_removed) {
+    RMU_ENTRY();
     if (!idx || (!rows && n > 0) || n < 0) return fail(RMU_E_INVALID, "rmu_index_remove_rows: bad argument");
     int rc = g_tls.ensure_stream();
     if (rc) return fail(rc, "rmu_index_remove_rows: stream");
@@ -702,7 +755,8 @@ extern "C" int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int6
     Buf& b = g_tls.in_r;
     if (b.ensure(todo.size() * sizeof(int64_t))) return fail(RMU_E_OOM, "rmu_index_remove_rows: workspace");
     hipStream_t s = g_tls.stream;
-    HIP_TRY(RMU_DEVICE_SYNC());
+    rc = wait_readers(idx, s);        // the poison kernels are ordered behind the scans still in flight on callers' streams
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(b.p, todo.data(), todo.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_poison_rows, dim3((unsigned)todo.size()), dim3(128), 0, s, idx->x, idx->dpad,
                        (const int64_t*)b.p, (int64_t)todo.size());
@@ -716,6 +770,7 @@ extern "C" int rmu_index_remove_rows(rmu_index_t* idx, const int64_t* rows, int6
 }
 
 extern "C" int rmu_index_get_rows(rmu_index_t* idx, const int64_t* rows, int64_t n, float* out_host) {
+    RMU_ENTRY();
     if (!idx || (!rows && n > 0) || (!out_host && n > 0) || n < 0)
         return fail(RMU_E_INVALID, "rmu_index_get_rows: bad argument");
     if (n == 0) return RMU_OK;
@@ -756,6 +811,7 @@ static void launch_mmr(const rmu_index* idx, const float* dq, const int64_t* dr,
 
 extern "C" int rmu_index_mmr(rmu_index_t* idx, const float* q, int64_t nq, const int64_t* rows, int fetch_k, int k,
                              double lambda_mult, unsigned flags, int32_t* out_pos) {
+    RMU_ENTRY();
     if (!idx || !q || !rows || !out_pos) return fail(RMU_E_INVALID, "rmu_index_mmr: null pointer");
     if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1) return fail(RMU_E_INVALID, "rmu_index_mmr: nq >= 1, fetch_k in [1, 64], k >= 1");
     Tls& t = g_tls;
@@ -832,6 +888,7 @@ static int search_mmr_on(rmu_index_t* idx, const float* q, bool q_dev, int64_t n
 
 extern "C" int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
                                     int64_t* out_rows, float* out_scores) {
+    RMU_ENTRY();
     if (!idx || !q || !out_rows) return fail(RMU_E_INVALID, "rmu_index_search_mmr: null pointer");
     if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1 || k > fetch_k)
         return fail(RMU_E_INVALID, "rmu_index_search_mmr: nq >= 1, fetch_k in [1, 64], k in [1, fetch_k]");
@@ -845,6 +902,7 @@ extern "C" int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq
 // bert.hip (rmu_bert_search_mmr): the same behind an encoder forward -- DEVICE queries on the encoder's stream
 extern "C" int rmu_index_search_mmr_dev_(rmu_index_t* idx, const float* q_dev, int64_t nq, int fetch_k, int k, double lambda_mult, int64_t row_base,
                                          int64_t* out_rows, float* out_scores, void* hip_stream) {
+    RMU_ENTRY();
     if (!idx || !q_dev || !out_rows || !hip_stream) return fail(RMU_E_INVALID, "rmu_bert_search_mmr: null pointer");
     if (nq < 1 || fetch_k < 1 || fetch_k > 64 || k < 1 || k > fetch_k)
         return fail(RMU_E_INVALID, "rmu_bert_search_mmr: nq >= 1, fetch_k in [1, 64], k in [1, fetch_k]");
@@ -868,6 +926,7 @@ struct RmuFileHeader {
 static_assert(sizeof(RmuFileHeader) == 64, "header");
 
 extern "C" int rmu_index_save(rmu_index_t* idx, const char* path) {
+    RMU_ENTRY();
     if (!idx || !path) return fail(RMU_E_INVALID, "rmu_index_save: null argument");
     int rc = g_tls.ensure_stream();
     if (rc) return fail(rc, "rmu_index_save: stream");
@@ -884,7 +943,8 @@ extern "C" int rmu_index_save(rmu_index_t* idx, const char* path) {
     std::vector<char> host(ok ? (size_t)std::min<int64_t>(chunk, std::max<int64_t>(idx->n, 1)) * rowb : 0);
     for (int64_t r0 = 0; ok && r0 < idx->n; r0 += chunk) {
         const int64_t nr = std::min<int64_t>(chunk, idx->n - r0);
-        if (hipMemcpy(host.data(), (const char*)idx->x + r0 * rowb, (size_t)nr * rowb, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (hipMemcpyAsync(host.data(), (const char*)idx->x + r0 * rowb, (size_t)nr * rowb, hipMemcpyDeviceToHost, g_tls.stream) != hipSuccess ||
+            hipStreamSynchronize(g_tls.stream) != hipSuccess) {
             fclose(f);
             return fail(RMU_E_HIP, "rmu_index_save: device read");
         }
@@ -895,6 +955,7 @@ extern "C" int rmu_index_save(rmu_index_t* idx, const char* path) {
 }
 
 extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
+    RMU_ENTRY();
     if (!out || !path) return fail(RMU_E_INVALID, "rmu_index_load: null argument");
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RMU_E_INVALID, std::string("rmu_index_load: cannot open ") + path);
@@ -916,7 +977,7 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
     for (int64_t r0 = 0; ok && r0 < h.n; r0 += chunk) {
         const int64_t nr = std::min<int64_t>(chunk, h.n - r0);
         ok = fread(host.data(), rowb, (size_t)nr, f) == (size_t)nr;
-        if (ok && hipMemcpy((char*)idx->x + r0 * rowb, host.data(), (size_t)nr * rowb, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        if (ok && hipMemcpyAsync((char*)idx->x + r0 * rowb, host.data(), (size_t)nr * rowb, hipMemcpyHostToDevice, s) != hipSuccess) ok = false;
         if (ok) ok = build_image(idx, r0, nr, s) == RMU_OK;
         if (ok && hipStreamSynchronize(s) != hipSuccess) ok = false;
         if (ok) fold_image_stats(idx);
@@ -1087,6 +1148,7 @@ static std::vector<int64_t> deep_bounds(int64_t n) {
 
 extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, int k, unsigned flags, int64_t row_base,
                                 float* out_scores, int64_t* out_rows, uint64_t hip_stream) {
+    RMU_ENTRY();
     if (!idx || !q || !out_scores || !out_rows) return fail(RMU_E_INVALID, "rmu_index_search: null pointer");
     if (nq < 1) return fail(RMU_E_INVALID, "rmu_index_search: nq must be >= 1");
     if (k < 1 || k > RMU_MAX_K) return fail(RMU_E_INVALID, "rmu_index_search: k must be in [1, 112]");
@@ -1296,6 +1358,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
         // device outputs and a single block nothing here waits: the work is merely ordered on that stream.
         const bool drained = !hip_stream || q0 + nb < nq || !out_dev;
         if (drained) HIP_TRY(hipStreamSynchronize(s));
+        else mark_reader(idx, s);
         t.finished(s, drained);
         if (screened) {   // the count of re-run queries is unknown while a caller's stream still runs: reported as 0 then
             any_screened = true;
@@ -1323,6 +1386,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
 // checked ON THE HARDWARE against fp32 scores computed independently (tests/test_search_gpu.py).
 extern "C" int rmu_index_screen_candidates(rmu_index_t* idx, const float* q_host, int64_t nq, float* out_approx, int64_t* out_rows,
                                            float* out_exact, float* out_eps) {
+    RMU_ENTRY();
     if (!idx || !q_host || !out_approx || !out_rows || !out_exact || !out_eps) return fail(RMU_E_INVALID, "rmu_index_screen_candidates: null pointer");
     if (nq < 1 || nq > kMaxQueriesPerLaunch) return fail(RMU_E_INVALID, "rmu_index_screen_candidates: 1 <= nq <= 8192");
     Tls& t = g_tls;
@@ -1387,6 +1451,7 @@ extern "C" int rmu_index_metric(rmu_index_t* idx, int* metric) {
 
 extern "C" int rmu_topk_merge(const float* scores, const int64_t* rows, int parts, int64_t nq, int k, unsigned flags,
                               float* out_scores, int64_t* out_rows, uint64_t hip_stream) {
+    RMU_ENTRY();
     if (!scores || !rows || !out_scores || !out_rows) return fail(RMU_E_INVALID, "rmu_topk_merge: null pointer");
     if (parts < 1 || nq < 1 || k < 1 || k > 128) return fail(RMU_E_INVALID, "rmu_topk_merge: parts/nq >= 1, k in [1,128]");
     Tls& t = g_tls;

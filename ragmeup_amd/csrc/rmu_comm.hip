@@ -83,6 +83,7 @@ struct rmu_comm {
 static_assert(RMU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique-id size");
 
 extern "C" int rmu_comm_unique_id(void* id_out) {
+    RMU_ENTRY();
     if (!id_out) return cfail(RMU_E_INVALID, "rmu_comm_unique_id: null");
     const RcclApi& api = rccl();
     if (!api.error.empty()) return cfail(RMU_E_RCCL, api.error);
@@ -105,6 +106,7 @@ struct CommDeviceScope {
 };
 
 extern "C" int rmu_comm_free(rmu_comm_t* c) {
+    RMU_ENTRY();
     if (!c) return RMU_OK;
     CommDeviceScope dev(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -117,6 +119,7 @@ extern "C" int rmu_comm_free(rmu_comm_t* c) {
 }
 
 extern "C" int rmu_comm_init(rmu_comm_t** out, const void* id, int world, int rank) {
+    RMU_ENTRY();
     if (!out || !id) return cfail(RMU_E_INVALID, "rmu_comm_init: null argument");
     if (world < 1 || rank < 0 || rank >= world) return cfail(RMU_E_INVALID, "rmu_comm_init: need 0 <= rank < world");
     const RcclApi& api = rccl();
@@ -158,6 +161,7 @@ extern "C" int rmu_comm_world(rmu_comm_t* c, int* world, int* rank) {
 
 extern "C" int rmu_shard_allgather_topk(rmu_comm_t* c, const float* scores, const int64_t* rows, int64_t nq, int k, unsigned flags,
                                         float* out_scores, int64_t* out_rows, uint64_t hip_stream) {
+    RMU_ENTRY();
     if (!c || !scores || !rows || !out_scores || !out_rows) return cfail(RMU_E_INVALID, "rmu_shard_allgather_topk: null pointer");
     if (nq < 1 || k < 1 || k > 128) return cfail(RMU_E_INVALID, "rmu_shard_allgather_topk: nq >= 1, k in [1,128]");
     const RcclApi& api = rccl();

@@ -121,21 +121,35 @@ inline const char* rmu_env(const char* name) {
 // the more conservative path.
 inline const char* rmu_env_kill(const char* name) { return getenv(name); }
 
-// A hipGraph capture (the host-path forwards of bert.hip, thread-local mode) and a DEVICE-WIDE synchronisation from another thread do not mix on
-// this runtime: the synchronisation reports "operation not permitted when stream is capturing", the capture is invalidated and its stream can
-// stay in capture mode (seen: query threads on clone contexts while another clone sized its workspace).  Captures are rare (once per shape and
-// context) and device-wide synchronisations are rarer: both take this mutex.
+// ---- hipGraph captures in the same process (round 6; measured: tools/ubench/capture_probe.hip -> profiles/r06_capture_probe.txt) ----------
+// The reference runs its LLM (PyTorch) on the same GPU and in the same process as this library (server/RAGHelper_local.py:42-105); a
+// torch.cuda.graph capture there uses the GLOBAL capture mode.  On ROCm 7 a second thread whose capture-interaction mode is the default
+// invalidates such a capture with nearly any synchronous call (hipMalloc, hipFree, hipStreamSynchronize, hipEventSynchronize,
+// hipEventQuery, hipHostMalloc ...); with the thread's mode exchanged to RELAXED -- what PyTorch's own allocator does around
+// cudaMalloc -- every one of them is harmless, EXCEPT hipDeviceSynchronize and the synchronous (pageable) hipMemcpy / hipMemset, which
+// break a capture on another thread in every mode (and did break this library's own thread-local captures in round 5).  Hence:
+//   1. every entry point runs under RMU_ENTRY(): the calling thread is in relaxed mode for the duration of the call;
+//   2. the library never calls hipDeviceSynchronize, hipMemcpy or hipMemset: it waits for exactly the streams / events that used a
+//      buffer (the index's reader events, a context's tail event) and copies with hipMemcpyAsync + hipStreamSynchronize.
+struct RmuRelaxedCapture {
+    hipStreamCaptureMode m = hipStreamCaptureModeRelaxed;
+    RmuRelaxedCapture() { (void)hipThreadExchangeStreamCaptureMode(&m); }
+    ~RmuRelaxedCapture() { (void)hipThreadExchangeStreamCaptureMode(&m); }
+    RmuRelaxedCapture(const RmuRelaxedCapture&) = delete;
+    RmuRelaxedCapture& operator=(const RmuRelaxedCapture&) = delete;
+};
+#define RMU_ENTRY() RmuRelaxedCapture rmu_relaxed_capture_
+// This library's own captures (the host-path forwards of bert.hip, thread-local mode) are taken one at a time (round 5: two threads
+// capturing at once failed 1 run in 4 on this runtime).
 inline std::mutex& rmu_capture_mutex() {
-    static std::mutex* mu = new std::mutex;      // (never destroyed: thread-local workspaces are released through it while the process winds down)
+    static std::mutex* mu = new std::mutex;      // (never destroyed: thread-local workspaces are released while the process winds down)
     return *mu;
 }
-// hipFree waits for the device like hipDeviceSynchronize does: the same exclusion
+// hipFree waits for the device by itself; in relaxed mode it leaves captures of other threads alone (probe above)
 inline hipError_t rmu_free(void* p) {
-    std::lock_guard<std::mutex> rmu_cap_(rmu_capture_mutex());
+    RMU_ENTRY();
     return hipFree(p);
 }
-// hipDeviceSynchronize that never overlaps a capture of this library
-#define RMU_DEVICE_SYNC() ([] { std::lock_guard<std::mutex> rmu_cap_(rmu_capture_mutex()); return hipDeviceSynchronize(); }())
 
 // ---- launch descriptors shared between rmu_api.hip and the kernel translation units -------------
 // Device-side launch predicate.  The screening path decides per query ON THE DEVICE whether the exact scan has to re-run

@@ -450,31 +450,51 @@ class MI355XVectorStore(VectorStore):
                 it[4].set_exception(e)
 
         rounds = 0
-        cur = None
-        while True:
-            if cur is None:
-                items, total = take()
-                if not items:
-                    return
-                cur = self._start_round(items, total, rounds)
-                rounds += 1
+        cur = nxt = None
+        try:
+            while True:
                 if cur is None:
-                    continue
-            nxt = None
-            if cur[2] is not None:
-                # the forward is in flight.  When it ENDS, whatever has queued up meanwhile goes straight behind it -- before this round's rows
-                # are appended and its callers released (taking the next round any earlier would cut the queue short: a round is as large
-                # as the calls that arrived during the previous forward, which is what keeps the forwards at pipeline-block size)
-                cur[2][1].synchronize()
-                items2, total2 = take()
-                if items2:
-                    nxt = self._start_round(items2, total2, rounds)
+                    items, total = take()
+                    if not items:
+                        return
+                    cur = self._start_round(items, total, rounds)
                     rounds += 1
-            self._finish_round(*cur)
-            cur = nxt
+                    if cur is None:
+                        continue
+                nxt = None
+                held = None
+                if cur[2] is not None:
+                    # the forward is in flight.  When it ENDS, whatever has queued up meanwhile goes straight behind it -- before this round's
+                    # rows are appended and its callers released (taking the next round any earlier would cut the queue short: a round is as
+                    # large as the calls that arrived during the previous forward, which is what keeps the forwards at pipeline-block size)
+                    cur[2][1].synchronize()
+                    items2, total2 = take()
+                    if items2:
+                        # a failure to START the next round must not skip the healthy round in front of it (its forward has finished): the
+                        # failure is recorded only after `cur` is appended, so only rounds BEHIND the failing one are rolled back
+                        nxt = self._start_round(items2, total2, rounds, defer_failure=True)
+                        rounds += 1
+                        if isinstance(nxt, _DeferredFailure):
+                            held, nxt = nxt, None
+                self._finish_round(*cur)
+                cur = None
+                if held is not None:
+                    self._round_failed(held.items, held.error)
+                cur = nxt
+        except BaseException as e:   # noqa: BLE001 - e.g. an asynchronous HIP error surfacing at the event wait: nobody may be left waiting
+            stuck = [r for r in (cur, nxt) if r is not None and not isinstance(r, _DeferredFailure)]
+            with self._wlock:
+                rest, self._work[:] = list(self._work), []
+            for r in stuck:
+                self._round_failed([it for it in r[0] if not it[4].done()], e)
+            if rest:
+                self._round_failed(rest, e)
+            if not stuck and not rest:
+                self._pipe_failed = True
 
-    def _start_round(self, items, total, round_no):
-        """-> (items, (ids, lens), in-flight handle | None), or None when the round was refused / failed before it started"""
+    def _start_round(self, items, total, round_no, defer_failure: bool = False):
+        """-> (items, (ids, lens), in-flight handle | None), or None when the round was refused / failed before it started
+        (defer_failure: a failure comes back as _DeferredFailure instead of being recorded -- the pump records it once the round in front is in)"""
         import contextlib
         import numpy as np
         emb = self._embeddings
@@ -509,6 +529,8 @@ class MI355XVectorStore(VectorStore):
                 lens = np.concatenate([it[0][1] for it in items])
             return items, (ids, lens), None
         except BaseException as e:
+            if defer_failure:
+                return _DeferredFailure(items, e)
             self._round_failed(items, e)
             return None
 
@@ -913,6 +935,13 @@ class _RowsOutOfStep(Exception):
         super().__init__(first, total)
         self.first = first          # the row the index gave the batch
         self.total = total          # rows the batch added there (tombstoned by the worker)
+
+
+class _DeferredFailure:
+    """A round of the insert pipeline that failed to start while the round in front of it was still to be appended."""
+
+    def __init__(self, items, error):
+        self.items, self.error = items, error
 
 
 class _DeleteResult(int):

@@ -758,3 +758,77 @@ def test_a_failure_after_the_rows_were_appended_tombstones_them_and_an_interrupt
     emb.gate.set()
     assert len(pip) == 400 and len(pip._index) == len(pip._texts) == 550
 
+
+
+class EnqueueEmbeddings(TokenEmbeddings):
+    """TokenEmbeddings with the in-flight interface of the native encoder (enqueue_token_arrays -> (vectors, done-event))."""
+
+    class _Done:
+        def __init__(self, owner, no):
+            self.owner, self.no = owner, no
+
+        def synchronize(self):
+            self.owner.entered.set()
+            assert self.owner.gate.wait(20)
+            if self.owner.sync_fails_on == self.no:
+                raise RuntimeError("HIP error at the event wait")
+
+    def __init__(self):
+        super().__init__()
+        self.sync_fails_on, self.enqueue_fails_on, self.enqueued = None, None, []
+
+    def enqueue_token_arrays(self, toks, round_no):
+        if self.enqueue_fails_on == round_no:
+            raise MemoryError("staging upload failed")
+        ids = np.concatenate([t[0] for t in toks])
+        self.enqueued.append(len(ids))
+        v = np.stack([np.random.default_rng(int(s)).standard_normal(384) for s in ids[:, 0]])
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32), self._Done(self, round_no)
+
+
+def test_an_error_at_the_pumps_event_wait_resolves_every_future_and_nobody_hangs():
+    """the wait for the in-flight forward sits outside _start_round/_finish_round; an asynchronous device error
+    surfacing there must fail the round, the round queued behind it and everything still in the work list -- flush() raises, it does not block."""
+    emb = EnqueueEmbeddings()
+    pip = PipeStore(embeddings=emb, collection_name="evt", auto_persist=False)
+    pip.pipeline_depth = 8
+    emb.gate.clear(); emb.entered.clear(); emb.sync_fails_on = 0
+    pip.add_documents(_docs(0, 200), ids=[str(i) for i in range(200)])
+    assert emb.entered.wait(20)
+    pip.add_documents(_docs(200, 400), ids=[str(i) for i in range(200, 400)])
+    pip.add_documents(_docs(400, 600), ids=[str(i) for i in range(400, 600)])
+    emb.gate.set()
+    done = threading.Event()
+    err = []
+
+    def waiter():
+        try:
+            pip.flush()
+        except BaseException as e:   # noqa: BLE001
+            err.append(e)
+        done.set()
+    threading.Thread(target=waiter, daemon=True).start()
+    assert done.wait(30), "flush() blocked: a future of the failed pump was never resolved"
+    assert err and "event wait" in str(err[0])
+    emb.sync_fails_on = None
+    assert not pip._pending and len(pip._texts) == len(pip._index) == 0
+    pip.add_documents(_docs(0, 200), ids=[str(i) for i in range(200)])        # the store carries on
+    assert len(pip) == 200
+
+
+def test_a_next_round_that_fails_to_start_does_not_skip_the_finished_round_in_front():
+    """round 0's forward has finished when round 1's upload fails; round 0's rows stay inserted, round 1 (and what is behind
+    it) is rolled back, and the caller sees round 1's real exception."""
+    emb = EnqueueEmbeddings()
+    pip = PipeStore(embeddings=emb, collection_name="nxt", auto_persist=False)
+    pip.pipeline_depth = 8
+    emb.gate.clear(); emb.entered.clear(); emb.enqueue_fails_on = 1
+    pip.add_documents(_docs(0, 200), ids=[str(i) for i in range(200)])
+    assert emb.entered.wait(20)
+    pip.add_documents(_docs(200, 400), ids=[str(i) for i in range(200, 400)])
+    emb.gate.set()
+    with pytest.raises(MemoryError, match="staging upload failed"):
+        pip.flush()
+    emb.enqueue_fails_on = None
+    assert emb.enqueued == [200]
+    assert len(pip) == len(pip._index) == len(pip._texts) == 200 and "199" in pip._pk_to_row and "200" not in pip._pk_to_row

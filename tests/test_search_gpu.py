@@ -1045,3 +1045,87 @@ def test_repeated_searches_into_caller_owned_tensors_stay_exact(rmu):
         idx.search(qd, 10, out=(out[0][:10], out[1]))
     idx.close()
 
+
+
+def test_a_torch_graph_capture_on_another_thread_survives_growth_removal_search_and_free(rmu):
+    """VERDICT r5 next-4 / SURVEY 8b ("all entry points thread-safe"), server/RAGHelper_local.py:42-105: the reference's LLM runs in PyTorch in
+    the same process and on the same GPU; a torch.cuda.graph capture there (GLOBAL capture mode) is invalidated by a hipDeviceSynchronize or a
+    synchronous hipMemcpy on ANY thread, and by most synchronous HIP calls of a thread in the default capture-interaction mode
+    (profiles/r06_capture_probe.txt).  The library now waits for exactly the streams that used a buffer and runs every entry point in relaxed
+    mode: while thread A is INSIDE a capture, thread B creates an index, appends (several re-allocations), searches on its internal stream and
+    on a caller stream left in flight, tombstones rows, saves / loads and frees -- ten rounds; every capture instantiates and replays with
+    the right numbers and every search is exact."""
+    import ctypes
+    import tempfile
+    import torch
+    from ragmeup_amd import _native as N
+    x = O.make_corpus(24_000)
+    q, _ = O.make_queries(x, 32)
+    want = O.flat_search(q, x, 12)
+    # everything thread B needs from torch exists BEFORE the captures start (a torch allocation or H2D copy on B would be torch's own
+    # interference with torch's capture, not this library's)
+    qd = torch.from_numpy(q).cuda()
+    out_s = torch.empty((32, 10), dtype=torch.float32, device="cuda")
+    out_r = torch.empty((32, 10), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    a = torch.randn((256, 256), device="cuda")
+    b = torch.randn((256, 256), device="cuda")
+    ref = (a * b + 1.0).relu().cpu()        # (elementwise only: a first rocBLAS call inside a capture on a fresh thread crashes in torch itself)
+    torch.cuda.synchronize()
+    errs = []
+    tmp = tempfile.mkdtemp()
+    for rnd in range(10):
+        inside, proceed = threading.Event(), threading.Event()
+
+        def capturer():
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):                  # capture_error_mode="global" (the default)
+                    y = a * b
+                    inside.set()
+                    assert proceed.wait(120)
+                    y = (y + 1.0).relu()
+                g.replay()
+                torch.cuda.synchronize()
+                if not torch.allclose(y.cpu(), ref, atol=1e-3):
+                    errs.append(("capture replay wrong", rnd))
+            except Exception as e:   # noqa: BLE001
+                errs.append(("capturer", rnd, repr(e)))
+            finally:
+                inside.set()
+
+        def library_user():
+            try:
+                assert inside.wait(120)
+                idx = rmu.FlatIndex(384, capacity_hint=16)                       # hipMalloc + zero fill
+                for lo in range(0, 24_000, 3000):                                # re-allocations: old matrices freed behind reader events
+                    idx.add(x[lo:lo + 3000])
+                    if lo == 9000:                                               # a search left IN FLIGHT on a caller stream, then growth behind it
+                        N.check(N.lib().rmu_index_search(idx._h, qd.data_ptr(), 32, 10, N.F_Q_DEVICE | N.F_OUT_DEVICE, 0, out_s.data_ptr(),
+                                                         out_r.data_ptr(), side.cuda_stream), "rmu_index_search")
+                assert idx.stats()["grow_count"] >= 5
+                s, r = idx.search(q, 10)                                         # internal stream, host buffers
+                assert_topk_parity(s, r, *want)
+                dead = np.unique(r[:, 0])
+                assert idx.remove_rows(dead) == dead.size
+                s2, r2 = idx.search(q, 10)
+                assert not np.isin(r2, dead).any()
+                p = os.path.join(tmp, f"cap{rnd}.rmu")
+                idx.save(p)
+                idx.close()                                                      # hipFree x3
+                back = rmu.FlatIndex.load(p)
+                s3, r3 = back.search(q, 10)
+                assert np.array_equal(r3, r2) and np.array_equal(s3, s2)
+                back.close()
+            except Exception as e:   # noqa: BLE001
+                errs.append(("library", rnd, repr(e)))
+            finally:
+                proceed.set()
+
+        ts = [threading.Thread(target=capturer), threading.Thread(target=library_user)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+    side.synchronize()
+    # the search that was left in flight over 12 000 rows while the matrix was re-allocated under it read the OLD matrix to the end
+    assert_topk_parity(out_s.cpu().numpy(), out_r.cpu().numpy(), *O.flat_search(q, x[:12_000], 12))
