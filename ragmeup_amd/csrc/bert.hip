@@ -3452,6 +3452,352 @@ __global__ __launch_bounds__(256, OCC) void k_attn4(const bf16* __restrict__ qkv
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_qa -- the bulk path's QKV projection AND attention in ONE launch (round 6).  Per layer k_gemm3 wrote 2.4 GB of
+// Q | K | V that k_attn3 read back 1 ms later (14.4 GB written + 14.6 GB fetched per forward, 98k cold workgroups each waiting for its
+// 64-byte row pieces): here Q, K and V never leave the CU.
+//   * Workgroup = one ITEM: up to 8 token tiles of 32 (wave w <-> tile slot w) from consecutive WHOLE sequences (k_qa_items packs them
+//     greedily: a 128-token sequence fills 4 slots, two of them share a workgroup and its weight stream).  8 waves, two per SIMD.
+//   * A wave keeps its 32 token rows as 24 MFMA B fragments in registers for the whole kernel (96, as k_ffn3 does).
+//   * The layer's Wq | Wk | Wv arrive as the k_pack_qa stream -- per head 72 fragments of 1 KiB in consumption order (k-step major,
+//     then Q / K / V), 3 slabs of 24 -- through a 3-slab LDS-DMA ring (72 KiB); wave w moves pieces w, w + 8, w + 16 of a slab; ONE
+//     barrier per slab (slab g landed for everybody; everybody is done with slab g - 1, whose slot takes slab g + 2).
+//   * Per head: 72 v_mfma_f32_32x32x16_bf16 (A = weight fragment from the ring, B = token fragment) into three accumulators
+//     [32 features of Q / K / V][32 tokens]; bias + bf16 rounding exactly as k_gemm3's epilogue; Q goes back into the wave's registers
+//     as the two B fragments of S^T = K Q^T (one exchange with lane ^ 32), K rows and V^T go into the LDS images k_attn3 stages from
+//     global memory -- same layout, keys of slot s at rows [32 s, +32) -- one barrier, then k_attn3's two-pass attention of the wave's
+//     query tile against the key tiles of ITS sequence, unchanged arithmetic.  The images are double-buffered over the heads (one
+//     barrier per head; a wave may run ahead into the next head's projection).
+// Bit-identical to k_gemm3 + k_attn3 (same summation orders and rounding points): tests compare the two paths exactly.
+// Wait counting (vmcnt counts this wave's LDS-DMA instructions and its ctx stores, in order): at the barrier of slab g the instructions
+// of slab g + 1 (3) may stay in flight; the two ctx stores of the previous head are younger still, so vmcnt(3) can only over-wait.
+// ------------------------------------------------------------------------------------------------------------
+namespace qa {
+constexpr int SLOTS = 8;
+constexpr int SLAB = 24 * 1024, NSLAB = 3, RING = NSLAB * SLAB;
+constexpr int HEAD_SLABS = 3, LAYER_SLABS = NH * HEAD_SLABS;
+constexpr int KS_BYTES = SLOTS * 32 * 64;
+constexpr int VSTR = SLOTS * 32 * 2 + 16;
+constexpr int VT_BYTES = 32 * VSTR;
+constexpr int IMG = KS_BYTES + VT_BYTES;
+constexpr int BIAS_OFF = RING + 2 * IMG;          // the layer's 1152 Q | K | V biases, fp32: the epilogue of every head reads 96 of them
+constexpr int LDS_BYTES = BIAS_OFF + 3 * H * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+}  // namespace qa
+
+// the layer's [1152][384] Q | K | V weight rows -> k_qa's stream: [head][fragment f = 3 * kstep + part][lane] 16-byte units, fragment
+// (part, kstep) lane (r31, hh) = row part * 384 + 32 head + r31, k [16 kstep + 8 hh, +8).  One thread per unit.
+__global__ void k_pack_qa(const bf16* __restrict__ wqkv, bf16* __restrict__ dst) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= 3 * H * H / 8) return;
+    const int lane = d & 63, f = (d >> 6) % 72, head = (d >> 6) / 72;
+    const int ks = f / 3, part = f % 3, r31 = lane & 31, hh = lane >> 5;
+    *(bf16x8*)(dst + (int64_t)d * 8) = *(const bf16x8*)(wqkv + (int64_t)(part * H + head * DH + r31) * H + ks * 16 + hh * 8);
+}
+
+// items[i] = (first sequence, sequences) of workgroup i of k_qa; *n_items = their number.  A thread packs a run of >= 32 consecutive
+// sequences greedily (a new item when the next sequence's tiles no longer fit the 8 slots); runs are independent, so the last item of
+// a run may stay part empty (1 item in ~18).  One workgroup; batch <= 65536.
+__global__ __launch_bounds__(1024) void k_qa_items(const int* __restrict__ cu, int batch, int2* __restrict__ items, int* __restrict__ n_items) {
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x;
+    const int per = max(32, (batch + 1023) / 1024);
+    const int lo = min(batch, t * per), hi = min(batch, lo + per);
+    auto walk = [&](int base, bool emit) {
+        int n = 0, start = lo, tiles = 0;
+        for (int b = lo; b < hi; ++b) {
+            const int nt = (cu[b + 1] - cu[b] + 31) >> 5;
+            if (tiles > 0 && tiles + nt > qa::SLOTS) {
+                if (emit) items[base + n] = int2{start, b - start};
+                ++n; start = b; tiles = 0;
+            }
+            tiles += nt;
+        }
+        if (tiles > 0) { if (emit) items[base + n] = int2{start, hi - start}; ++n; }
+        return n;
+    };
+    const int mine = walk(0, false);
+    cnt[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {          // inclusive scan
+        const int v = t >= o ? cnt[t - o] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    walk(cnt[t] - mine, true);
+    if (t == 1023) *n_items = cnt[1023];
+}
+
+__global__ __launch_bounds__(512) void k_qa(const bf16* __restrict__ x, int x_tiled, const bf16* __restrict__ wstream, const float* __restrict__ bias,
+                                            const int* __restrict__ cu, const int2* __restrict__ items, const int* __restrict__ n_items,
+                                            bf16* __restrict__ ctx, int ctx_tiled, int dflags) {
+    // dflags (RMU_QA_DBG, timing ablations only -- results are wrong with any bit set): 1 no attention, 2 no projection MFMAs / fragment reads,
+    // 4 no epilogue (bias, pack, image writes), 8 no weight DMA
+    using namespace qa;
+    using ffn::static_for; using ffn::sgpr_ptr;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    if ((int)blockIdx.x >= *n_items) return;
+    const int2 item = items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c31 = lane & 31, hh = lane >> 5;
+    // ---- this wave's tile: sequence b, query tile qt of it, the sequence's first slot s0 / length L / first token t0 ------------------
+    int b = -1, qt = 0, s0 = 0, L = 0, t0 = 0;
+    {
+        int slot = 0;
+        for (int i = 0; i < item.y; ++i) {
+            const int a = cu[item.x + i], l = cu[item.x + i + 1] - a, nt = (l + 31) >> 5;
+            if (w >= slot && w < slot + nt) { b = item.x + i; qt = w - slot; s0 = slot; L = l; t0 = a; }
+            slot += nt;
+        }
+    }
+    const bool active = b >= 0;                    // (wave-uniform) a wave without a tile still moves its ring pieces and meets the barriers
+    const int nkt = (L + 31) >> 5;
+
+    // ---- the weight stream ------------------------------------------------------------------------------------------------------
+    const u32 lane16 = (u32)lane * 16;
+    auto issue = [&](int g, int slot) {              // slab g of the layer's stream -> ring slot `slot` (= g % 3, a literal at every call site)
+        const char* src = (const char*)wstream + (size_t)g * SLAB + (size_t)w * 1024;
+        char* dst = gsm + slot * SLAB + w * 1024;
+        if (dflags & 8) return;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            u32 o = lane16;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sgpr_ptr(src + i * 8192) + o),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    issue(1, 1);
+    float* bl = (float*)(gsm + BIAS_OFF);
+    for (int i = tid; i < 3 * H; i += 512) bl[i] = bias[i];      // (six dependent scalar-load round trips per head and wave when read from global memory)
+
+    // ---- token rows as B fragments: k-step ks = features [16 ks + 8 hh, +8) of token (tile row c31); rows past the sequence repeat its last
+    bf16x8 xf[24];
+    {
+        const int tok = t0 + min(qt * 32 + c31, max(L - 1, 0));
+        if (x_tiled) {                             // k_ffn3's tiled store: 1-KiB blocks (token / 16, feature / 32), unit ^ tswz(row)
+            const int r = tok & 15, sw = tswz(r);
+            const bf16* blk = x + (int64_t)(tok >> 4) * (NH * 512) + r * 32;
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks) xf[ks] = *(const bf16x8*)(blk + (ks >> 1) * 512 + ((((ks & 1) * 2 + hh) ^ sw) * 8));
+        } else {
+            const bf16* row = x + (int64_t)tok * H + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < 24; ++ks) xf[ks] = *(const bf16x8*)(row + ks * 16);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // rows, biases and the first two slabs (own pieces) landed: the counted waits below start from an empty queue
+
+    const u32 ring_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)gsm;
+    // attention constants of this wave's sequence (k_attn3).  The padding mask of the LAST key tile (0 for real keys, -inf for padding;
+    // register r <-> key 32 (nkt - 1) + 8 (r >> 2) + 4 hh + (r & 3)) is rebuilt from `mlim` where it is needed: 16 registers less to carry
+    // through the projection (the wave's 96 token-fragment registers leave ~150 for everything else at two waves per SIMD)
+    const int mlim = L - (nkt - 1) * 32 - 4 * hh;
+    auto mask_into = [&](f32x16& m, float base) {
+        int lim = mlim;
+        asm volatile("" : "+v"(lim));              // (opaque: hipcc otherwise hoists the 16 selects out of the head loop and spills them)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = (8 * (r >> 2) + (r & 3) < lim) ? base : -INFINITY;
+    };
+    const u32 ksw = (u32)((c31 >> 2) & 3);
+    // key r of the tile -> slot inside its 16-block: keys 0-3 -> 0-3, 4-7 -> 8-11, 8-11 -> 4-7, 12-15 -> 12-15 (k_attn3's V^T order)
+    const int r16 = c31 & 15, vslot = w * 32 + (c31 & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
+
+#pragma unroll 1
+    for (int head = 0; head < NH; ++head) {
+        char* ks = gsm + RING + (head & 1) * IMG;
+        char* vt = ks + KS_BYTES;
+        f32x16 acc[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+        // ---- projection: three slabs of 8 k-steps x (Q, K, V) ------------------------------------------------------------------
+        static_for<HEAD_SLABS>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int g = head * HEAD_SLABS + j;
+            if (g + 1 < LAYER_SLABS) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (g + 2 < LAYER_SLABS) issue(g + 2, (j + 2) % NSLAB);
+            if (active && !(dflags & 2)) {
+                u32 base = ring_addr + (u32)(j * SLAB) + lane16;
+                asm volatile("" : "+v"(base));          // ONE address register per slab: the 24 fragments are immediate offsets (hipcc otherwise keeps 24 addresses -- spilled)
+                bf16x8 fo[4];
+                static_for<4>([&, base](auto nc) { (void)base; ffn::ds_read16<decltype(nc)::value * 1024>(fo[decltype(nc)::value], base); });
+                static_for<24>([&, base](auto nc) {
+                    constexpr int n = decltype(nc)::value;
+                    (void)base;
+                    if constexpr (n % 2 == 0)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fo[n % 4]), "+v"(fo[(n + 1) % 4]) : "n"(n + 4 <= 24 ? 2 : 24 - 2 - n));
+                    acc[n % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[n % 4], xf[8 * j + n / 3], acc[n % 3], 0, 0, 0);
+                    if constexpr (n + 4 < 24) ffn::ds_read16<(n + 4) * 1024>(fo[n % 4], base);
+                    else asm volatile("" : "+v"(fo[n % 4]));
+                });
+            }
+        });
+        bf16x8 qf0 = bf16x8{}, qf1 = bf16x8{};
+        if (active && !(dflags & 4)) {
+            // ---- acc[p][4 q + e] = feature 8 q + 4 hh + e of part p for token c31: + bias, one bf16 rounding (k_gemm3's epilogue) ----------
+            union { bf16x4 v; int i[2]; } pq[4], pk4[4], pv[4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float* bp = bl + p * H + head * DH + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *(const f32x4*)(bp + 8 * q);
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[p][4 * q + e] + bv[e]);
+                    if (p == 0) pq[q].v = o; else if (p == 1) pk4[q].v = o; else pv[q].v = o;
+                }
+            }
+            // Q: the B fragment of k-step s2 holds dims [16 s2 + 8 hh, +8) = pieces (q = 2 s2 + hh) of BOTH lane halves: elements 0-3 from
+            // the half-0 lane of this token, 4-7 from its half-1 lane.  Half 0 sends pieces 1, 3 and keeps 0, 2; half 1 the other way round.
+            {
+                union { bf16x4 v; int i[2]; } rc[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int snd0 = hh ? pq[2 * s2].i[0] : pq[2 * s2 + 1].i[0], snd1 = hh ? pq[2 * s2].i[1] : pq[2 * s2 + 1].i[1];
+                    rc[s2].i[0] = __shfl_xor(snd0, 32);
+                    rc[s2].i[1] = __shfl_xor(snd1, 32);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qf0[e] = hh ? rc[0].v[e] : pq[0].v[e];
+                    qf0[4 + e] = hh ? pq[1].v[e] : rc[0].v[e];
+                    qf1[e] = hh ? rc[1].v[e] : pq[2].v[e];
+                    qf1[4 + e] = hh ? pq[3].v[e] : rc[1].v[e];
+                }
+            }
+            // K row (slot w, key c31): 16-byte unit q holds dims [8 q, +8), this lane's piece at byte 8 hh of it; unit ^ ((row >> 2) & 3)
+            {
+                char* krow = ks + (w * 32 + c31) * 64 + hh * 8;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(bf16x4*)(krow + (((u32)q ^ ksw) * 16)) = pk4[q].v;
+            }
+            // V^T: dim 8 q + 4 hh + e, key slot vslot
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(bf16*)(vt + (8 * q + 4 * hh + e) * VSTR + vslot * 2) = pv[q].v[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!active || (dflags & 1)) continue;
+
+        // ---- attention of query tile qt against the key tiles [s0, s0 + nkt) of its sequence: k_attn3's two passes ------------------
+        const u32 kaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ks + (u32)(s0 * 2048 + c31 * 64);
+        auto kfrag = [&](int kt, int s2) -> bf16x8 {
+            return *(const bf16x8*)((const __attribute__((address_space(3))) char*)(uintptr_t)(kaddr + (u32)(kt * 2048) + (((u32)(2 * s2 + hh) ^ ksw) * 16)));
+        };
+        // The NEXT key tile's S^T MFMAs are issued in front of the VALU work on the current one (row maximum / exp2 + pack): two waves per
+        // SIMD in the same phase do not hide a dependent MFMA pair + an LDS round trip per tile the way k_attn3's four do.  Same arithmetic,
+        // same order of every accumulation (max is exact in any order).
+        auto stile = [&](int kt, const f32x16& c) -> f32x16 {
+            const bf16x8 k0 = kfrag(kt, 0), k1 = kfrag(kt, 1);
+            const f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf0, c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf1, a, 0, 0, 0);
+        };
+        auto stile_last = [&](float base) -> f32x16 {      // the last key tile: C carries -inf in the padded key slots
+            f32x16 c;
+            mask_into(c, base);
+            return stile(nkt - 1, c);
+        };
+        float mx = -INFINITY;
+        {
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 a = nkt > 1 ? stile(0, zero16) : stile_last(0.f);
+#pragma unroll 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                f32x16 an = a;
+                if (kt + 1 < nkt) an = kt + 2 < nkt ? stile(kt + 1, zero16) : stile_last(0.f);
+                float m3 = fmaxf(fmaxf(a[0], a[1]), a[2]);
+#pragma unroll
+                for (int r = 3; r + 1 < 16; r += 2) m3 = fmaxf(fmaxf(m3, a[r]), a[r + 1]);
+                mx = fmaxf(mx, fmaxf(m3, a[15]));
+                a = an;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        f32x16 negm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -mx;
+        f32x16 ot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+        float sum = 0.f;
+        const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+        {
+            f32x16 a = nkt > 1 ? stile(0, negm) : stile_last(-mx);
+#pragma unroll 1
+            for (int kt = 0; kt < nkt; ++kt) {
+                f32x16 an = a;
+                if (kt + 1 < nkt) an = kt + 2 < nkt ? stile(kt + 1, negm) : stile_last(-mx);
+                const bf16x8 vf0 = *(const bf16x8*)(vt + c31 * VSTR + ((s0 + kt) * 32 + hh * 8) * 2);
+                const bf16x8 vf1 = *(const bf16x8*)(vt + c31 * VSTR + ((s0 + kt) * 32 + 16 + hh * 8) * 2);
+                u32x4 pu[2];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    bf16x2 pb;
+                    pb[0] = (bf16)__builtin_amdgcn_exp2f(a[r]);           // exp2(-inf) = 0 for the padding
+                    pb[1] = (bf16)__builtin_amdgcn_exp2f(a[r + 1]);
+                    sum = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, sum, false);
+                    pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
+                }
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, __builtin_bit_cast(bf16x8, pu[0]), ot, 0, 0, 0);
+                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, __builtin_bit_cast(bf16x8, pu[1]), ot, 0, 0, 0);
+                a = an;
+            }
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        {
+            union { bf16x4 v; int i[2]; } pc[4], rcv[2];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pc[g4].v[e] = (bf16)(ot[4 * g4 + e] * inv);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int snd0 = hh ? pc[j].i[0] : pc[2 + j].i[0], snd1 = hh ? pc[j].i[1] : pc[2 + j].i[1];
+                rcv[j].i[0] = __shfl_xor(snd0, 32);
+                rcv[j].i[1] = __shfl_xor(snd1, 32);
+            }
+            int q = qt * 32 + c31;
+            asm volatile("" : "+v"(q));            // (opaque: the store addresses are rebuilt per head instead of living -- spilled -- across the loop)
+            if (q < L) {
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = hh ? rcv[0].v[e] : pc[0].v[e];
+                    o0[4 + e] = hh ? pc[2].v[e] : rcv[0].v[e];
+                    o1[e] = hh ? rcv[1].v[e] : pc[1].v[e];
+                    o1[4 + e] = hh ? pc[3].v[e] : rcv[1].v[e];
+                }
+                if (ctx_tiled) {
+                    const int64_t m = t0 + q;
+                    const int r = (int)(m & 15), sw = tswz(r);
+                    bf16* blk = ctx + ((m >> 4) * NH + head) * 512 + r * 32;
+                    __builtin_nontemporal_store(o0, (bf16x8*)(blk + ((2 * hh) ^ sw) * 8));
+                    __builtin_nontemporal_store(o1, (bf16x8*)(blk + ((2 * hh + 1) ^ sw) * 8));
+                } else {
+                    bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 16;
+                    __builtin_nontemporal_store(o0, (bf16x8*)dst);
+                    __builtin_nontemporal_store(o1, (bf16x8*)(dst + 8));
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // pooling heads
 // ------------------------------------------------------------------------------------------------------------
 // sentence-transformers Pooling + Normalize: one wave per sequence.  pool_cls = 0: masked mean over the sequence's tokens
@@ -3571,6 +3917,7 @@ struct BertLayer {
     bf16* w2p;      // W2 with the columns of every 32-block permuted to the fused FFN kernel's k-slot order
     bf16* w1p;      // (debug builds) W1 with the same permutation of ITS columns: k_ffn3's fused out-proj prologue builds the token fragments in accumulator order
     bf16 *wqkv_t, *wo_t, *w1_t, *w2_t;   // k_tile_w copies for k_gemm3
+    bf16* wqkv_s;                        // k_pack_qa stream for k_qa (per head: 72 fragments of 1 KiB in consumption order)
     bf16 *w1s, *w2s;                     // k_pack_ffn3 streams for k_ffn3's VAR bit 1 (debug builds only; nullptr otherwise)
     float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b;
 };
@@ -3587,6 +3934,7 @@ struct rmu_bert {
     bf16 *h = nullptr, *h1 = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *mid = nullptr;
     float2 *st1 = nullptr, *st2 = nullptr;        // (mean, rstd) per token of the two LayerNorms folded into their consumers (small path)
     int* cu = nullptr;
+    int2* qa_items = nullptr;                     // k_qa's work list (k_qa_items): [ws_batch] (first sequence, sequences); its length at qa_items[ws_batch]
     hipStream_t stream = nullptr;
     // small-batch host path (rmu_bert_encode_host): one captured graph per (batch, max_len, mode, token types) shape -- H2D of the
     // ids, the ~45 launches of a forward, D2H of the result -- replayed with ONE hipGraphLaunch.  All addresses inside are
@@ -3655,7 +4003,7 @@ extern "C" int rmu_bert_free(rmu_bert_t* m) {
     for (rmu_bert* c : m->clones) (void)rmu_bert_free(c);      // (their `owned` lists are empty: workspaces, staging, graphs, stream)
     m->clones.clear();
     for (void* p : m->owned) (void)hipFree(p);
-    for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->cu, (void*)m->st1, (void*)m->st2})
+    for (void* p : {(void*)m->h, (void*)m->h1, (void*)m->y, (void*)m->qkv, (void*)m->ctx, (void*)m->mid, (void*)m->cu, (void*)m->qa_items, (void*)m->st1, (void*)m->st2})
         if (p) (void)hipFree(p);
     for (auto& kv : m->graphs) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -3730,6 +4078,8 @@ extern "C" int rmu_bert_create(rmu_bert_t** out, const rmu_bert_cfg* cfg, const 
         hipLaunchKernelGGL(k_scale_copy, dim3(2), dim3(256), 0, s, (const float*)qb, L.bqkv, (int64_t)H, qs);
         hipLaunchKernelGGL(k_scale_copy, dim3(2), dim3(256), 0, s, (const float*)kb, L.bqkv + H, (int64_t)H, 1.f);
         hipLaunchKernelGGL(k_scale_copy, dim3(2), dim3(256), 0, s, (const float*)vb, L.bqkv + 2 * H, (int64_t)H, 1.f);
+        rc |= dev_alloc(m, &L.wqkv_s, (size_t)3 * H * H);
+        if (!rc) hipLaunchKernelGGL(k_pack_qa, dim3((unsigned)((3 * H * H / 8 + 255) / 256)), dim3(256), 0, s, (const bf16*)L.wqkv, L.wqkv_s);
         rc |= dev_alloc(m, &L.wo, (size_t)H * H);
         if (!rc) conv_bf16(L.wo, wptr[wi], (size_t)H * H, 1.f, s);
         wi++;
@@ -3854,10 +4204,12 @@ static int ensure_ws(rmu_bert* m, int64_t tokens, int batch) {
         if (m->cu) {
             quiesce(m);
             (void)hipFree(m->cu);
+            if (m->qa_items) (void)hipFree(m->qa_items);
         }
-        m->cu = nullptr; m->ws_batch = 0;
+        m->cu = nullptr; m->qa_items = nullptr; m->ws_batch = 0;
         const int nb = batch + batch / 8 + 64;
         if (hipMalloc((void**)&m->cu, (size_t)nb * sizeof(int)) != hipSuccess) return RMU_E_OOM;
+        if (hipMalloc((void**)&m->qa_items, (size_t)(nb + 1) * sizeof(int2)) != hipSuccess) return RMU_E_OOM;
         m->ws_batch = nb;
     }
     return RMU_OK;
@@ -4082,6 +4434,16 @@ static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, b
     hipLaunchKernelGGL(k_attn3<KT>, grid, dim3(256), lds, s, qkv, cu, batch, ctx, ctx_tiled ? 1 : 0, (long)hm_stride);
 }
 
+static void launch_qa(int batch, const bf16* x, bool x_tiled, const bf16* wstream, const float* bias, const int* cu, const int2* items, int items_cap,
+                      bf16* ctx, bool ctx_tiled, hipStream_t s) {
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_qa, hipFuncAttributeMaxDynamicSharedMemorySize, qa::LDS_BYTES);
+    (void)attr_rc;
+    // one workgroup per item; their number is known on the device only: `batch` is its upper bound, the surplus workgroups return at once
+    static const int dbg = rmu_env("RMU_QA_DBG") ? atoi(rmu_env("RMU_QA_DBG")) : 0;
+    hipLaunchKernelGGL(k_qa, dim3((unsigned)batch), dim3(512), qa::LDS_BYTES, s, x, x_tiled ? 1 : 0, wstream, bias, cu, items, (const int*)(items + items_cap),
+                       ctx, ctx_tiled ? 1 : 0, dbg);
+}
+
 template <int KT, bool LNA>
 static void launch_qkv_attn_small(hipStream_t s, int batch, const bf16* A, const bf16* W, const float* bias, const int* cu, const float* lng,
                                   const float* lnb, float eps, float2* stats_out, bf16* ctx) {
@@ -4224,7 +4586,13 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // (measured and dropped, round 5: the last LayerNorm inside the pooling launch -- one wave per sequence normalising its rows four at a
         // time -- made a 16-token query forward SLOWER, 0.182 vs 0.171-0.176 ms: k_layernorm spreads the rows over the chip, the fold serialises them)
         if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);
-    } else
+    } else {
+    // (round 6) QKV projection + attention as ONE launch per layer (k_qa) for sequences up to 256 tokens; RMU_QA=0: k_gemm3 + k_attn3
+    static const bool qa_env = !(rmu_env("RMU_QA") && atoi(rmu_env("RMU_QA")) == 0);
+    static const int g3_mask0 = rmu_env("RMU_GEMM3") ? atoi(rmu_env("RMU_GEMM3")) : 1;
+    const bool qa_on = qa_env && (g3_mask0 & 1) && max_len <= 256 && cap > g3_min_tokens() && batch <= 65536 && m->qa_items != nullptr;
+    if (qa_on)
+        hipLaunchKernelGGL(k_qa_items, dim3(1), dim3(1024), 0, s, (const int*)m->cu, batch, m->qa_items, (int*)(m->qa_items + m->ws_batch));
     for (const BertLayer& L : m->layers) {
         ++li;
         static const int g3_mask = rmu_env("RMU_GEMM3") ? atoi(rmu_env("RMU_GEMM3")) : 1;   // k_gemm3 for: bit 0 QKV (default: 1.22 vs 1.38 ms), bit 1 out-proj (0.67 vs 0.61), bit 2 FFN1 + FFN2 instead of k_ffn_fused (3.6 vs 3.35)
@@ -4239,7 +4607,8 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // workspace's token capacity
         static const bool hm_env = !(rmu_env("RMU_QKV_HM") && atoi(rmu_env("RMU_QKV_HM")) == 0);
         const int64_t hm_stride = (hm_env && (g3_mask & 1) && cap > g3_min_tokens() && attn_v == 3) ? m->ws_tokens : 0;
-        if ((g3_mask & 1) && cap > g3_min_tokens()) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled, hm_stride);
+        if (qa_on && attn_v == 3) { /* below */ }
+        else if ((g3_mask & 1) && cap > g3_min_tokens()) launch_gemm3<EPI_BIAS>(m->h, L.wqkv_t, L.bqkv, nullptr, m->qkv, m->cu, batch, 3 * H, H, s, h_in_tiled, hm_stride);
         else launch_gemm<EPI_BIAS>(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, m->cu, batch, cap, 3 * H, H, s);
         // big batches: k_attn3 writes ctx as the 1-KiB operand blocks the out-proj GEMM's LDS-DMA reads whole (RMU_CTX_TILED=0: row-major)
         static const bool tiled_env = !(rmu_env("RMU_CTX_TILED") && atoi(rmu_env("RMU_CTX_TILED")) == 0);
@@ -4261,7 +4630,9 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
             else launch_attn4<8, 2>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
         } else
 #endif
-        if (attn_v == 3) {
+        if (qa_on && attn_v == 3) {
+            launch_qa(batch, m->h, h_in_tiled, L.wqkv_s, L.bqkv, m->cu, m->qa_items, m->ws_batch, m->ctx, ctx_tiled, s);
+        } else if (attn_v == 3) {
             if (max_len <= 128) launch_attn3<4>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
             else if (max_len <= 256) launch_attn3<8>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
             else launch_attn3<16>(batch, m->qkv, m->cu, m->ctx, ctx_tiled, hm_stride, s);
@@ -4333,6 +4704,7 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         launch_gemm<EPI_GELU>(m->h1, L.w1, L.b1, nullptr, m->mid, m->cu, batch, cap, FF, H, s);
         launch_gemm<EPI_RESID>(m->mid, L.w2, L.b2, m->h1, m->y, m->cu, batch, cap, H, FF, s);
         hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)m->y, (const int*)m->cu, batch, L.ln2g, L.ln2b, eps, m->h);
+    }
     }
     if (kind == RMU_BERT_POOL_MEAN || kind == RMU_BERT_POOL_CLS)
         hipLaunchKernelGGL(k_pool, dim3((unsigned)batch), dim3(64), 0, s, (const bf16*)m->h, (const int*)m->cu, out_dev, out_stride,

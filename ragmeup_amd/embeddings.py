@@ -255,6 +255,10 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
         fwd = getattr(self.encoder, "_fwd_stream", None) if can_upload else None
         if can_upload and fwd is None:
             fwd = self.encoder._fwd_stream = torch.cuda.Stream(self.encoder.device)
+        if fwd is not None:
+            # `out` came from the caching allocator on the CURRENT stream: a block it handed back may still be read by work queued there
+            # (the consumer of an earlier result); the forwards that overwrite it run on `fwd` -- order them behind
+            fwd.wait_stream(torch.cuda.current_stream(self.encoder.device))
         with _SwitchInterval(2e-4), guard, ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(prepare, 0)
             done_prev = None                                # event: the forward enqueued one iteration ago has ended
@@ -311,6 +315,7 @@ class MI355XEmbeddings(_EncoderBase, Embeddings):
             fwd = enc._fwd_stream = torch.cuda.Stream(enc.device)
         ids_d, lens_d = enc.upload_rows([a for a, _ in parts], cut, Lmax, slot=f"add{round_no & 1}", min_cap=self.token_budget)
         out = torch.empty((n, 384), dtype=torch.float32, device=enc.device)
+        fwd.wait_stream(torch.cuda.current_stream(enc.device))      # `out` may be a recycled block still read on the allocating stream
         enc.encode_ids(ids_d, lens_d, None, mode=self._mode, out=out, stream=fwd)
         done = torch.cuda.Event()
         done.record(fwd)

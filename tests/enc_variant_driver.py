@@ -36,7 +36,8 @@ for n, lmax, mean in ((1, 16, 12), (3, 40, 24), (2, 200, 150), (5, 64, 40)):
     sp, sr = enc.encode_ids(sids, slens, None, mode=0).cpu().numpy(), O.embed_pool(shid, slens)
     small_cos = min(small_cos, float(((sp * sr).sum(1) / np.linalg.norm(sp, axis=1) / np.linalg.norm(sr, axis=1)).min()))
     assert np.array_equal(enc.encode_host(sids, slens, None, 0), sp)          # the graph-replayed host entry point takes the same kernels
-print("RESULT " + json.dumps({"small_max_tok_rel": small_rel, "small_min_cos": small_cos, "min_cos": float(cos.min()), "finite": bool(np.isfinite(got).all()),
+import hashlib  # noqa: E402
+print("RESULT " + json.dumps({"tok_sha": hashlib.sha256(np.ascontiguousarray(tok).tobytes()).hexdigest(), "pooled_sha": hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest(), "small_max_tok_rel": small_rel, "small_min_cos": small_cos, "min_cos": float(cos.min()), "finite": bool(np.isfinite(got).all()),
                               "max_tok_rel": float(rel.max()), "mean_tok_rel": float(rel.mean()),
                               "min_centred_cos": float(centred_cosine(g, ref).min()),
                               "norm_err": float(np.abs(np.linalg.norm(got, axis=1) - 1).max())}))
