@@ -3528,9 +3528,10 @@ __global__ __launch_bounds__(1024) void k_qa_items(const int* __restrict__ cu, i
     if (t == 1023) *n_items = cnt[1023];
 }
 
+template <bool DBG>      // DBG: cycle counters of the phases into `dbg` (RMU_QA_CLK=1, debug builds)
 __global__ __launch_bounds__(512) void k_qa(const bf16* __restrict__ x, int x_tiled, const bf16* __restrict__ wstream, const float* __restrict__ bias,
                                             const int* __restrict__ cu, const int2* __restrict__ items, const int* __restrict__ n_items,
-                                            bf16* __restrict__ ctx, int ctx_tiled, int dflags) {
+                                            bf16* __restrict__ ctx, int ctx_tiled, int dflags, unsigned long long* dbg) {
     // dflags (RMU_QA_DBG, timing ablations only -- results are wrong with any bit set): 1 no attention, 2 no projection MFMAs / fragment reads,
     // 4 no epilogue (bias, pack, image writes), 8 no weight DMA
     using namespace qa;
@@ -3542,23 +3543,27 @@ __global__ __launch_bounds__(512) void k_qa(const bf16* __restrict__ x, int x_ti
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c31 = lane & 31, hh = lane >> 5;
+    // Waves w and w + 4 share a SIMD (round-robin placement): `half` 0 = waves 0-3, 1 = waves 4-7.  Tile slots alternate between the
+    // halves (slot i -> half i & 1), so both halves have work whenever the item has two tiles or more.
+    const int half = w >> 2, myslot = 2 * (w & 3) + half;
     // ---- this wave's tile: sequence b, query tile qt of it, the sequence's first slot s0 / length L / first token t0 ------------------
     int b = -1, qt = 0, s0 = 0, L = 0, t0 = 0;
     {
         int slot = 0;
         for (int i = 0; i < item.y; ++i) {
             const int a = cu[item.x + i], l = cu[item.x + i + 1] - a, nt = (l + 31) >> 5;
-            if (w >= slot && w < slot + nt) { b = item.x + i; qt = w - slot; s0 = slot; L = l; t0 = a; }
+            if (myslot >= slot && myslot < slot + nt) { b = item.x + i; qt = myslot - slot; s0 = slot; L = l; t0 = a; }
             slot += nt;
         }
     }
     const bool active = b >= 0;                    // (wave-uniform) a wave without a tile still moves its ring pieces and meets the barriers
     const int nkt = (L + 31) >> 5;
 
-    // ---- the weight stream ------------------------------------------------------------------------------------------------------
+    // ---- the weight stream: ring slab index g = 3 * segment + j; segment sg projects head sg >> 1 (every head passes TWICE: once per half)
     const u32 lane16 = (u32)lane * 16;
-    auto issue = [&](int g, int slot) {              // slab g of the layer's stream -> ring slot `slot` (= g % 3, a literal at every call site)
-        const char* src = (const char*)wstream + (size_t)g * SLAB + (size_t)w * 1024;
+    auto issue = [&](int g, int slot) {            // stream slab g -> ring slot `slot` (= g % 3, a literal at every call site)
+        const int src_slab = ((g / 3) >> 1) * HEAD_SLABS + g % 3;
+        const char* src = (const char*)wstream + (size_t)src_slab * SLAB + (size_t)w * 1024;
         char* dst = gsm + slot * SLAB + w * 1024;
         if (dflags & 8) return;
 #pragma unroll
@@ -3594,207 +3599,290 @@ __global__ __launch_bounds__(512) void k_qa(const bf16* __restrict__ x, int x_ti
     const u32 ring_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)gsm;
     // attention constants of this wave's sequence (k_attn3).  The padding mask of the LAST key tile (0 for real keys, -inf for padding;
     // register r <-> key 32 (nkt - 1) + 8 (r >> 2) + 4 hh + (r & 3)) is rebuilt from `mlim` where it is needed: 16 registers less to carry
-    // through the projection (the wave's 96 token-fragment registers leave ~150 for everything else at two waves per SIMD)
     const int mlim = L - (nkt - 1) * 32 - 4 * hh;
-    auto mask_into = [&](f32x16& m, float base) {
+    [[maybe_unused]] auto mask_into = [&](f32x16& m, float base) {
         int lim = mlim;
-        asm volatile("" : "+v"(lim));              // (opaque: hipcc otherwise hoists the 16 selects out of the head loop and spills them)
+        asm volatile("" : "+v"(lim));              // (opaque: hipcc otherwise hoists the 16 selects out of the segment loop and spills them)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m[r] = (8 * (r >> 2) + (r & 3) < lim) ? base : -INFINITY;
     };
     const u32 ksw = (u32)((c31 >> 2) & 3);
     // key r of the tile -> slot inside its 16-block: keys 0-3 -> 0-3, 4-7 -> 8-11, 8-11 -> 4-7, 12-15 -> 12-15 (k_attn3's V^T order)
-    const int r16 = c31 & 15, vslot = w * 32 + (c31 & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
+    const int r16 = c31 & 15, vslot = myslot * 32 + (c31 & ~15) + ((r16 & 3) | ((r16 & 4) << 1) | ((r16 & 8) >> 1));
+    const int n1 = (nkt + 1) >> 1;                 // key tiles of the first pass-2 chunk
 
-#pragma unroll 1
-    for (int head = 0; head < NH; ++head) {
-        char* ks = gsm + RING + (head & 1) * IMG;
-        char* vt = ks + KS_BYTES;
-        f32x16 acc[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-        // ---- projection: three slabs of 8 k-steps x (Q, K, V) ------------------------------------------------------------------
-        static_for<HEAD_SLABS>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int g = head * HEAD_SLABS + j;
-            if (g + 1 < LAYER_SLABS) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (g + 2 < LAYER_SLABS) issue(g + 2, (j + 2) % NSLAB);
-            if (active && !(dflags & 2)) {
-                u32 base = ring_addr + (u32)(j * SLAB) + lane16;
-                asm volatile("" : "+v"(base));          // ONE address register per slab: the 24 fragments are immediate offsets (hipcc otherwise keeps 24 addresses -- spilled)
-                bf16x8 fo[4];
-                static_for<4>([&, base](auto nc) { (void)base; ffn::ds_read16<decltype(nc)::value * 1024>(fo[decltype(nc)::value], base); });
-                static_for<24>([&, base](auto nc) {
-                    constexpr int n = decltype(nc)::value;
-                    (void)base;
-                    if constexpr (n % 2 == 0)
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fo[n % 4]), "+v"(fo[(n + 1) % 4]) : "n"(n + 4 <= 24 ? 2 : 24 - 2 - n));
-                    acc[n % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[n % 4], xf[8 * j + n / 3], acc[n % 3], 0, 0, 0);
-                    if constexpr (n + 4 < 24) ffn::ds_read16<(n + 4) * 1024>(fo[n % 4], base);
-                    else asm volatile("" : "+v"(fo[n % 4]));
-                });
-            }
-        });
-        bf16x8 qf0 = bf16x8{}, qf1 = bf16x8{};
-        if (active && !(dflags & 4)) {
-            // ---- acc[p][4 q + e] = feature 8 q + 4 hh + e of part p for token c31: + bias, one bf16 rounding (k_gemm3's epilogue) ----------
-            union { bf16x4 v; int i[2]; } pq[4], pk4[4], pv[4];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const float* bp = bl + p * H + head * DH + 4 * hh;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *(const f32x4*)(bp + 8 * q);
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[p][4 * q + e] + bv[e]);
-                    if (p == 0) pq[q].v = o; else if (p == 1) pk4[q].v = o; else pv[q].v = o;
-                }
-            }
-            // Q: the B fragment of k-step s2 holds dims [16 s2 + 8 hh, +8) = pieces (q = 2 s2 + hh) of BOTH lane halves: elements 0-3 from
-            // the half-0 lane of this token, 4-7 from its half-1 lane.  Half 0 sends pieces 1, 3 and keeps 0, 2; half 1 the other way round.
-            {
-                union { bf16x4 v; int i[2]; } rc[2];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int snd0 = hh ? pq[2 * s2].i[0] : pq[2 * s2 + 1].i[0], snd1 = hh ? pq[2 * s2].i[1] : pq[2 * s2 + 1].i[1];
-                    rc[s2].i[0] = __shfl_xor(snd0, 32);
-                    rc[s2].i[1] = __shfl_xor(snd1, 32);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    qf0[e] = hh ? rc[0].v[e] : pq[0].v[e];
-                    qf0[4 + e] = hh ? pq[1].v[e] : rc[0].v[e];
-                    qf1[e] = hh ? rc[1].v[e] : pq[2].v[e];
-                    qf1[4 + e] = hh ? pq[3].v[e] : rc[1].v[e];
-                }
-            }
-            // K row (slot w, key c31): 16-byte unit q holds dims [8 q, +8), this lane's piece at byte 8 hh of it; unit ^ ((row >> 2) & 3)
-            {
-                char* krow = ks + (w * 32 + c31) * 64 + hh * 8;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *(bf16x4*)(krow + (((u32)q ^ ksw) * 16)) = pk4[q].v;
-            }
-            // V^T: dim 8 q + 4 hh + e, key slot vslot
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) *(bf16*)(vt + (8 * q + 4 * hh + e) * VSTR + vslot * 2) = pv[q].v[e];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned long long c_bar = 0, c_proj = 0, c_epi = 0, c_p1 = 0, c_p2a = 0, c_p2b = 0, c_all = 0, tk = 0;
+    auto tick = [&](unsigned long long& acc_) { if (DBG) { const unsigned long long n_ = __builtin_readcyclecounter(); acc_ += n_ - tk; tk = n_; } };
+    if (DBG) { tk = __builtin_readcyclecounter(); c_all = tk; }
+    // one sub-step boundary: stream slab g landed for everybody, everybody is done with slab g - 1, whose slot takes slab g + 2
+    constexpr int STREAM = 2 * LAYER_SLABS;        // 72 slabs: every head twice
+    auto boundary = [&](int g, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (g + 1 < STREAM) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (!active || (dflags & 1)) continue;
+        if (g + 2 < STREAM) issue(g + 2, (j + 2) % NSLAB);
+        tick(c_bar);
+    };
 
-        // ---- attention of query tile qt against the key tiles [s0, s0 + nkt) of its sequence: k_attn3's two passes ------------------
-        const u32 kaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ks + (u32)(s0 * 2048 + c31 * 64);
-        auto kfrag = [&](int kt, int s2) -> bf16x8 {
-            return *(const bf16x8*)((const __attribute__((address_space(3))) char*)(uintptr_t)(kaddr + (u32)(kt * 2048) + (((u32)(2 * s2 + hh) ^ ksw) * 16)));
-        };
-        // The NEXT key tile's S^T MFMAs are issued in front of the VALU work on the current one (row maximum / exp2 + pack): two waves per
-        // SIMD in the same phase do not hide a dependent MFMA pair + an LDS round trip per tile the way k_attn3's four do.  Same arithmetic,
-        // same order of every accumulation (max is exact in any order).
-        auto stile = [&](int kt, const f32x16& c) -> f32x16 {
-            const bf16x8 k0 = kfrag(kt, 0), k1 = kfrag(kt, 1);
-            const f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf0, c, 0, 0, 0);
-            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf1, a, 0, 0, 0);
-        };
-        auto stile_last = [&](float base) -> f32x16 {      // the last key tile: C carries -inf in the padded key slots
-            f32x16 c;
-            mask_into(c, base);
-            return stile(nkt - 1, c);
-        };
-        float mx = -INFINITY;
-        {
-            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 a = nkt > 1 ? stile(0, zero16) : stile_last(0.f);
+    // Q fragments of the heads this wave has projected and not yet attended to: even heads in qe, odd heads in qo (half 0 attends head h
+    // three segments after projecting it, with head h + 1's projection in between)
+    bf16x8 qe0 = bf16x8{}, qe1 = bf16x8{}, qo0 = bf16x8{}, qo1 = bf16x8{};
+
+    // ---- 26 segments of three sub-steps.  Segment sg: half (sg & 1) PROJECTS head sg >> 1 (sg < 24) while the other half ATTENDS -- half 1
+    // to head (sg - 2) / 2 (projected in segments sg - 2 and sg - 1), half 0 to head (sg - 3) / 2: on every SIMD a matrix-bound wave runs
+    // beside a VALU-bound one (both waves of a SIMD in the same phase -- the lockstep form of this kernel -- measured 2.31 ms per layer
+    // against 1.90 for k_gemm3 + k_attn3: nothing overlapped).  K rows / V^T of head h: written in segments 2h and 2h + 1 into image buffer
+    // h & 1, read in segments 2h + 2 and 2h + 3; the buffer's next writer (head h + 2) starts in segment 2h + 4.
 #pragma unroll 1
-            for (int kt = 0; kt < nkt; ++kt) {
-                f32x16 an = a;
-                if (kt + 1 < nkt) an = kt + 2 < nkt ? stile(kt + 1, zero16) : stile_last(0.f);
-                float m3 = fmaxf(fmaxf(a[0], a[1]), a[2]);
+    for (int sg = 0; sg < 2 * NH + 2; ++sg) {
+        if ((sg & 1) == half) {
+            // ================= projection of head hp ======================================================================================
+            const int hp = sg >> 1;
+            const bool work = active && sg < 2 * NH;
+            f32x16 acc[3];
 #pragma unroll
-                for (int r = 3; r + 1 < 16; r += 2) m3 = fmaxf(fmaxf(m3, a[r]), a[r + 1]);
-                mx = fmaxf(mx, fmaxf(m3, a[15]));
-                a = an;
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        f32x16 negm;
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -mx;
-        f32x16 ot;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-        float sum = 0.f;
-        const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
-        {
-            f32x16 a = nkt > 1 ? stile(0, negm) : stile_last(-mx);
-#pragma unroll 1
-            for (int kt = 0; kt < nkt; ++kt) {
-                f32x16 an = a;
-                if (kt + 1 < nkt) an = kt + 2 < nkt ? stile(kt + 1, negm) : stile_last(-mx);
-                const bf16x8 vf0 = *(const bf16x8*)(vt + c31 * VSTR + ((s0 + kt) * 32 + hh * 8) * 2);
-                const bf16x8 vf1 = *(const bf16x8*)(vt + c31 * VSTR + ((s0 + kt) * 32 + 16 + hh * 8) * 2);
-                u32x4 pu[2];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    bf16x2 pb;
-                    pb[0] = (bf16)__builtin_amdgcn_exp2f(a[r]);           // exp2(-inf) = 0 for the padding
-                    pb[1] = (bf16)__builtin_amdgcn_exp2f(a[r + 1]);
-                    sum = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, sum, false);
-                    pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
+                for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+            static_for<HEAD_SLABS>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                boundary(sg * HEAD_SLABS + j, jc);
+                if (work && !(dflags & 2)) {
+                    u32 base = ring_addr + (u32)(j * SLAB) + lane16;
+                    asm volatile("" : "+v"(base));          // ONE address register per slab: the 24 fragments are immediate offsets (hipcc otherwise keeps 24 addresses -- spilled)
+                    bf16x8 fo[4];
+                    static_for<4>([&, base](auto nc) { (void)base; ffn::ds_read16<decltype(nc)::value * 1024>(fo[decltype(nc)::value], base); });
+                    static_for<24>([&, base](auto nc) {
+                        constexpr int n = decltype(nc)::value;
+                        (void)base;
+                        if constexpr (n % 2 == 0)
+                            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fo[n % 4]), "+v"(fo[(n + 1) % 4]) : "n"(n + 4 <= 24 ? 2 : 24 - 2 - n));
+                        acc[n % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[n % 4], xf[8 * j + n / 3], acc[n % 3], 0, 0, 0);
+                        if constexpr (n + 4 < 24) ffn::ds_read16<(n + 4) * 1024>(fo[n % 4], base);
+                        else asm volatile("" : "+v"(fo[n % 4]));
+                    });
                 }
-                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, __builtin_bit_cast(bf16x8, pu[0]), ot, 0, 0, 0);
-                ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, __builtin_bit_cast(bf16x8, pu[1]), ot, 0, 0, 0);
-                a = an;
-            }
-        }
-        sum += __shfl_xor(sum, 32);
-        const float inv = __builtin_amdgcn_rcpf(sum);
-        {
-            union { bf16x4 v; int i[2]; } pc[4], rcv[2];
+                tick(c_proj);
+            });
+            if (work && !(dflags & 4)) {
+                char* ks = gsm + RING + (hp & 1) * IMG;
+                char* vt = ks + KS_BYTES;
+                // ---- acc[p][4 q + e] = feature 8 q + 4 hh + e of part p for token c31: + bias, one bf16 rounding (k_gemm3's epilogue) ----------
+                union { bf16x4 v; int i[2]; } pq[4], pk4[4], pv[4];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
+                for (int p = 0; p < 3; ++p) {
+                    const float* bp = bl + p * H + hp * DH + 4 * hh;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pc[g4].v[e] = (bf16)(ot[4 * g4 + e] * inv);
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bv = *(const f32x4*)(bp + 8 * q);
+                        bf16x4 o;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int snd0 = hh ? pc[j].i[0] : pc[2 + j].i[0], snd1 = hh ? pc[j].i[1] : pc[2 + j].i[1];
-                rcv[j].i[0] = __shfl_xor(snd0, 32);
-                rcv[j].i[1] = __shfl_xor(snd1, 32);
-            }
-            int q = qt * 32 + c31;
-            asm volatile("" : "+v"(q));            // (opaque: the store addresses are rebuilt per head instead of living -- spilled -- across the loop)
-            if (q < L) {
-                bf16x8 o0, o1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o0[e] = hh ? rcv[0].v[e] : pc[0].v[e];
-                    o0[4 + e] = hh ? pc[2].v[e] : rcv[0].v[e];
-                    o1[e] = hh ? rcv[1].v[e] : pc[1].v[e];
-                    o1[4 + e] = hh ? pc[3].v[e] : rcv[1].v[e];
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[p][4 * q + e] + bv[e]);
+                        if (p == 0) pq[q].v = o; else if (p == 1) pk4[q].v = o; else pv[q].v = o;
+                    }
                 }
-                if (ctx_tiled) {
-                    const int64_t m = t0 + q;
-                    const int r = (int)(m & 15), sw = tswz(r);
-                    bf16* blk = ctx + ((m >> 4) * NH + head) * 512 + r * 32;
-                    __builtin_nontemporal_store(o0, (bf16x8*)(blk + ((2 * hh) ^ sw) * 8));
-                    __builtin_nontemporal_store(o1, (bf16x8*)(blk + ((2 * hh + 1) ^ sw) * 8));
-                } else {
-                    bf16* dst = ctx + (int64_t)(t0 + q) * H + head * DH + hh * 16;
-                    __builtin_nontemporal_store(o0, (bf16x8*)dst);
-                    __builtin_nontemporal_store(o1, (bf16x8*)(dst + 8));
+                // Q: the B fragment of k-step s2 holds dims [16 s2 + 8 hh, +8) = pieces (q = 2 s2 + hh) of BOTH lane halves: elements 0-3 from
+                // the half-0 lane of this token, 4-7 from its half-1 lane.  Half 0 sends pieces 1, 3 and keeps 0, 2; half 1 the other way round.
+                {
+                    union { bf16x4 v; int i[2]; } rc[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int snd0 = hh ? pq[2 * s2].i[0] : pq[2 * s2 + 1].i[0], snd1 = hh ? pq[2 * s2].i[1] : pq[2 * s2 + 1].i[1];
+                        rc[s2].i[0] = __shfl_xor(snd0, 32);
+                        rc[s2].i[1] = __shfl_xor(snd1, 32);
+                    }
+                    bf16x8 q0, q1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        q0[e] = hh ? rc[0].v[e] : pq[0].v[e];
+                        q0[4 + e] = hh ? pq[1].v[e] : rc[0].v[e];
+                        q1[e] = hh ? rc[1].v[e] : pq[2].v[e];
+                        q1[4 + e] = hh ? pq[3].v[e] : rc[1].v[e];
+                    }
+                    if (hp & 1) { qo0 = q0; qo1 = q1; } else { qe0 = q0; qe1 = q1; }
+                }
+                // K row (slot myslot, key c31): 16-byte unit q holds dims [8 q, +8), this lane's piece at byte 8 hh of it; unit ^ ((row >> 2) & 3)
+                {
+                    char* krow = ks + (myslot * 32 + c31) * 64 + hh * 8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(bf16x4*)(krow + (((u32)q ^ ksw) * 16)) = pk4[q].v;
+                }
+                // V^T: dim 8 q + 4 hh + e, key slot vslot
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *(bf16*)(vt + (8 * q + 4 * hh + e) * VSTR + vslot * 2) = pv[q].v[e];
+            }
+            tick(c_epi);
+        } else {
+            // ================= attention to head ha: query tile qt against the key tiles [s0, s0 + nkt) of its sequence (k_attn3's two passes) ===
+            const int ha = half ? (sg - 2) >> 1 : (sg - 3) >> 1;
+            const bool work = active && !(dflags & 1) && (half ? sg >= 2 : sg >= 3) && ha < NH;
+            char* ks = gsm + RING + (ha & 1) * IMG;
+            char* vt = ks + KS_BYTES;
+            const bf16x8 qf0 = (ha & 1) ? qo0 : qe0, qf1 = (ha & 1) ? qo1 : qe1;
+            // K / V^T fragments are read with inline-asm ds_read_b128 and counted lgkmcnt waits, one key tile AHEAD of the MFMAs that eat them:
+            // left to hipcc every S^T tile was read -> wait -> MFMA -> read -> wait -> MFMA, two exposed LDS round trips per tile and pass on a
+            // wave that has no partner in the same phase to hide them (the first ping-pong form ran 2.87 ms per layer).
+            const u32 kaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)ks + (u32)(s0 * 2048 + c31 * 64);
+            const u32 koff0 = ((u32)hh ^ ksw) * 16, koff1 = ((u32)(2 + hh) ^ ksw) * 16;
+            const u32 vaddr = (u32)(uintptr_t)(__attribute__((address_space(3))) char*)vt + (u32)(c31 * VSTR + (s0 * 32 + hh * 8) * 2);
+            auto kread = [&](bf16x8& k0, bf16x8& k1, int kt) {      // key tile kt (clamped: a harmless re-read keeps the wait counts uniform)
+                const u32 base = kaddr + (u32)(min(kt, nkt - 1) * 2048);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(k0) : "v"(base + koff0));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(k1) : "v"(base + koff1));
+            };
+            auto vread = [&](bf16x8& v0, bf16x8& v1, int kt) {      // V^T fragments of key tile kt: keys [32 kt + 16 s2 + 8 hh, +8) of dim c31
+                const u32 base = vaddr + (u32)(min(kt, nkt - 1) * 64);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(base));
+                asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(v1) : "v"(base));
+            };
+            // the padded key slots of the LAST key tile -> -inf (what k_attn3's masked C operand makes of them: -inf + finite = -inf)
+            auto pad_fix = [&](f32x16& a) {
+                int lim = mlim;
+                asm volatile("" : "+v"(lim));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = (8 * (r >> 2) + (r & 3) < lim) ? a[r] : -INFINITY;
+            };
+            float mx = -INFINITY, sum = 0.f;
+            f32x16 negm, ot;
+            const bf16x2 one2 = {(bf16)1.0f, (bf16)1.0f};
+            // pass 2 over the key tiles [lo, hi): P = exp2(S - max) straight off the MFMA, O^T += V^T . P^T.  Per tile t: first S^T MFMA of tile
+            // t + 1 | the 16 exp2 of tile t | second MFMA of t + 1, K fragments of t + 2 requested | pack + row sum | P.V MFMAs of t, V^T of t + 1 requested
+            auto pass2 = [&](int lo, int hi) {
+                if (lo >= hi) return;
+                bf16x8 kn0, kn1, v0, v1;
+                kread(kn0, kn1, lo);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn0), "+v"(kn1));
+                f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn0, qf0, negm, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn1, qf1, a, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                kread(kn0, kn1, lo + 1);
+                vread(v0, v1, lo);
+#pragma unroll 2
+                for (int kt = lo; kt < hi; ++kt) {
+                    const bool more = kt + 1 < hi;
+                    f32x16 an = a;
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kn0), "+v"(kn1));          // K(t + 1) landed; V^T(t) may still be on its way
+                    if (more) an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn0, qf0, negm, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt == nkt - 1) pad_fix(a);
+                    float ex[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[r] = __builtin_amdgcn_exp2f(a[r]);       // exp2(-inf) = 0 for the padding
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn1, qf1, an, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    kread(kn0, kn1, kt + 2);
+                    u32x4 pu[2];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        bf16x2 pb;
+                        pb[0] = (bf16)ex[r];
+                        pb[1] = (bf16)ex[r + 1];
+                        sum = __builtin_amdgcn_fdot2_f32_bf16(pb, one2, sum, false);
+                        pu[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(u32, pb);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(v0), "+v"(v1));            // V^T(t) landed; K(t + 2) may still be on its way
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, __builtin_bit_cast(bf16x8, pu[0]), ot, 0, 0, 0);
+                    ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, __builtin_bit_cast(bf16x8, pu[1]), ot, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    vread(v0, v1, kt + 1);
+                    a = an;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn0), "+v"(kn1), "+v"(v0), "+v"(v1));      // the reads issued past the last tile
+            };
+            // ---- sub-step 0: pass 1, the row maximum (log2 domain: log2(e) / sqrt(d) is folded into W_q) --------------------------------
+            boundary(sg * HEAD_SLABS + 0, std::integral_constant<int, 0>{});
+            if (work) {
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                bf16x8 kn0, kn1;
+                kread(kn0, kn1, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn0), "+v"(kn1));
+                f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn0, qf0, zero16, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn1, qf1, a, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                kread(kn0, kn1, 1);
+#pragma unroll 2
+                for (int kt = 0; kt < nkt; ++kt) {
+                    const bool more = kt + 1 < nkt;
+                    f32x16 an = a;
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn0), "+v"(kn1));
+                    if (more) an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn0, qf0, zero16, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt == nkt - 1) pad_fix(a);
+                    float m3 = fmaxf(fmaxf(a[0], a[1]), a[2]);
+#pragma unroll
+                    for (int r = 3; r + 1 < 16; r += 2) m3 = fmaxf(fmaxf(m3, a[r]), a[r + 1]);
+                    mx = fmaxf(mx, fmaxf(m3, a[15]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) an = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kn1, qf1, an, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    kread(kn0, kn1, kt + 2);
+                    a = an;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kn0), "+v"(kn1));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));        // the other half of this query's keys (every query has >= 1 real key: finite)
+            }
+            tick(c_p1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { negm[r] = -mx; ot[r] = 0.f; }
+            // ---- sub-steps 1 and 2: pass 2 over the first / the second half of the key tiles ------------------------------------------
+            boundary(sg * HEAD_SLABS + 1, std::integral_constant<int, 1>{});
+            if (work) pass2(0, n1);
+            tick(c_p2a);
+            boundary(sg * HEAD_SLABS + 2, std::integral_constant<int, 2>{});
+            if (work) {
+                pass2(n1, nkt);
+                sum += __shfl_xor(sum, 32);
+                const float inv = __builtin_amdgcn_rcpf(sum);
+                // ot[4 g + e] = dim 8 g + 4 hh + e of query c31.  Lane halves trade two 8-byte pieces so that each stores 16 consecutive dims
+                union { bf16x4 v; int i[2]; } pc[4], rcv[2];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pc[g4].v[e] = (bf16)(ot[4 * g4 + e] * inv);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int snd0 = hh ? pc[j].i[0] : pc[2 + j].i[0], snd1 = hh ? pc[j].i[1] : pc[2 + j].i[1];
+                    rcv[j].i[0] = __shfl_xor(snd0, 32);
+                    rcv[j].i[1] = __shfl_xor(snd1, 32);
+                }
+                int q = qt * 32 + c31;
+                asm volatile("" : "+v"(q));            // (opaque: the store addresses are rebuilt per head instead of living -- spilled -- across the loop)
+                if (q < L) {
+                    bf16x8 o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o0[e] = hh ? rcv[0].v[e] : pc[0].v[e];
+                        o0[4 + e] = hh ? pc[2].v[e] : rcv[0].v[e];
+                        o1[e] = hh ? rcv[1].v[e] : pc[1].v[e];
+                        o1[4 + e] = hh ? pc[3].v[e] : rcv[1].v[e];
+                    }
+                    if (ctx_tiled) {
+                        const int64_t m = t0 + q;
+                        const int r = (int)(m & 15), sw = tswz(r);
+                        bf16* blk = ctx + ((m >> 4) * NH + ha) * 512 + r * 32;
+                        __builtin_nontemporal_store(o0, (bf16x8*)(blk + ((2 * hh) ^ sw) * 8));
+                        __builtin_nontemporal_store(o1, (bf16x8*)(blk + ((2 * hh + 1) ^ sw) * 8));
+                    } else {
+                        bf16* dst = ctx + (int64_t)(t0 + q) * H + ha * DH + hh * 16;
+                        __builtin_nontemporal_store(o0, (bf16x8*)dst);
+                        __builtin_nontemporal_store(o1, (bf16x8*)(dst + 8));
+                    }
                 }
             }
+            tick(c_p2b);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (DBG && lane == 0 && active) {
+        unsigned long long* d = dbg + half * 8;
+        atomicAdd(d + 0, 1ull); atomicAdd(d + 1, c_bar); atomicAdd(d + 2, c_proj); atomicAdd(d + 3, c_epi); atomicAdd(d + 4, c_p1); atomicAdd(d + 5, c_p2a);
+        atomicAdd(d + 6, c_p2b); atomicAdd(d + 7, __builtin_readcyclecounter() - c_all);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -4436,12 +4524,33 @@ static void launch_attn3(int batch, const bf16* qkv, const int* cu, bf16* ctx, b
 
 static void launch_qa(int batch, const bf16* x, bool x_tiled, const bf16* wstream, const float* bias, const int* cu, const int2* items, int items_cap,
                       bf16* ctx, bool ctx_tiled, hipStream_t s) {
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_qa, hipFuncAttributeMaxDynamicSharedMemorySize, qa::LDS_BYTES);
+    static const int dbg_flags = rmu_env("RMU_QA_DBG") ? atoi(rmu_env("RMU_QA_DBG")) : 0;
+#ifdef RMU_DEBUG_KERNELS
+    static const bool want_clk = rmu_env("RMU_QA_CLK") != nullptr;
+    if (want_clk) {          // phase cycle counters (per wave, summed over the grid)
+        static const hipError_t attr_dbg = hipFuncSetAttribute((const void*)k_qa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, qa::LDS_BYTES);
+        (void)attr_dbg;
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) { (void)hipMalloc((void**)&dbg, 128); (void)hipMemsetAsync(dbg, 0, 128, s); }
+        hipLaunchKernelGGL(k_qa<true>, dim3((unsigned)batch), dim3(512), qa::LDS_BYTES, s, x, x_tiled ? 1 : 0, wstream, bias, cu, items, (const int*)(items + items_cap),
+                           ctx, ctx_tiled ? 1 : 0, dbg_flags, dbg);
+        unsigned long long h[16];
+        (void)hipMemcpyAsync(h, dbg, 128, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemsetAsync(dbg, 0, 128, s);
+        for (int hf = 0; hf < 2; ++hf) {
+            const double n = (double)h[hf * 8] > 0 ? (double)h[hf * 8] : 1.0;
+            fprintf(stderr, "[k_qa clk half %d] waves %llu; cycles per wave: total %.0f = boundaries %.0f + projection %.0f + epilogue %.0f + pass1 %.0f + pass2a %.0f + pass2b/final %.0f\n", hf,
+                    h[hf * 8], h[hf * 8 + 7] / n, h[hf * 8 + 1] / n, h[hf * 8 + 2] / n, h[hf * 8 + 3] / n, h[hf * 8 + 4] / n, h[hf * 8 + 5] / n, h[hf * 8 + 6] / n);
+        }
+        return;
+    }
+#endif
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_qa<false>, hipFuncAttributeMaxDynamicSharedMemorySize, qa::LDS_BYTES);
     (void)attr_rc;
     // one workgroup per item; their number is known on the device only: `batch` is its upper bound, the surplus workgroups return at once
-    static const int dbg = rmu_env("RMU_QA_DBG") ? atoi(rmu_env("RMU_QA_DBG")) : 0;
-    hipLaunchKernelGGL(k_qa, dim3((unsigned)batch), dim3(512), qa::LDS_BYTES, s, x, x_tiled ? 1 : 0, wstream, bias, cu, items, (const int*)(items + items_cap),
-                       ctx, ctx_tiled ? 1 : 0, dbg);
+    hipLaunchKernelGGL(k_qa<false>, dim3((unsigned)batch), dim3(512), qa::LDS_BYTES, s, x, x_tiled ? 1 : 0, wstream, bias, cu, items, (const int*)(items + items_cap),
+                       ctx, ctx_tiled ? 1 : 0, dbg_flags, (unsigned long long*)nullptr);
 }
 
 template <int KT, bool LNA>
@@ -4587,8 +4696,11 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
         // time -- made a 16-token query forward SLOWER, 0.182 vs 0.171-0.176 ms: k_layernorm spreads the rows over the chip, the fold serialises them)
         if (prev) hipLaunchKernelGGL(k_layernorm, ln_grid, dim3(256), 0, s, (const bf16*)y2, (const int*)m->cu, batch, prev->ln2g, prev->ln2b, eps, m->h);
     } else {
-    // (round 6) QKV projection + attention as ONE launch per layer (k_qa) for sequences up to 256 tokens; RMU_QA=0: k_gemm3 + k_attn3
-    static const bool qa_env = !(rmu_env("RMU_QA") && atoi(rmu_env("RMU_QA")) == 0);
+    // (round 6) RMU_QA=1: QKV projection + attention as ONE launch per layer (k_qa) for sequences up to 256 tokens.  Built, bit-identical to
+    // k_gemm3 + k_attn3 (tests), and NOT the default: 2.31 ms per layer in its lockstep form, 2.99 as a ping-pong of the two wave halves,
+    // against 1.90 for the pair -- at 8 waves per CU (the 96 token-fragment registers) one wave's attention chain takes ~6.6k cycles per
+    // head whatever runs beside it (profiles/r06_qa_fusion.md)
+    static const bool qa_env = rmu_env("RMU_QA") && atoi(rmu_env("RMU_QA")) != 0;
     static const int g3_mask0 = rmu_env("RMU_GEMM3") ? atoi(rmu_env("RMU_GEMM3")) : 1;
     const bool qa_on = qa_env && (g3_mask0 & 1) && max_len <= 256 && cap > g3_min_tokens() && batch <= 65536 && m->qa_items != nullptr;
     if (qa_on)
