@@ -36,19 +36,27 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, debug_kernels: bool = False) -> str:
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
+
+
+def build(force: bool = False, verbose: bool = False, debug_kernels: bool = False, asan: bool = False) -> str:
     """debug_kernels: also compile the cycle-counter / ablation instantiations (-DRMU_DEBUG_KERNELS: RMU_FFN_DBG, RMU_G3_DBG,
-    RMU_GEMM_DBG); the product library carries none of them.  Switching the flag needs force=True."""
-    os.makedirs(OBJDIR, exist_ok=True)
+    RMU_GEMM_DBG); the product library carries none of them.  Switching the flag needs force=True.
+    asan: a SEPARATE library, lib/librmu_asan.so (objects under lib/obj_asan), whose HOST code -- the C-ABI, the WordPiece tokenizer and
+    its thread pool, the index's locking and bookkeeping -- is compiled with AddressSanitizer + UBSan (`make asan-test` runs the CPU
+    tests that call into the library against it; device code is not instrumented: GPU sanitizers are not available on this pool)."""
+    objdir = os.path.join(LIBDIR, "obj_asan") if asan else OBJDIR
+    so = os.path.join(LIBDIR, "librmu_asan.so") if asan else SO
+    os.makedirs(objdir, exist_ok=True)
     srcs = _sources()
     hdrs = _headers()
     objs = []
     jobs = []
     for s in srcs:
-        o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, *(["-DRMU_DEBUG_KERNELS"] if debug_kernels else []), "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, *(SAN_FLAGS if asan else []), *(["-DRMU_DEBUG_KERNELS"] if debug_kernels else []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -61,10 +69,11 @@ def build(force: bool = False, verbose: bool = False, debug_kernels: bool = Fals
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(SO, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs])
-    return SO
+    if force or jobs or _stale(so, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *(SAN_FLAGS if asan else []), "-o", so, *objs])
+    return so
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv or "--debug-kernels" in sys.argv, verbose=True, debug_kernels="--debug-kernels" in sys.argv))
+    print(build(force="--force" in sys.argv or "--debug-kernels" in sys.argv, verbose=True, debug_kernels="--debug-kernels" in sys.argv,
+                asan="--asan" in sys.argv))

@@ -87,10 +87,20 @@ class HotPath:
     compressor: Any
 
 
-def from_env(env: Optional[Mapping[str, str]] = None, device: int = 0, embeddings: Any = None) -> HotPath:
-    """Everything `RAGHelper` builds for the retrieval path, from the reference's own environment variables."""
+def from_env(env: Optional[Mapping[str, str]] = None, device: int = 0, embeddings: Any = None, logger: Any = None) -> HotPath:
+    """Everything `RAGHelper` builds for the retrieval path, from the reference's own environment variables.
+    `logger`: the logger the reference passes into its helper (server/server.py:134-146, `RAGHelperLocal(logger)`); the hot-path objects
+    then log through it -- the same lines at the same places as server/RAGHelper.py:387, 482, 496 -- instead of the package's own."""
+    from . import _log
+    if logger is not None:
+        _log.set_logger(logger)
+    log = _log.get_logger()
     env = os.environ if env is None else env
     emb = embeddings if embeddings is not None else embeddings_from_env(env, device)
+    log.info("Setting up the MI355X vector store.")
     db = vector_store_from_env(emb, env, device)
+    log.info("Setting up the Vector Retriever.")
     retriever = db.as_retriever(search_type="mmr", search_kwargs={"k": int(env.get("vector_store_k", "4"))})
+    if _flag(env, "rerank"):
+        log.info("Setting up the ScoredCrossEncoderReranker.")
     return HotPath(emb, db, retriever, reranker_from_env(env, device))

@@ -37,6 +37,7 @@ from typing import Any, Iterable, Optional
 
 import numpy as np
 
+from . import _log
 from . import _native as N
 from ._lc import Document, VectorStore, VectorStoreRetriever
 from .index import FlatIndex
@@ -271,7 +272,7 @@ class MI355XVectorStore(VectorStore):
             self.persist()
         except Exception as e:   # noqa: BLE001
             import sys
-            print(f"ragmeup_amd: persisting collection {self.collection_name!r} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            _log.get_logger().error(f"ragmeup_amd: persisting collection {self.collection_name!r} failed: {type(e).__name__}: {e}")
             for p in self._persist_paths() or ():
                 try:
                     if os.path.exists(p + ".tmp"):
@@ -537,9 +538,8 @@ class MI355XVectorStore(VectorStore):
     def _round_failed(self, items, e):
         self._pipe_failed = True
         # said where it happens: with deferred halves the RuntimeError itself is raised by whichever call touches the store next
-        print(f"ragmeup_amd: a deferred insert of collection {self.collection_name!r} failed ({type(e).__name__}: {e}); "
-              f"{sum(it[2] for it in items)} records of {len(items)} add_texts call(s) and everything queued behind them are rolled back",
-              file=sys.stderr)
+        _log.get_logger().error(f"ragmeup_amd: a deferred insert of collection {self.collection_name!r} failed ({type(e).__name__}: {e}); "
+                                f"{sum(it[2] for it in items)} records of {len(items)} add_texts call(s) and everything queued behind them are rolled back")
         for it in items:
             it[4].set_exception(e)
 

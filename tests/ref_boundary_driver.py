@@ -178,7 +178,25 @@ out["delete_count"] = h.db.delete(expr='source == "alpha.pdf"').delete_count
 from ragmeup_amd import factory  # noqa: E402
 env = dict(os.environ, vector_store="mi355x", vector_store_initial_load="True", rerank="False",
            vector_store_collection="factory_probe")   # a fresh collection: the product class itself (index built lazily)
-hp = factory.from_env(env, embeddings=HashEmbeddings())
+class _Rec:                      # the logger server.py hands to its helper (server/server.py:134-146): anything with .info / .error
+    def __init__(self):
+        self.lines = []
+
+    def info(self, m):
+        self.lines.append(("info", str(m)))
+
+    def error(self, m):
+        self.lines.append(("error", str(m)))
+
+    warning = info
+
+
+rec = _Rec()
+hp = factory.from_env(env, embeddings=HashEmbeddings(), logger=rec)
+out["factory_logged"] = [m for _, m in rec.lines]
+from ragmeup_amd import _log  # noqa: E402
+out["logger_injected"] = _log.get_logger() is rec
+_log.set_logger(None)
 out["factory_db"] = type(hp.db).__name__
 out["factory_retriever"] = [hp.retriever.search_type, hp.retriever.search_kwargs]
 out["factory_compressor"] = hp.compressor

@@ -41,6 +41,8 @@ def test_reference_wiring_accepts_our_objects():
     # env factory
     assert o["factory_db"] == "MI355XVectorStore" and o["factory_retriever"] == ["mmr", {"k": 4}]
     assert o["factory_compressor"] is None and o["force_cpu_raises"]
+    # the reference's logger (server/server.py:134-146) injected through the factory: the set-up lines of RAGHelper.py:387/496 go through it
+    assert o["logger_injected"] and o["factory_logged"] == ["Setting up the MI355X vector store.", "Setting up the Vector Retriever."]
 
 
 def test_shims_without_langchain():

@@ -242,7 +242,7 @@ def test_persist_and_reopen(tmp_path):
         pass
 
 
-def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, capsys):
+def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, caplog):
     """metadata values that JSON does not know (numpy scalars, datetimes, bytes -- what loaders produce) must not
     make persist() raise; a persist that does fail at exit is reported, leaves no .tmp behind and keeps the previous files; a
     dirty store that is garbage-collected before exit is written; a pre-JSON .meta.pkl is not silently re-opened empty."""
@@ -266,7 +266,7 @@ def test_persist_survives_loader_metadata_and_reports_failures(tmp_path, capsys)
         a._index.save = lambda p: (open(p, "wb").write(b"partial"), (_ for _ in ()).throw(OSError("disk full")))
         a._persist_quietly()
         a._index.save = real_save
-        assert "disk full" in capsys.readouterr().err
+        assert "disk full" in caplog.text                     # (through the package logger: the reference's, once injected by factory.from_env)
         assert not os.path.exists(uri + ".c.rmu.tmp") and not os.path.exists(uri + ".c.meta.json.tmp")
         assert open(uri + ".c.meta.json").read() == before
         # collected before exit while dirty -> written by the finalizer

@@ -53,6 +53,12 @@ timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b3
 keep scan_b32 kernel_stats.csv stats
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b32 -o b -- $B32 > $OUT/pmc_b32_bench.json 2>> $OUT/scan.err
 keep pmc_b32 counter_collection.csv counters
+# 3b') batch 16 -- the leg bench.py reports as roofline.north_star (>= 10k queries/sec at >= 0.70 of 8 TB/s): kernel stats + FETCH_SIZE (no b16 record existed)
+B16="python $R/bench.py --batch 16 --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check"
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scan_b16 -o scan -- $B16 > $OUT/scan_b16_bench.json 2>> $OUT/scan.err
+keep scan_b16 kernel_stats.csv stats
+timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b16 -o b -- $B16 > $OUT/pmc_b16_bench.json 2>> $OUT/scan.err
+keep pmc_b16 counter_collection.csv counters
 # 3c) BASELINE.json configs[1] (1M x 384, batch 1024) and the 8-way shard size (1.25M rows): kernel stats (round 5: VERDICT r4 asked for a c2_stats.csv)
 for cfg in "c2 1000000" "shard8 1250000"; do set -- $cfg
   timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1 -o scan -- python $R/bench.py --rows $2 --steps 10 --warmup 2 --legs none --no-cpu-baseline --no-identity-check > $OUT/$1_bench.json 2>> $OUT/scan.err
