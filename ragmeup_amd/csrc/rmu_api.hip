@@ -996,7 +996,15 @@ extern "C" int rmu_index_load(rmu_index_t** out, const char* path) {
 static const int64_t kMaxQueriesPerLaunch = 8192;
 static const int kScreenKp = 32;     // K': candidates the screening pass keeps per query (k <= 24)
 // (round 5) 24 < k <= 32: K' = 40 -- the same eight spare candidates behind the k-th for the sufficiency test; the slots hold RMU_KS_CAP = 48
-static inline int screen_kp(int k) { return k <= 24 ? kScreenKp : 40; }
+// (round 6) 32 < k <= 104 (BASELINE config 5's dense top-100): K' = k + max(8, k / 5), at most 120 -- the sufficiency test needs the K'-th approximate
+// score 2 EPS below the k-th, and the order statistics crowd together as k grows (16..20 spare candidates at k = 100; 8 sufficed at k <= 32)
+static const int kScreenMaxK = 104;
+static inline int screen_kp(int k) {
+    if (k <= 24) return kScreenKp;
+    if (k <= 32) return 40;
+    const int kp = k + (k / 5 > 8 ? k / 5 : 8);
+    return kp < RMU_KS_CAP_DEEP - 8 ? kp : RMU_KS_CAP_DEEP - 8;
+}
 
 static u64* g_dbg = nullptr;         // RMU_SCAN_EXP=7: cycle / event counters of the scan kernels (diagnostics only)
 static u64* dbg_buffer() {
@@ -1079,7 +1087,8 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
     const size_t gbytes = (gwords + pwords) * sizeof(u32);    // one memset zeroes thresholds and progress words
     size_t gcand_bytes = 0;                              // K-split launches: global candidate slots (reused by every launch of the ladder)
     for (int l = 0; l < nl; ++l)
-        if (lv[(size_t)l].kv >= 1) gcand_bytes = std::max(gcand_bytes, (size_t)lv[(size_t)l].parts * (size_t)nb * RMU_KS_CAP * sizeof(u64));
+        if (lv[(size_t)l].kv >= 1)
+            gcand_bytes = std::max(gcand_bytes, (size_t)lv[(size_t)l].parts * (size_t)nb * (kp > RMU_KS_CAP - 8 ? RMU_KS_CAP_DEEP : RMU_KS_CAP) * sizeof(u64));
     if (gcand_bytes && t.gcand.ensure(gcand_bytes)) return fail(RMU_E_OOM, "rmu_index_search: screening candidate slots");
     if (t.partial.ensure((size_t)slots * part_keys * sizeof(u64)) || t.qsplit.ensure((size_t)nb * RMU_IMG_ROW_BYTES) ||
         t.gthr.ensure(gbytes) || t.ckeys.ensure(part_keys * sizeof(u64)) || t.ensure_events(2 * nl))
@@ -1126,10 +1135,11 @@ static bool screen_applies(const rmu_index* idx, int64_t nb, int k) {
     const int64_t screen_min_nq = idx->screen_min_nq > 0 ? idx->screen_min_nq : env_min_nq;
     // small batches are HBM-bound either way: the screen reads half the bytes (768 vs 1536 B per row) but pays for the
     // ladder's launches and merges per batch, which only pays off on a large enough corpus
-    const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || min_nq_set;
+    // (deep k: the alternative is the exact 128-deep ladder at ~0.3 of the HBM roof -- the screen pays from the size that ladder starts at)
+    const bool screen_pays = nb >= 128 || idx->n >= 3000000 || (nb > 64 && idx->n >= 1000000) || min_nq_set || (k > 32 && idx->n >= 262144);
     const bool geom = idx->dim == 384 && (idx->metric == RMU_METRIC_L2SQ ? idx->nrm != nullptr : idx->dpad == 384);
     return idx->split && idx->screen_enabled && geom &&
-           nb >= screen_min_nq && screen_pays && k <= 32 && idx->n > 0 && idx->xnorm_max > 0.f &&
+           nb >= screen_min_nq && screen_pays && k <= kScreenMaxK && idx->n > 0 && idx->xnorm_max > 0.f &&
            idx->xnorm_max < 500.f;   // fp16(64*x) must not overflow
 }
 

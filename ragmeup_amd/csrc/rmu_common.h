@@ -192,6 +192,7 @@ struct ScanLaunch {
     const float* nrm;
 };
 #define RMU_KS_CAP 48     /* K' <= 40 kept candidates + 8 free slots between compactions (one key per lane in the rank: <= 64) */
+#define RMU_KS_CAP_DEEP 128   /* (round 6) 32 < k <= 104: K' <= 120 kept candidates + 8 free slots, two keys per lane in the rank */
 
 int rmu_scan_plan(ScanLaunch* p);                        // chooses geometry; returns 0 or RMU_E_INVALID
 int rmu_scan_launch(const ScanLaunch* p, hipStream_t s); // launches the fused scan

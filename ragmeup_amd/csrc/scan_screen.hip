@@ -1281,10 +1281,12 @@ __global__ __launch_bounds__(512) void scan_screen_lean2_kernel(const ScanLaunch
 // NWV = 8: full query tiles (256 queries per workgroup, two waves per SIMD).  NWV = 4: ONE query tile (batches <= 128 queries: every image byte
 // is read by exactly one workgroup -- NT streams it past the L2 with non-temporal loads; the HBM-bound regime, where the round-3 form's ~300
 // instructions per tile and wave cost bandwidth: one wave per SIMD cannot issue them and keep 24 KiB per microsecond in flight).
-template <int NWV>
+template <int NWV, bool DEEP = false>
 struct Lean3Cfg {
     static constexpr int NW = NWV, QW = 32, NR = 12, NDW = NWV, NIW = 24 / NWV;
-    static constexpr int CAP = RMU_KS_CAP;
+    // DEEP (round 6): 32 < k <= 104 -- K' <= 120 candidates per (chunk, query) slot of 128 keys, two keys per lane wherever the whole wave works
+    // on one slot (compaction, emit); everything else -- ring, MFMA chain, filter, appends -- is the K' <= 40 kernel unchanged
+    static constexpr int CAP = DEEP ? RMU_KS_CAP_DEEP : RMU_KS_CAP, NPL = DEEP ? 2 : 1;
     static constexpr int RING_BYTES = NR * S_SLOT;
     static constexpr int GT_OFF = RING_BYTES;
     static constexpr int NRM_OFF = GT_OFF + NW * 256;      // L2 form: -2048 |x|^2 of the rows of the six ring tiles (32 floats per tile)
@@ -1298,9 +1300,9 @@ struct Lean3Cfg {
 // tile ahead between two fragment reads (the lgkmcnt of the four steps behind them counts them in); the norms of a PAIR of tiles are one
 // 256-byte LDS-DMA by wave 0, issued two pairs ahead next to the threshold refresh (older than the pieces the pair barrier's vmcnt leaves
 // in flight, like the refresh).  +4 KiB-reads per 24 on the LDS return path; the fp16 image bytes are unchanged.
-template <int EXP = 0, int NWV = 8, int NT = 0, int L2N = 0>
+template <int EXP = 0, int NWV = 8, int NT = 0, int L2N = 0, bool DEEP = false>
 __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanLaunch a) {
-    using C = Lean3Cfg<NWV>;
+    using C = Lean3Cfg<NWV, DEEP>;
     constexpr bool DBG = (EXP & 4) != 0;
     constexpr int NW = NWV, S_PRE = 4;
     const int lane = threadIdx.x & 63;
@@ -1439,18 +1441,26 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
         const u32 n = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
         u64* slot = (u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
                            (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
-        u64 key[1];
-        u32 rank[1];
-        key[0] = 0ull;
-        if ((u32)lane < n) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(key[0]) : "v"(slot + lane) : "memory");
-        rank_keys<1>(key, n, rank);
-        const bool keep = (u32)lane < n && rank[0] < (u32)a.k;
-        if (keep) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(slot + rank[0]), "v"(key[0]) : "memory");
-        const u64 kb = __ballot(keep && rank[0] == (u32)(a.k - 1));
-        if (kb) {
-            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(key[0] >> 32), __builtin_ctzll(kb));
-            if (j == jj) thr_s = fmaxf(thr_s, rmu_ord2f(hi) * 4096.0f);
-            if (lane == 0) asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(gthr_w + jj), "v"(hi) : "memory");
+        u64 key[C::NPL];
+        u32 rank[C::NPL];
+#pragma unroll
+        for (int pp = 0; pp < C::NPL; ++pp) {
+            key[pp] = 0ull;
+            if ((u32)(lane + 64 * pp) < n) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(key[pp]) : "v"(slot + lane + 64 * pp) : "memory");
+        }
+#pragma unroll
+        for (int pp = 0; pp < C::NPL; ++pp) asm volatile("s_waitcnt vmcnt(0)" : "+v"(key[pp])::"memory");
+        rank_keys<C::NPL>(key, n, rank);
+#pragma unroll
+        for (int pp = 0; pp < C::NPL; ++pp) {
+            const bool keep = (u32)(lane + 64 * pp) < n && rank[pp] < (u32)a.k;
+            if (keep) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(slot + rank[pp]), "v"(key[pp]) : "memory");
+            const u64 kb = __ballot(keep && rank[pp] == (u32)(a.k - 1));
+            if (kb) {
+                const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(key[pp] >> 32), __builtin_ctzll(kb));
+                if (j == jj) thr_s = fmaxf(thr_s, rmu_ord2f(hi) * 4096.0f);
+                if (lane == 0) asm volatile("global_atomic_umax %0, %1, off sc1" ::"v"(gthr_w + jj), "v"(hi) : "memory");
+            }
         }
         if (j == jj) cnt = n < (u32)a.k ? n : (u32)a.k;
         if (DBG) ++d_comp;
@@ -1622,32 +1632,39 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
             atomicAdd((unsigned long long*)a.dbg + 7, (unsigned long long)(clock64() - d_clk_all));
         }
     }
-    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  All 32 slots are read back in ONE round trip (the query fragments are dead: registers are free).
+    // ---- emit: best K' approximate candidates of this (chunk, query), sorted.  All 32 slots (DEEP: 8 at a time) are read back in ONE round trip (the query fragments are dead: registers are free).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int part = s_idx;
-    for (int j0 = 0; j0 < 32; j0 += 32) {
+    constexpr int GE = DEEP ? 8 : 32;
+    for (int j0 = 0; j0 < 32; j0 += GE) {
         if (q_base + j0 >= a.nq) break;
-        u64 key[32][1];
-        u32 nn[32];
+        u64 key[GE][C::NPL];
+        u32 nn[GE];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
+        for (int e = 0; e < GE; ++e) {
             const int jj = j0 + e;
             nn[e] = (u32)__builtin_amdgcn_readlane((int)cnt, jj);
             const u64* slot = (const u64*)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)((u64)gslot >> 32), jj) << 32) |
                                            (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(u64)gslot, jj));
-            key[e][0] = (u32)lane < nn[e] ? __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+            for (int pp = 0; pp < C::NPL; ++pp)
+                key[e][pp] = (u32)(lane + 64 * pp) < nn[e] ? __hip_atomic_load(slot + lane + 64 * pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         }
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
+        for (int e = 0; e < GE; ++e) {
             const int qq = q_base + j0 + e;
             if (qq < a.nq) {
-                u32 rank[1];
-                rank_keys<1>(key[e], nn[e], rank);
+                u32 rank[C::NPL];
+                rank_keys<C::NPL>(key[e], nn[e], rank);
                 u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
-                if ((u32)lane < nn[e]) {
-                    if (rank[0] < (u32)a.k) dst[rank[0]] = key[e][0];
-                } else if (lane < a.k) {
-                    dst[lane] = 0ull;
+#pragma unroll
+                for (int pp = 0; pp < C::NPL; ++pp) {
+                    const int le = lane + 64 * pp;
+                    if ((u32)le < nn[e]) {
+                        if (rank[pp] < (u32)a.k) dst[rank[pp]] = key[e][pp];
+                    } else if (le < a.k) {
+                        dst[le] = 0ull;
+                    }
                 }
             }
         }
@@ -2530,7 +2547,7 @@ __global__ __launch_bounds__(256) void scan_screen_g4_kernel(const ScanLaunch a)
 // (q~.x~ - |x|^2 / 2: see scan_screen_lean3_kernel), the sufficiency test runs in those units: the image errors bound the q.x part as before,
 // the norm is the SAME stored number on both sides, and the roundings that see it -- the screening chain starts at 2048 |x|^2 instead of 0
 // (<= 408 roundings relative to |x||q| + |x|^2 / 2: 1.22e-5 |x|^2), the exact chain's last step rounds 2 q.x - |x|^2 once -- add 1.5e-5 |x|max^2.
-template <bool L2>
+template <bool L2, int NPL = 1>       // NPL: candidates per lane (K' <= 64 NPL); lane l holds candidates l, l + 64
 __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, int kp, const float* __restrict__ x,
                                                  const float* __restrict__ q, int64_t nq, int k, float xnorm_max, float dx_max,
                                                  int64_t row_base, float* __restrict__ out_s, int64_t* __restrict__ out_r,
@@ -2541,20 +2558,35 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
-    const u64 ck = lane < kp ? cand[qi * kp + lane] : 0ull;
-    const bool valid = ck != 0ull;
-    const float sa = valid ? rmu_key_score(ck) : -INFINITY;     // approximate score (sorted descending over lanes)
-    const u32 row = valid ? rmu_key_row(ck) : 0u;
+    u64 ck[NPL];
+    bool valid[NPL];
+    float sa[NPL], acc[NPL];
+    u32 row[NPL];
+    const float* xv[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        ck[p] = lane + 64 * p < kp ? cand[qi * kp + lane + 64 * p] : 0ull;
+        valid[p] = ck[p] != 0ull;
+        sa[p] = valid[p] ? rmu_key_score(ck[p]) : -INFINITY;     // approximate score (sorted descending over the candidate index)
+        row[p] = valid[p] ? rmu_key_row(ck[p]) : 0u;
+        xv[p] = x + (int64_t)row[p] * stride;
+        acc[p] = 0.f;
+    }
     const float* qv = q + qi * stride;
-    const float* xv = x + (int64_t)row * stride;
-    float acc = 0.f, qn2 = 0.f, dq2 = 0.f;
+    float qn2 = 0.f, dq2 = 0.f;
     for (int t = 0; t < SD / 8; ++t) {
         const f32x4 qa = *(const f32x4*)(qv + 8 * t), qb = *(const f32x4*)(qv + 8 * t + 4);
-        const f32x4 xa = *(const f32x4*)(xv + 8 * t), xb = *(const f32x4*)(xv + 8 * t + 4);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            const f32x4 xa = *(const f32x4*)(xv[p] + 8 * t), xb = *(const f32x4*)(xv[p] + 8 * t + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[p] = fmaf(xa[c], qa[c], acc[p]);
+                acc[p] = fmaf(xb[c], qb[c], acc[p]);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            acc = fmaf(xa[c], qa[c], acc);
-            acc = fmaf(xb[c], qb[c], acc);
             const float ua = L2 ? 0.5f * qa[c] : qa[c], ub = L2 ? 0.5f * qb[c] : qb[c];      // the query itself (the L2 index stores 2q)
             qn2 = fmaf(ua, ua, qn2);
             qn2 = fmaf(ub, ub, qn2);
@@ -2564,11 +2596,22 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
             dq2 = fmaf(db, db, dq2);
         }
     }
-    if (L2) acc = fmaf(xv[SD], qv[SD], acc);
+    if (L2) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) acc[p] = fmaf(xv[p][SD], qv[SD], acc[p]);
+    }
     // sufficiency test on the approximate scores
-    const int nvalid = __builtin_popcountll(__ballot(valid));
-    const float tau = __shfl(sa, k - 1);                        // k-th best approximate score (or -inf)
-    const float smin = __shfl(sa, kp - 1);                      // worst kept candidate
+    int nvalid = 0;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) nvalid += __builtin_popcountll(__ballot(valid[p]));
+    auto approx_at = [&](int idx) -> float {                    // approximate score of candidate `idx` (uniform)
+        float v = __shfl(sa[0], idx & 63);
+#pragma unroll
+        for (int p = 1; p < NPL; ++p) { const float vp = __shfl(sa[p], idx & 63); v = (idx >> 6) == p ? vp : v; }
+        return v;
+    };
+    const float tau = approx_at(k - 1);                         // k-th best approximate score (or -inf)
+    const float smin = approx_at(kp - 1);                       // worst kept candidate
     const float qn = sqrtf(qn2) * 1.0001f, dq = sqrtf(dq2) * 1.0001f;
     const float eps = dx_max * qn + xnorm_max * dq + dx_max * dq + 5.0e-5f * xnorm_max * qn +   // see the header
                       (L2 ? 1.5e-5f * xnorm_max * xnorm_max : 0.f);
@@ -2580,18 +2623,23 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
         if (!ok) flagged_list[atomicAdd(flagged, 1)] = qi;
         if (eps_out) eps_out[qi] = eps;
     }
-    u64 key[1];
-    u32 rank[1];
-    key[0] = valid ? rmu_make_key(acc + 0.0f, row) : 0ull;
-    rank_keys<1>(key, (u32)(kp < 64 ? kp : 64), rank);
+    u64 key[NPL];
+    u32 rank[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) key[p] = valid[p] ? rmu_make_key(acc[p] + 0.0f, row[p]) : 0ull;
+    rank_keys<NPL>(key, (u32)(kp < 64 * NPL ? kp : 64 * NPL), rank);
     // keys of invalid lanes are 0 and rank below every valid one
-    if (valid && rank[0] < (u32)k) {
-        out_s[qi * k + rank[0]] = L2 ? fmaxf(qn2_l2[qi] - (acc + 0.0f), 0.f) : acc + 0.0f;
-        out_r[qi * k + rank[0]] = (int64_t)row + row_base;
-    }
-    if (lane < k && lane >= nvalid) {
-        out_s[qi * k + lane] = L2 ? INFINITY : -INFINITY;
-        out_r[qi * k + lane] = -1;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        if (valid[p] && rank[p] < (u32)k) {
+            out_s[qi * k + rank[p]] = L2 ? fmaxf(qn2_l2[qi] - (acc[p] + 0.0f), 0.f) : acc[p] + 0.0f;
+            out_r[qi * k + rank[p]] = (int64_t)row[p] + row_base;
+        }
+        const int le = lane + 64 * p;
+        if (le < k && le >= nvalid) {
+            out_s[qi * k + le] = L2 ? INFINITY : -INFINITY;
+            out_r[qi * k + le] = -1;
+        }
     }
 }
 
@@ -2621,7 +2669,7 @@ int rmu_screen_lds_bytes(int qg) { return qg == 2 ? ScreenCfg<2>::LDS_BYTES : Sc
 // geometry of one screening launch: p->qg 32-query groups per wave (2 when the batch fills 256-query workgroups),
 // S row chunks (a multiple of 8 for the XCD-aware block map) so that grid = S * nqt fills the 256 CUs evenly
 int rmu_screen_plan(ScanLaunch* p) {
-    if (p->k < 1 || p->k > RMU_KS_CAP - 8 || p->nq < 1 || p->n_rows < 0 || p->dpad != SD) return RMU_E_INVALID;   // (p->k is K': 32 or 40)
+    if (p->k < 1 || p->k > RMU_KS_CAP_DEEP - 8 || p->nq < 1 || p->n_rows < 0 || p->dpad != SD) return RMU_E_INVALID;   // (p->k is K': 32, 40, or up to 120 for 32 < k <= 104)
     // (round 5) The PRODUCT library carries exactly the kernels it takes: scan_screen_lean3_kernel<NW = 8> for full query tiles and
     // <NW = 4, nt> for one query tile.  The earlier forms of the same kernel (scan_screen_kernel in its 4- and 8-wave instantiations,
     // scan_screen_lean_kernel, scan_screen_lean2_kernel) and the switches that select them (RMU_SCREEN_G / _W8 / _LEAN / _LEAN4) exist in
@@ -2689,7 +2737,7 @@ int rmu_screen_plan(ScanLaunch* p) {
 #ifndef RMU_DEBUG_KERNELS
     if (p->kv != 4) return RMU_E_INVALID;      // every product geometry is one of the two lean3 instantiations
 #endif
-    p->lds_bytes = p->kv == 4 ? (p->wq == 8 ? Lean3Cfg<8>::LDS_BYTES : Lean3Cfg<4>::LDS_BYTES) : p->kv == 3 ? Lean2Cfg::LDS_BYTES : p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
+    p->lds_bytes = p->kv == 4 ? (p->wq == 8 ? Lean3Cfg<8>::LDS_BYTES : Lean3Cfg<4>::LDS_BYTES)   /* (the DEEP forms take the same LDS) */ : p->kv == 3 ? Lean2Cfg::LDS_BYTES : p->kv == 2 ? G4Cfg::LDS_BYTES : p->kv ? KsCfg::LDS_BYTES : p->wq == 8 ? ScreenCfg<1, 0, 8>::LDS_BYTES : rmu_screen_lds_bytes(p->qg);
     // sibling pacing (see the kernel): query tiles of a chunk on one XCD, 2..4 of them, the whole grid resident at once (these
     // kernels take > 80 KiB of LDS: one workgroup per CU), and enough tiles per workgroup for drift to matter
     // window in tiles (0 = off).  Measured (tools/pace_probe.py, 10M x 1024): 0 / 4 / 8 / 16 / 32 all 7.82-7.86 ms of scan kernels -- the pacing
@@ -2728,12 +2776,13 @@ static int screen_launch_g4(const ScanLaunch* p, hipStream_t s) {
 }
 #endif
 
-template <int EXP, int NWV, int NT, int L2N>
+template <int EXP, int NWV, int NT, int L2N, bool DEEP = false>
 static int screen_launch_lean3(const ScanLaunch* p, hipStream_t s) {
-    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<EXP, NWV, NT, L2N>,
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, Lean3Cfg<NWV>::LDS_BYTES);
+    static const hipError_t attr_rc = hipFuncSetAttribute((const void*)scan_screen_lean3_kernel<EXP, NWV, NT, L2N, DEEP>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (Lean3Cfg<NWV, DEEP>::LDS_BYTES));
     if (attr_rc != hipSuccess) return RMU_E_HIP;
-    hipLaunchKernelGGL((scan_screen_lean3_kernel<EXP, NWV, NT, L2N>), dim3(p->grid), dim3(64 * NWV), Lean3Cfg<NWV>::LDS_BYTES, s, *p);
+    constexpr int lds = Lean3Cfg<NWV, DEEP>::LDS_BYTES;
+    hipLaunchKernelGGL((scan_screen_lean3_kernel<EXP, NWV, NT, L2N, DEEP>), dim3(p->grid), dim3(64 * NWV), lds, s, *p);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
@@ -2741,6 +2790,13 @@ int rmu_screen_launch(const ScanLaunch* p, hipStream_t s) {
     if (p->kv == 4) {
         if (!p->gcand) return RMU_E_INVALID;
         const bool l2 = p->nrm != nullptr;                // RMU_METRIC_L2SQ: the row norms enter the chain as its C operand
+        if (p->k > RMU_KS_CAP - 8) {                      // deep K' (32 < k <= 104): slots of RMU_KS_CAP_DEEP keys
+            if (p->wq == 4) {
+                if (p->nt) return l2 ? screen_launch_lean3<0, 4, 1, 1, true>(p, s) : screen_launch_lean3<0, 4, 1, 0, true>(p, s);
+                return l2 ? screen_launch_lean3<0, 4, 0, 1, true>(p, s) : screen_launch_lean3<0, 4, 0, 0, true>(p, s);
+            }
+            return l2 ? screen_launch_lean3<0, 8, 0, 1, true>(p, s) : screen_launch_lean3<0, 8, 0, 0, true>(p, s);
+        }
         if (p->wq == 4) {                                 // one query tile
             if (p->nt) return l2 ? screen_launch_lean3<0, 4, 1, 1>(p, s) : screen_launch_lean3<0, 4, 1, 0>(p, s);
             return l2 ? screen_launch_lean3<0, 4, 0, 1>(p, s) : screen_launch_lean3<0, 4, 0, 0>(p, s);
@@ -2861,12 +2917,20 @@ int rmu_img_err_launch(const float* x, int64_t n_rows, float* err2, hipStream_t 
 int rmu_rescore_launch(const u64* cand, int kp, const float* x, const float* q, int64_t nq, int k, float xnorm_max, float dx_max,
                        int64_t row_base, float* out_s, int64_t* out_r, int* flagged, int64_t* flagged_list, float* eps_out, hipStream_t s,
                        int stride, const float* qn2_l2) {
-    if (kp < k || kp > 64 || stride < SD || (qn2_l2 && stride < SD + 1)) return RMU_E_INVALID;
-    if (qn2_l2)
-        hipLaunchKernelGGL(k_rescore<true>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
+    if (kp < k || kp > 128 || stride < SD || (qn2_l2 && stride < SD + 1)) return RMU_E_INVALID;
+    const dim3 grid((unsigned)((nq + 3) / 4));
+    if (kp > 64) {       // deep K' (32 < k <= 104): two candidates per lane
+        if (qn2_l2)
+            hipLaunchKernelGGL((k_rescore<true, 2>), grid, dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base, out_s, out_r, flagged,
+                               flagged_list, eps_out, stride, qn2_l2);
+        else
+            hipLaunchKernelGGL((k_rescore<false, 2>), grid, dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base, out_s, out_r, flagged,
+                               flagged_list, eps_out, stride, qn2_l2);
+    } else if (qn2_l2)
+        hipLaunchKernelGGL((k_rescore<true, 1>), grid, dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
                            out_s, out_r, flagged, flagged_list, eps_out, stride, qn2_l2);
     else
-        hipLaunchKernelGGL(k_rescore<false>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
+        hipLaunchKernelGGL((k_rescore<false, 1>), grid, dim3(256), 0, s, cand, kp, x, q, nq, k, xnorm_max, dx_max, row_base,
                            out_s, out_r, flagged, flagged_list, eps_out, stride, qn2_l2);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }

@@ -176,7 +176,7 @@ def test_cosine_metric_on_the_screening_path(rmu):
     s, r = idx.search(q, 10)
     assert idx.last_screened() != 0
     assert_topk_parity(s, r, *O.flat_search(q, x, 14, O.METRIC_COSINE))
-    s2, r2 = idx.search(q, 33)
+    s2, r2 = idx.search(q, 112)                      # (k > 104: the exact fp32 scan)
     assert idx.last_screened() == 0 and np.array_equal(r2[:, :10], r) and np.array_equal(s2[:, :10], s)
     idx.close()
 
@@ -347,7 +347,7 @@ def test_screened_search_matches_oracle_and_exact_path(rmu, nq, k):
     assert_topk_parity(s, r, *O.flat_search(q, x, k + 4))      # oracle a few ranks deeper: boundary near-ties
     assert (r[:, 0] == planted).all()
     # bit-identical to the exact fp32 scan (same summation order in the re-score)
-    s2, r2 = idx.search(q, 33)                       # k > 32 always takes the exact scan
+    s2, r2 = idx.search(q, 112)                      # k > 104 always takes the exact scan
     assert idx.last_screened() == 0
     assert np.array_equal(r2[:, :k], r) and np.array_equal(s2[:, :k], s)
     idx.close()
@@ -364,7 +364,7 @@ def test_screened_ladder_matches_oracle_and_exact_path(rmu, n, nq, k):
     s, r = idx.search(q, k)
     assert idx.last_screened() != 0, "expected the screening path"
     assert idx.last_geometry()["launches"] >= 3, "expected a multi-launch ladder"
-    s2, r2 = idx.search(q, 33)                       # exact fp32 scan (k > 32)
+    s2, r2 = idx.search(q, 112)                      # exact fp32 scan (k > 104)
     assert idx.last_screened() == 0
     assert np.array_equal(r2[:, :k], r) and np.array_equal(s2[:, :k], s)          # bit-identical
     assert (r[:, 0] == planted).all()
@@ -382,7 +382,7 @@ def test_screened_ladder_after_deletes_and_reload(rmu, tmp_path):
     idx.remove_rows(dead)
     s, r = idx.search(q, 10)
     assert idx.last_screened() != 0 and not np.isin(r, dead).any()
-    s2, r2 = idx.search(q, 33)
+    s2, r2 = idx.search(q, 112)                      # (k > 104: the exact fp32 scan)
     assert idx.last_screened() == 0 and np.array_equal(r2[:, :10], r) and np.array_equal(s2[:, :10], s)
     path = str(tmp_path / "big.rmu")
     idx.save(path)
@@ -916,10 +916,13 @@ def corpus300k():
 
 @pytest.mark.parametrize("nq,k", [(64, 100), (5, 33), (33, 112), (130, 100), (1, 64)])
 def test_deep_k_ladder_parity_vs_oracle(rmu, corpus300k, nq, k):
+    """The EXACT 128-deep ladder (k > 104 by default; k > 32 with the screening switched off, which is how it is reached here)."""
     x, q, planted = corpus300k
     idx = rmu.FlatIndex(384)
     idx.add(x)
+    idx.set_screening(False)
     s, r = idx.search(q[:nq], k)
+    assert idx.last_screened() == 0
     assert idx.last_geometry()["launches"] >= 2                    # really the ladder (one scan launch per row range)
     assert_topk_parity(s, r, *O.flat_search(q[:nq], x, k + 4))
     assert (r[:, 0] == planted[:nq]).all() and (np.diff(s, axis=1) <= 0).all()
@@ -930,10 +933,66 @@ def test_deep_k_ladder_parity_vs_oracle(rmu, corpus300k, nq, k):
     # ... and so does the single cold launch over a prefix that is too small for the ladder (same rows, same arithmetic)
     small = rmu.FlatIndex(384)
     small.add(x[:200_000])
+    small.set_screening(False)
     s1, r1 = small.search(q[:nq], k)
     assert small.last_geometry()["launches"] == 1
     assert_topk_parity(s1, r1, *O.flat_search(q[:nq], x[:200_000], k + 4))
     small.close(); idx.close()
+
+
+@pytest.mark.parametrize("nq,k", [(64, 100), (5, 33), (130, 64), (1024, 100), (1, 104), (200, 40), (33, 112)])
+def test_deep_k_screening_is_bit_identical_to_the_exact_ladder(rmu, corpus300k, nq, k):
+    """(round 6; BASELINE config 5's dense top-100, server/RAGHelper.py:497-499 with fetch_k = 100) 32 < k <= 104 over >= 262144 rows
+    takes the fp16 screening ladder with K' = k + max(8, k / 5) <= 120 candidates (slots of 128 keys, two keys per lane in the
+    compaction / emit / re-score) + the exact fp32 re-score: ids AND scores bit-identical to the exact fp32 128-deep ladder, for one-tile
+    (nq <= 128) and full-tile geometries; k > 104 stays on the exact ladder."""
+    x, q, planted = corpus300k
+    qq = q[:nq] if nq <= q.shape[0] else np.concatenate([q] * ((nq + q.shape[0] - 1) // q.shape[0]))[:nq]
+    idx = rmu.FlatIndex(384)
+    idx.add(x)
+    s, r = idx.search(qq, k)
+    if k <= 104:
+        assert idx.last_screened() != 0, "expected the screening path"
+    else:
+        assert idx.last_screened() == 0
+    idx.set_screening(False)
+    s2, r2 = idx.search(qq, k)
+    assert idx.last_screened() == 0
+    assert np.array_equal(r2, r) and np.array_equal(s2, s)
+    sub = slice(0, min(nq, 16))
+    assert_topk_parity(s[sub], r[sub], *O.flat_search(qq[sub], x, k + 4))
+    idx.close()
+
+
+def test_deep_k_screening_on_the_l2_index_and_with_near_duplicates(rmu, corpus300k):
+    """k = 100 on the NATIVE squared-L2 index (Milvus' default metric, server/RAGHelper.py:388-394) screens like the inner-product
+    index; 100 near-duplicates in consecutive rows (every candidate in ONE chunk's slot: the compaction path with two keys per lane) and
+    deleted rows."""
+    from ragmeup_amd import _native as N
+    x, q, _ = corpus300k
+    rng = np.random.default_rng(6)
+    dup = x[1000][None, :] + 1e-3 * rng.standard_normal((150, 384)).astype(np.float32)
+    dup /= np.linalg.norm(dup, axis=1, keepdims=True)
+    xd = np.concatenate([x[:150_000], dup, x[150_000:]])
+    qq = np.concatenate([x[1000][None, :], dup[:40], q[:24]])
+    for metric in (N.METRIC_IP, N.METRIC_L2SQ):
+        idx = rmu.FlatIndex(384, metric)
+        idx.add(xd)
+        s, r = idx.search(qq, 100)
+        assert idx.last_screened() != 0
+        idx.set_screening(False)
+        s2, r2 = idx.search(qq, 100)
+        assert idx.last_screened() == 0 and np.array_equal(r2, r) and np.array_equal(s2, s)
+        idx.set_screening(True)
+        assert set(r[0].tolist()) <= set(range(150_000, 150_150)) | {1000}
+        dead = np.arange(0, xd.shape[0], 3)
+        idx.remove_rows(dead)
+        s, r = idx.search(qq[:20], 100)
+        assert not np.isin(r, dead).any()
+        idx.set_screening(False)
+        s2, r2 = idx.search(qq[:20], 100)
+        assert np.array_equal(r2, r) and np.array_equal(s2, s)
+        idx.close()
 
 
 def test_deep_k_ladder_with_clustered_duplicates_tombstones_and_l2(rmu, corpus300k):
@@ -1018,7 +1077,7 @@ def test_repeated_searches_into_caller_owned_tensors_stay_exact(rmu):
     qd.copy_(torch.from_numpy(q2))
     s, r = idx.search(qd, 10, out=out)
     assert (r[:, 0].cpu().numpy() == planted2).all()
-    s_ex, r_ex = idx.search(qd, 33)                             # exact scan (k > 32)
+    s_ex, r_ex = idx.search(qd, 112)                            # exact scan (k > 104)
     assert torch.equal(r_ex[:, :10], r) and torch.equal(s_ex[:, :10], s)
     # rows deleted between two replays of the same graph
     dead = np.unique(planted2[:50])
