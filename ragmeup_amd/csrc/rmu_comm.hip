@@ -145,6 +145,7 @@ extern "C" int rmu_comm_init(rmu_comm_t** out, const void* id, int world, int ra
 }
 
 extern "C" int rmu_comm_world(rmu_comm_t* c, int* world, int* rank) {
+    RMU_ENTRY();
     if (!c) return cfail(RMU_E_INVALID, "rmu_comm_world: null");
     // what RCCL says the communicator is (ncclCommCount / ncclCommUserRank), not what rmu_comm_init was asked for
     int w = c->world, r = c->rank;
