@@ -45,8 +45,10 @@ def build(force: bool = False, verbose: bool = False, debug_kernels: bool = Fals
     asan: a SEPARATE library, lib/librmu_asan.so (objects under lib/obj_asan), whose HOST code -- the C-ABI, the WordPiece tokenizer and
     its thread pool, the index's locking and bookkeeping -- is compiled with AddressSanitizer + UBSan (`make asan-test` runs the CPU
     tests that call into the library against it; device code is not instrumented: GPU sanitizers are not available on this pool)."""
-    objdir = os.path.join(LIBDIR, "obj_asan") if asan else OBJDIR
-    so = os.path.join(LIBDIR, "librmu_asan.so") if asan else SO
+    # (round 6) a debug-kernels build is a separate library as well (lib/librmu_dbg.so): RMU_TUNING=1 RMU_LIB=<that> selects it for one
+    # process, the product library stays in place
+    objdir = os.path.join(LIBDIR, "obj_asan") if asan else os.path.join(LIBDIR, "obj_dbg") if debug_kernels else OBJDIR
+    so = os.path.join(LIBDIR, "librmu_asan.so") if asan else os.path.join(LIBDIR, "librmu_dbg.so") if debug_kernels else SO
     os.makedirs(objdir, exist_ok=True)
     srcs = _sources()
     hdrs = _headers()
@@ -75,5 +77,5 @@ def build(force: bool = False, verbose: bool = False, debug_kernels: bool = Fals
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv or "--debug-kernels" in sys.argv, verbose=True, debug_kernels="--debug-kernels" in sys.argv,
+    print(build(force="--force" in sys.argv, verbose=True, debug_kernels="--debug-kernels" in sys.argv,
                 asan="--asan" in sys.argv))

@@ -616,7 +616,7 @@ constexpr int SMALL_M = 256;                           // tokens (upper bound ba
 // a 16-token query forward 0.182 ms fused / 0.183 apart (no gain: inside a replayed graph a kernel boundary is not the 4.4 us it costs under
 // the profiler, a kernel's own load -> MFMA -> store chain is), the 14-pair rerank forward (1.5k tokens) 0.417 fused / 0.437 apart: the
 // whole folded path takes it.
-constexpr int QKV_ATTN_TOKENS = 2560;
+constexpr int QKV_ATTN_TOKENS = 2560, QKV_ATTN_MIN_TOKENS = 128;
 constexpr int FOLD_TOKENS = 2560;                      // ... and up to which a whole forward runs on it with the LayerNorms folded (enqueue_forward)
 // Round 4: the token dimension is a grid dimension too -- workgroup (x, y) takes features [32 x, +32) of tokens [SMALL_TB y, +SMALL_TB)
 // -- so the same kernel serves a few THOUSAND tokens (the reference's rerank call: <= 14 (query, passage) pairs, ~1.5k tokens,
@@ -4672,7 +4672,11 @@ static void enqueue_forward(rmu_bert* m, const int32_t* ids, const int32_t* type
             // (round 5) up to QKV_ATTN_TOKENS tokens the QKV projection and the attention are ONE launch
             // (k_qkv_attn_small: a workgroup per (head, sequence); bit-identical to the pair below); RMU_QKV_ATTN_TOKENS=0 keeps them apart
             static const int64_t qa_tokens = rmu_env("RMU_QKV_ATTN_TOKENS") ? atoll(rmu_env("RMU_QKV_ATTN_TOKENS")) : QKV_ATTN_TOKENS;
-            if (cap <= qa_tokens) {
+            // (round 6) ... but not below QKV_ATTN_MIN_TOKENS: one short query (16-48 tokens) runs 2.6-4.5 % faster on the two launches (a
+            // workgroup per (head, sequence) is 12 workgroups for one query), the 14-pair rerank call 3.7 % faster on the fused one
+            // (profiles/r06_ab_interactive.txt).  Bit-identical either way.  RMU_QKV_ATTN_MIN=0: fused from the first token on.
+            static const int64_t qa_min = rmu_env("RMU_QKV_ATTN_MIN") ? atoll(rmu_env("RMU_QKV_ATTN_MIN")) : QKV_ATTN_MIN_TOKENS;
+            if (cap <= qa_tokens && cap > qa_min) {
                 if (max_len <= 128) {
                     if (!prev) launch_qkv_attn_small<4, false>(s, batch, m->h, L.wqkv, L.bqkv, cu, nullptr, nullptr, eps, nullptr, m->ctx);
                     else launch_qkv_attn_small<4, true>(s, batch, y2, L.wqkv, L.bqkv, cu, prev->ln2g, prev->ln2b, eps, m->st2, m->ctx);
