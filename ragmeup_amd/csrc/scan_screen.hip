@@ -2574,26 +2574,40 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
     }
     const float* qv = q + qi * stride;
     float qn2 = 0.f, dq2 = 0.f;
-    for (int t = 0; t < SD / 8; ++t) {
-        const f32x4 qa = *(const f32x4*)(qv + 8 * t), qb = *(const f32x4*)(qv + 8 * t + 4);
+    // (round 6) the row pieces of UN steps are requested TOGETHER, then eaten in order: left as one load pair per step the 48-step chain of a
+    // candidate paid a memory round trip per step (24-27 us per launch behind every search; the summation order is untouched)
+    constexpr int UN = NPL == 1 ? 12 : 6;
+    for (int t0 = 0; t0 < SD / 8; t0 += UN) {
+        f32x4 xa[NPL][UN], xb[NPL][UN];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-            const f32x4 xa = *(const f32x4*)(xv[p] + 8 * t), xb = *(const f32x4*)(xv[p] + 8 * t + 4);
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                xa[p][u] = *(const f32x4*)(xv[p] + 8 * (t0 + u));
+                xb[p][u] = *(const f32x4*)(xv[p] + 8 * (t0 + u) + 4);
+            }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int t = t0 + u;
+            const f32x4 qa = *(const f32x4*)(qv + 8 * t), qb = *(const f32x4*)(qv + 8 * t + 4);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[p] = fmaf(xa[p][u][c], qa[c], acc[p]);
+                    acc[p] = fmaf(xb[p][u][c], qb[c], acc[p]);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                acc[p] = fmaf(xa[c], qa[c], acc[p]);
-                acc[p] = fmaf(xb[c], qb[c], acc[p]);
+                const float ua = L2 ? 0.5f * qa[c] : qa[c], ub = L2 ? 0.5f * qb[c] : qb[c];      // the query itself (the L2 index stores 2q)
+                qn2 = fmaf(ua, ua, qn2);
+                qn2 = fmaf(ub, ub, qn2);
+                const float da = ua - (float)(_Float16)(ua * 64.0f) * (1.0f / 64.0f);
+                const float db = ub - (float)(_Float16)(ub * 64.0f) * (1.0f / 64.0f);
+                dq2 = fmaf(da, da, dq2);
+                dq2 = fmaf(db, db, dq2);
             }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ua = L2 ? 0.5f * qa[c] : qa[c], ub = L2 ? 0.5f * qb[c] : qb[c];      // the query itself (the L2 index stores 2q)
-            qn2 = fmaf(ua, ua, qn2);
-            qn2 = fmaf(ub, ub, qn2);
-            const float da = ua - (float)(_Float16)(ua * 64.0f) * (1.0f / 64.0f);
-            const float db = ub - (float)(_Float16)(ub * 64.0f) * (1.0f / 64.0f);
-            dq2 = fmaf(da, da, dq2);
-            dq2 = fmaf(db, db, dq2);
         }
     }
     if (L2) {
