@@ -82,5 +82,5 @@ for wl in "embed 8192" "rerank 6400"; do set -- $wl; name=$1; n=$2; extra=""; [ 
   ENC_DEVICE_IDS=1 timeout -k 5 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$ENCK" --output-format csv -d $OUT/enc_${name}_w -o a -- python $R/tools/enc_smoke.py $n $extra > /dev/null 2>> $OUT/scan.err
   keep enc_${name}_w counter_collection.csv counters
 done
-for d in c2 shard8 enc_embed_f enc_embed_w enc_rerank_f enc_rerank_w top100 enc_pmc scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
+for d in scan_b16 pmc_b16 c2 shard8 enc_embed_f enc_embed_w enc_rerank_f enc_rerank_w top100 enc_pmc scan pmc_a pmc_b pmc_c exact exact_pmc_a exact_pmc_b scan_b1 pmc_b1 exact_b1 exact_pmc_b1 scan_b32 pmc_b32 embed; do rm -rf $OUT/$d; done
 ls -la $OUT
