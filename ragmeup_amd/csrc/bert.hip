@@ -1906,10 +1906,8 @@ __global__ __launch_bounds__(512) void k_ffn3(const bf16* __restrict__ x, const 
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    // (round 6 A/B, RMU_FFN3_PRIO=1|2: static priority for the second-dispatched / the first-dispatched half of the workgroup through the slab loop --
-    // MI355X_MICROARCH.md "two waves per SIMD", item 4)
-    if ((dflags & 4096) && w >= 4) __builtin_amdgcn_s_setprio(1);
-    if ((dflags & 8192) && w < 4) __builtin_amdgcn_s_setprio(1);
+    // (round 6, measured and removed: static s_setprio 1 for either half of the workgroup through the slab loop -- 3 301 / 3 306 vs 3 304 us, nothing;
+    // and the two uniform branches that selected it cost the allocator 196 bytes of scratch in this kernel: NOTES_r06.md 6)
 
     f32x16 acc2[6];                                 // outputs [192 s + 32 j, +32)
 #pragma unroll
@@ -4447,9 +4445,8 @@ static void launch_ffn3_t(const bf16* x, const BertLayer& L, float eps, bf16* ou
     static const hipError_t attr_rc = hipFuncSetAttribute((const void*)k_ffn3<LN_IN, PF, false, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, ffn3::LDS_BYTES);
     (void)attr_rc;
     static const int epi_old = rmu_env("RMU_FFN3_EPI") && atoi(rmu_env("RMU_FFN3_EPI")) == 0 ? 2048 : 0;   // A/B: the round-3/4 epilogue (row-serial LayerNorm 2)
-    static const int prio = rmu_env("RMU_FFN3_PRIO") ? (atoi(rmu_env("RMU_FFN3_PRIO")) == 1 ? 4096 : atoi(rmu_env("RMU_FFN3_PRIO")) == 2 ? 8192 : 0) : 0;
     hipLaunchKernelGGL((k_ffn3<LN_IN, PF, false, VAR>), grid, dim3(512), ffn3::LDS_BYTES, s, x, w1, L.b1, w2, L.b2, L.ln2g, L.ln2b, eps, out, cu, batch,
-                       L.ln1g, L.ln1b, (out_tiled ? 256 : 0) | epi_old | prio);
+                       L.ln1g, L.ln1b, (out_tiled ? 256 : 0) | epi_old);
 }
 #ifdef RMU_DEBUG_KERNELS
 // the attention output in, the layer output out: out-proj + residual + LayerNorm 1 + FFN + LayerNorm 2 in one launch.  MEASURED (8192

@@ -144,3 +144,32 @@ def test_no_device_wide_synchronisation_and_every_entry_point_in_relaxed_capture
     cap = bert.index("hipStreamBeginCapture(")
     assert "rmu_capture_mutex()" in bert[cap - 400:cap]
     assert re.search(r"inline std::mutex& rmu_capture_mutex\(\)", common)
+
+
+def test_no_kernel_of_the_product_library_spills_to_scratch(tmp_path):
+    """(round 6) Two uniform `if`s added to k_ffn3 for an A/B experiment cost the register allocator 196 bytes of scratch per lane: +4.8 GB of
+    HBM traffic per forward and 3.05 -> 3.30 ms per launch, found only because a PMC table looked wrong.  The code objects inside librmu.so
+    carry every kernel's resources: none of the hot kernels may have a private (scratch) segment."""
+    import re
+    import shutil
+    import subprocess
+    from ragmeup_amd import _native
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        import pytest
+        pytest.skip("ROCm's llvm-objdump / llvm-readelf are not installed")
+    so = tmp_path / "librmu.so"
+    shutil.copy(_native.SO_PATH, so)
+    r = subprocess.run([objdump, "--offloading", str(so)], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found, spilled = 0, []
+    for co in sorted(tmp_path.glob("librmu.so.*gfx950")):
+        notes = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True).stdout
+        for name, scratch in re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            found += 1
+            if int(scratch) != 0:
+                spilled.append((name[:70], int(scratch)))
+    assert found > 40, found                                   # the metadata was really read
+    hot = [s for s in spilled if re.search(r"k_ffn3|k_gemm3|k_attn3|k_gemm|scan_screen_lean3|scan_topk|k_qa|k_rescore|merge_select", s[0])]
+    assert hot == [], hot

@@ -12,8 +12,8 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05p"
-RP = sys.argv[2] if len(sys.argv) > 2 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+RP = sys.argv[2] if len(sys.argv) > 2 else "r06"
 src = f"gpurun_out/{tag}"
 STEPS = 22   # tools/profile.sh runs bench.py with --warmup 2 --steps 10; bench.py then repeats 10 searches with per-launch events (roofline pass)
 
@@ -43,7 +43,9 @@ with open(f'profiles/{RP}_pmc_means.csv', 'w') as o:
     o.write('pass,kernel,counter,dispatches,mean_per_dispatch,sum_per_bench_step,wg,lds_block,scratch,vgpr,agpr,sgpr\n')
     for r in rows:
         o.write(','.join(str(x) for x in r) + '\n')
-for t in ['scan', 'exact', 'scan_b1', 'exact_b1', 'scan_b32', 'embed']:
+for t in ['scan', 'exact', 'scan_b1', 'exact_b1', 'scan_b32', 'scan_b16', 'embed']:
+    if not os.path.exists(f'{src}/{t}_stats.csv'):
+        continue
     shutil.copy(f'{src}/{t}_stats.csv', f'profiles/{RP}_{t}_stats.csv')
     open(f'profiles/{RP}_{t}_bench.json', 'w').write(open(f'{src}/{t}_bench.json').read().strip().splitlines()[-1] + '\n')
 
@@ -109,9 +111,10 @@ txt = [
     stats('scan_b1', 'HBM-bound regime: batch 1, default path (fp16 image, 768 B per row, screening ladder with ratio 8)'),
     stats('exact_b1', 'batch 1 forced onto the exact fp32 scan (`RMU_SCREEN=0`, WQ=1 geometry)'),
     stats('scan_b32', 'north-star regime: batch 32 over 10M rows, default path (fp16 image, nt stream, ladder ratio 8)'),
+    stats('scan_b16', 'north-star regime: batch 16 over 10M rows (the leg bench.py reports as roofline.north_star)') if os.path.exists(f'profiles/{RP}_scan_b16_stats.csv') else '',
     stats('embed', 'encoder: 8192-chunk calls x ~128 tokens (BERT-6x384, bf16 MFMA; k_ffn3 / k_attn3 / k_gemm3 / k_gemm)'),
     "## PMC passes (separate runs, `--kernel-trace --pmc ...` only)\n",
-    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK1), line('exact_pmc_b1', B1), line('pmc_b32', SK1),
+    line('pmc_a', SK), line('pmc_b', SK), line('pmc_c', SK), line('exact_pmc_a', EK), line('exact_pmc_b', EK), line('pmc_b1', SK1), line('exact_pmc_b1', B1), line('pmc_b32', SK1), line('pmc_b16', SK1) if ('pmc_b16', SK1) in pm else '',
     "\n## Derived (FETCH_SIZE is in KiB and under-reports by 2x on gfx950 per MI355X_MICROARCH.md -> bytes = FETCH_SIZE x 1024 x 2)\n",
     f"- screening launches, per batch: HBM fetch {scr_fetch/1e9:.2f} GB + write {scr_write/1e6:.1f} MB; the fp16 image is 7.68 GB and each of the 4 "
     f"query-tile workgroups of a row chunk streams it (L2 hit {hit:.3f}; ideal 0.75), i.e. x{scr_fetch/7.68e9:.2f} the image, x{scr_fetch/15.36e9:.2f} the "
@@ -122,6 +125,7 @@ txt = [
     f"MFMA busy {f('exact_pmc_a',EK,'SQ_VALU_MFMA_BUSY_CYCLES')/(f('exact_pmc_a',EK,'GRBM_GUI_ACTIVE')*128):.3f} of SIMD-cycles; mean clock {clk_e:.2f} GHz",
     f"- batch 1, default path: HBM fetch {f('pmc_b1',SK1,'FETCH_SIZE')*2048/1e9:.3f} GB per query over all launches vs the 7.680 GB image (x{f('pmc_b1',SK1,'FETCH_SIZE')*2048/7.68e9:.4f})",
     f"- batch 32, default path: HBM fetch {f('pmc_b32',SK1,'FETCH_SIZE')*2048/1e9:.3f} GB per batch over all launches vs the 7.680 GB image (x{f('pmc_b32',SK1,'FETCH_SIZE')*2048/7.68e9:.4f})",
+    (f"- batch 16, default path: HBM fetch {f('pmc_b16',SK1,'FETCH_SIZE')*2048/1e9:.3f} GB per batch over all launches vs the 7.680 GB image (x{f('pmc_b16',SK1,'FETCH_SIZE')*2048/7.68e9:.4f})" if ('pmc_b16', SK1) in pm else ''),
     f"- batch 1, exact scan: HBM fetch {f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/1e9:.3f} GB per launch vs 15.360 GB algorithmic (x{f('exact_pmc_b1',B1,'FETCH_SIZE')*2048/15.36e9:.4f}) -- no wasted re-reads",
 ]
 open(f'profiles/{RP}_summary.md', 'w').write("\n".join(txt) + "\n")
@@ -193,7 +197,8 @@ json.dump({"source": f"tools/profile.sh {tag} -> tools/summarize_profiles.py: su
                      f"+ WRITE_SIZE where collected) x 1024, profiles/{RP}_pmc_means.csv",
            "entries": [{"path": "screen", "rows": 10_000_000, "batch": 1024, "bytes_per_step": scr_fetch + scr_write},
                        {"path": "screen", "rows": 10_000_000, "batch": 32, "bytes_per_step": f('pmc_b32', SK1, 'FETCH_SIZE') * 2048},
-                       {"path": "screen", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('pmc_b1', SK1, 'FETCH_SIZE') * 2048},
+                       {"path": "screen", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('pmc_b1', SK1, 'FETCH_SIZE') * 2048}]
+                      + ([{"path": "screen", "rows": 10_000_000, "batch": 16, "bytes_per_step": f('pmc_b16', SK1, 'FETCH_SIZE') * 2048}] if ('pmc_b16', SK1) in pm else []) + [
                        {"path": "exact", "rows": 10_000_000, "batch": 1024, "bytes_per_step": f('exact_pmc_b', EK, 'FETCH_SIZE') * 2048},
                        {"path": "exact", "rows": 10_000_000, "batch": 1, "bytes_per_step": f('exact_pmc_b1', B1, 'FETCH_SIZE') * 2048}] + enc_entries},
           open(f'profiles/{RP}_traffic.json', 'w'), indent=1)
