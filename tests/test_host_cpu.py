@@ -832,3 +832,122 @@ def test_a_next_round_that_fails_to_start_does_not_skip_the_finished_round_in_fr
     emb.enqueue_fails_on = None
     assert emb.enqueued == [200]
     assert len(pip) == len(pip._index) == len(pip._texts) == 200 and "199" in pip._pk_to_row and "200" not in pip._pk_to_row
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("inflight", [False, True], ids=["two_halves", "enqueue_interface"])
+def test_randomised_differential_pipelined_store_vs_serial_store(seed, inflight):
+    """the insert pipeline is the most fragile host code in the tree.  A seeded random walk -- synchronous adds, adds
+    inside an insert loop (deferred halves, coalesced forwards), calls larger than one pipeline block, upserts, deletes by source / by
+    id, searches, flushes, and forwards that FAIL (everything queued since the last flush must roll back, the store must stay usable) --
+    on the pipelined store and on a serial store that is given only the operations that must survive; after every step group both hold
+    the same live (pk -> text) map, the same row / record alignment invariants, and answer searches with the same (pk, score) lists."""
+    import random
+    rnd = random.Random(1000 * seed + (7 if inflight else 0))
+    emb = EnqueueEmbeddings() if inflight else TokenEmbeddings()
+    emb.pipeline_block = rnd.choice([300, 500, 8192])
+    pip = PipeStore(embeddings=emb, collection_name=f"rw{seed}", auto_persist=False, pipeline_inserts=rnd.choice([True, "auto"]), pipeline_window=30.0)
+    pip.pipeline_depth = rnd.choice([1, 2, 8])
+    ser = FakeStore(embeddings=HashEmbeddings(), collection_name=f"rs{seed}", auto_persist=False, pipeline_inserts=False)
+    next_id = [0]
+
+    def make_docs(n, upsert_frac):
+        docs, ids = [], []
+        for _ in range(n):
+            if next_id[0] > 0 and rnd.random() < upsert_frac:
+                i = rnd.randrange(next_id[0])                 # an id seen before: upsert (possibly of a deleted pk, possibly twice in one call)
+            else:
+                i = next_id[0]; next_id[0] += 1
+            ver = rnd.randrange(1_000_000)
+            docs.append(Document(f"doc {i} version {ver} " + "w " * (i % 5), {"source": f"src{i % 7}", "id": str(i)}))
+            ids.append(str(i))
+        return docs, ids
+
+    def live(store):
+        store.flush() if hasattr(store, "flush") else None
+        return {pk: store._texts[r] for pk, r in store._pk_to_row.items() if store._alive[r]}
+
+    def check():
+        a, b = live(pip), live(ser)
+        assert a == b, (sorted(set(a) ^ set(b))[:5], [(k, a[k], b[k]) for k in a if k in b and a[k] != b[k]][:3])
+        n_index = len(pip._index) if pip._index is not None else 0           # (the index is built with the first insert)
+        assert not pip._pending and n_index == len(pip._texts) == len(pip._alive) == len(pip._pks) == len(pip._metas)
+        assert len(pip) == len(a)
+        for qtext in ("doc 3 version", "w w w", f"doc {max(next_id[0] - 1, 0)}"):
+            ra = [(d.metadata["pk"], round(float(s), 6)) for d, s in pip.similarity_search_with_score(qtext, k=5)]
+            rb = [(d.metadata["pk"], round(float(s), 6)) for d, s in ser.similarity_search_with_score(qtext, k=5)]
+            assert ra == rb, (qtext, ra, rb)
+
+    for step in range(18):
+        op = rnd.random()
+        if op < 0.55:                                           # a run of adds (a loop), no failure
+            for _ in range(rnd.randrange(1, 5)):
+                n = rnd.choice([1, 5, 60, 130, 200, 350, 620, 900])
+                docs, ids = make_docs(n, upsert_frac=rnd.choice([0.0, 0.1, 0.5]))
+                assert pip.add_documents(docs, ids=ids) == ids
+                ser.add_documents(docs, ids=ids)
+        elif op < 0.70 and next_id[0] > 0:                      # delete by source or by ids
+            if rnd.random() < 0.5:
+                src = f"src{rnd.randrange(7)}"
+                assert pip.delete(expr=f'source == "{src}"').delete_count == ser.delete(expr=f'source == "{src}"').delete_count
+            else:
+                ids = [str(rnd.randrange(next_id[0])) for _ in range(rnd.randrange(1, 40))]
+                pip.delete(ids=ids); ser.delete(ids=ids)
+        elif op < 0.85 and next_id[0] > 0:                      # a forward fails: every call issued since the last flush rolls back
+            pip.flush()
+            before = live(pip)
+            saved_next = next_id[0]
+            if inflight:
+                emb.enqueue_fails_on = None
+                emb.sync_fails_on = None
+            bad = [make_docs(rnd.choice([150, 300, 450]), upsert_frac=0.3) for _ in range(rnd.randrange(1, 4))]
+            if inflight:
+                # (round numbers restart per pump; the first forward of this group fails at its event wait)
+                orig = emb.enqueue_token_arrays
+
+                def failing(toks, round_no, _o=orig):
+                    out, done = _o(toks, round_no)
+
+                    class Boom:
+                        def synchronize(self):
+                            raise RuntimeError("injected device failure")
+                    return out, Boom()
+                emb.enqueue_token_arrays = failing
+            else:
+                emb.fail_on = len(emb.forwards) + 1
+            raised = False
+            try:
+                for docs, ids in bad:
+                    pip.add_documents(docs, ids=ids)             # (a synchronous or block-wise call raises here itself)
+                pip.flush()
+            except RuntimeError as e:
+                raised = "injected device failure" in str(e) or "device lost" in str(e) or "skipped" in str(e)
+            if inflight:
+                emb.enqueue_token_arrays = orig
+            else:
+                emb.fail_on = None
+            assert raised
+            try:
+                pip.flush()
+            except RuntimeError:
+                pass
+            next_id[0] = saved_next                               # the serial store never saw these ids
+            after = live(pip)
+            # calls in FRONT of the failing forward may have been inserted (block-wise calls are not atomic; a synchronous small call in the
+            # group succeeds on its own): whatever did get in must be a valid state -- bring the serial store to it
+            if after != before:
+                changed = {pk for pk in set(after) | set(before) if after.get(pk) != before.get(pk)}
+                for pk in changed:
+                    if pk in after:
+                        i = int(pk)
+                        ser.add_documents([Document(after[pk], {"source": f"src{i % 7}", "id": pk})], ids=[pk])
+                        next_id[0] = max(next_id[0], i + 1)
+                    else:
+                        ser.delete(ids=[pk])
+        else:
+            pip.flush()
+        if step % 3 == 2:
+            check()
+    check()
+    if hasattr(emb, "pipeline_block"):
+        del emb.pipeline_block
