@@ -15,6 +15,10 @@
  *                 next call on any other stream (or stream 0) is ordered behind it -- consecutive calls from one thread
  *                 never overlap on the device, whichever streams they name; use one thread per concurrent stream.
  *   - thread-safe: searches on one index run concurrently (shared lock); add/remove are exclusive.
+ *   - a good neighbour in the host process (the reference runs its LLM in PyTorch on the same GPU, RAGHelper_local.py:42-105): no entry point
+ *     synchronises the whole device or issues a synchronous copy -- a writer (add that re-allocates, remove_rows, free) waits for exactly
+ *     the streams on which searches of that index are still in flight -- and every entry point runs with the calling thread's stream-capture
+ *     interaction mode set to relaxed for its duration, so a hipGraph / torch.cuda.graph capture on another thread is never invalidated.
  *   - row ids are int64 row numbers in insertion order; pk/metadata mapping stays in the host language.
  */
 #ifndef RMU_H_
@@ -129,7 +133,7 @@ int rmu_index_search_mmr(rmu_index_t* idx, const float* q, int64_t nq, int fetch
 int rmu_index_save(rmu_index_t* idx, const char* path);
 int rmu_index_load(rmu_index_t** out, const char* path);
 
-/* Exact top-k of every query against all live rows (dim 384, k <= 32, any metric: fp16 screening + exact fp32 re-score under a
+/* Exact top-k of every query against all live rows (dim 384, k <= 104, any metric: fp16 screening + exact fp32 re-score under a
  * per-query sufficiency test; otherwise, and for every query that fails the test, the exact fp32 fused scan -- the
  * returned ids and scores are those of the exact scan either way; the failing queries are re-run by launches that are
  * predicated on the device, so the call never waits on the host for a decision and, given a caller stream with device
