@@ -537,11 +537,16 @@ class MI355XVectorStore(VectorStore):
 
     def _round_failed(self, items, e):
         self._pipe_failed = True
-        # said where it happens: with deferred halves the RuntimeError itself is raised by whichever call touches the store next
-        _log.get_logger().error(f"ragmeup_amd: a deferred insert of collection {self.collection_name!r} failed ({type(e).__name__}: {e}); "
-                                f"{sum(it[2] for it in items)} records of {len(items)} add_texts call(s) and everything queued behind them are rolled back")
+        # the futures FIRST: an injected logger that raises (the reference's, factory.from_env(logger=)) must not leave a caller waiting
         for it in items:
-            it[4].set_exception(e)
+            if not it[4].done():
+                it[4].set_exception(e)
+        # said where it happens: with deferred halves the RuntimeError itself is raised by whichever call touches the store next
+        try:
+            _log.get_logger().error(f"ragmeup_amd: a deferred insert of collection {self.collection_name!r} failed ({type(e).__name__}: {e}); "
+                                    f"{sum(it[2] for it in items)} records of {len(items)} add_texts call(s) and everything queued behind them are rolled back")
+        except Exception:   # noqa: BLE001 - a logging failure is not the insert's failure
+            pass
 
     def _finish_round(self, items, tok, handle):
         import contextlib
