@@ -85,6 +85,31 @@ def timed(fn, steps: int, warmup: int) -> float:
     return (time.perf_counter() - t0) * 1e3 / steps
 
 
+SUSTAINED = {}     # filled once per run by measure_sustained() (rank 0, on the GPU)
+
+
+def measure_sustained(millis: int = 350) -> dict:
+    """What THIS GPU sustains on v_mfma_f32_32x32x16 when the operands are data (rmu_probe_mfma_rate, csrc/mfma_probe.hip): random operands
+    that change from MFMA to MFMA, two waves per SIMD on every CU, (a) nothing else in the loop, f16 and bf16, (b) f16 with the screening
+    kernel's operand delivery beside the MFMAs (one 1-KiB LDS fragment read per MFMA + its LDS-DMA fill rate).  The nominal peak (2.5
+    PFLOP/s, reached on CONSTANT operands: profiles/r06_mfma_power.txt) stays the `peak` of every roofline block; these are reported next
+    to it, measured on the same box in the same run."""
+    import ctypes
+    from ragmeup_amd import _native as N
+    lib = N.lib()
+    out = {}
+    for key, dtype, variant in (("f16_mfma_only", 0, 0), ("f16_lds_read_per_mfma_plus_dma_fill", 0, 1), ("bf16_mfma_only", 1, 0)):
+        v = ctypes.c_double(0.0)
+        rc = lib.rmu_probe_mfma_rate(dtype, variant, int(millis), ctypes.byref(v))
+        out[key] = round(v.value, 1) if rc == 0 else None
+    out["unit"] = "TFLOP/s"
+    out["basis"] = ("rmu_probe_mfma_rate: random N(0, 3.3) operands changing every MFMA, 8 waves per CU, mean of the last half of ~%d ms of "
+                    "back-to-back launches; constant operands reach the nominal 2.5 PFLOP/s, data does not (power)" % millis)
+    SUSTAINED.clear()
+    SUSTAINED.update(out)
+    return out
+
+
 def scan_roofline(index, run, n_rows: int, d: int, nq: int, k: int, steps: int) -> dict:
     """Roofline block of the dense scan: launch durations by hipEvents inside librmu.so (rmu_last_scan_ms = sum over the
     scan launches of one search), algorithmic work of those launches, the roof that binds."""
@@ -290,6 +315,8 @@ def encoder_roofline(tf: float, traffic_key=None) -> dict:
     traffic = TRAFFIC.get(traffic_key) if traffic_key else None
     return {"traffic_source": TRAFFIC_SOURCE if traffic else None, "kernel": "whole forward: k_ffn3 (bf16 MFMA 32x32x16, two waves per SIMD: LayerNorm1 + FFN1 + GELU + FFN2 + residual + LayerNorm2), k_gemm3 (persistent 32x32x16 GEMM: QKV), k_gemm (16x16x32: out-proj + residual, both operands as 1-KiB tiled blocks), k_attn3 (32x32x16, two-pass softmax off the MFMA accumulator), k_embed_ln, k_pool", "bound": "mfma", "achieved": round(tf, 2),
             "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
+            "sustained_bf16_mfma_only": SUSTAINED.get("bf16_mfma_only"),
+            "frac_of_sustained": round(tf / SUSTAINED["bf16_mfma_only"], 4) if SUSTAINED.get("bf16_mfma_only") else None,
             "basis": "21.23 MFLOP + 6*4*L*384 per real (unpadded) token; duration = host-bracketed whole forward (all launches); traffic = HBM bytes of ONE "
                      "forward of this workload, all encoder kernels (2 x FETCH_SIZE + WRITE_SIZE)"}
 
@@ -920,7 +947,7 @@ def _compact_roofline(r, top=False):
     if not r:
         return None
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes", "algorithmic_flops", "path",
-            "mfma_frac", "hbm_frac") if top else ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms")
+            "mfma_frac", "hbm_frac") if top else ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "frac_of_sustained")
     o = {k: r[k] for k in keep if k in r}
     if isinstance(o.get("traffic"), float):
         o["traffic"] = int(o["traffic"])
@@ -935,6 +962,8 @@ def _compact_roofline(r, top=False):
             o["north_star"] = ns
         if r.get("emulated_shard_8"):
             o["emulated_shard_8"] = r["emulated_shard_8"]
+        if isinstance(r.get("sustained"), dict):
+            o["sustained"] = {k: v for k, v in r["sustained"].items() if k != "basis"}
     return o
 
 
@@ -1186,6 +1215,18 @@ def main(argv=None, hooks=None):
         if world > 1:
             dist.destroy_process_group()
         return
+
+    if on_gpu and roofline is not None:
+        # the rates the part sustains on data, next to the nominal peaks (same box, same run; ~1 s)
+        try:
+            sus = measure_sustained()
+            roofline["sustained"] = dict(sus)
+            if roofline.get("bound") == "mfma" and roofline.get("path", "").startswith("screen") and sus.get("f16_mfma_only"):
+                roofline["sustained"]["frac_of_f16_mfma_only"] = round(roofline["achieved"] / sus["f16_mfma_only"], 4)
+                if sus.get("f16_lds_read_per_mfma_plus_dma_fill"):
+                    roofline["sustained"]["frac_of_f16_skeleton"] = round(roofline["achieved"] / sus["f16_lds_read_per_mfma_plus_dma_fill"], 4)
+        except Exception as e:       # a diagnostic: never the reason a bench line is missing
+            roofline["sustained"] = {"error": repr(e)[:200]}
 
     ms_per_step = elapsed * 1e3 / args.steps
     qps = B * args.steps / elapsed

@@ -186,6 +186,13 @@ int rmu_last_scan_geometry(int* grid, int* block, int* lds_bytes, int* passes);
 int rmu_last_screened(void);
 /* Enable (1) / disable (0) the event timing above for the calling thread (off by default). */
 int rmu_set_timing(int on);
+/* Diagnostic for bench.py (no reference counterpart): the rate in TFLOP/s THIS GPU sustains on v_mfma_f32_32x32x16 with operands that change
+ * from instruction to instruction (random N(0, 3.3) values: the fp16 image's distribution) -- the power-limited roof a kernel working on data
+ * can approach, as opposed to the nominal peak reached on constant operands (tools/ubench/mfma_power.hip, profiles/r06_mfma_power.txt).
+ * dtype 0 = f16, 1 = bf16.  variant 0 = nothing but MFMAs (two waves per SIMD on every CU); variant 1 (f16 only) = the screening kernel's operand
+ * delivery beside them: one 1-KiB LDS fragment read per MFMA + one 1-KiB LDS-DMA piece per wave and 8 MFMAs.  Runs ~millis ms of back-to-back
+ * launches on a stream of its own and returns the mean of the last half of them.  Thread-safe; allocates and frees its own buffers. */
+int rmu_probe_mfma_rate(int dtype, int variant, int millis, double* tflops_out);
 
 /* ---- BERT-6x384 encoder (bi-encoder and cross-encoder forwards) -------------------------------
  * Serves: HuggingFaceEmbeddings.embed_documents / embed_query (RAGHelper_local.py:107-117 via

@@ -28,7 +28,7 @@ SYMBOLS = [
     "rmu_init", "rmu_last_error", "rmu_version",
     "rmu_index_create", "rmu_index_free", "rmu_index_size", "rmu_index_dim", "rmu_index_metric", "rmu_index_set_option", "rmu_index_stat", "rmu_index_reserve", "rmu_index_add",
     "rmu_index_remove_rows", "rmu_index_get_rows", "rmu_index_save", "rmu_index_load", "rmu_index_mmr", "rmu_index_search_mmr", "rmu_index_search", "rmu_topk_merge",
-    "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing", "rmu_last_screened",
+    "rmu_last_scan_ms", "rmu_last_search_ms", "rmu_last_scan_geometry", "rmu_set_timing", "rmu_last_screened", "rmu_probe_mfma_rate",
     "rmu_comm_unique_id", "rmu_comm_init", "rmu_comm_free", "rmu_comm_world", "rmu_shard_allgather_topk", "rmu_index_screen_candidates",
     "rmu_bert_create", "rmu_bert_free", "rmu_bert_encode", "rmu_bert_encode_host", "rmu_bert_search_mmr",
     "rmu_tok_create", "rmu_tok_free", "rmu_tok_vocab_size", "rmu_tok_encode", "rmu_tok_encode_blob",
@@ -78,6 +78,7 @@ def _declare(lib):
     lib.rmu_last_search_ms.restype = f32
     lib.rmu_last_scan_geometry.argtypes = [c.POINTER(i32)] * 4
     lib.rmu_set_timing.argtypes = [i32]
+    lib.rmu_probe_mfma_rate.argtypes = [i32, i32, i32, c.POINTER(c.c_double)]
     lib.rmu_tok_create.argtypes = [c.POINTER(vp), c.c_char_p, i32]
     lib.rmu_tok_free.argtypes = [vp]
     lib.rmu_tok_vocab_size.argtypes = [vp]

@@ -39,6 +39,11 @@ def test_invalid_arguments_fail_without_gpu(librmu):
     assert b"metric" in librmu.rmu_last_error()
     assert librmu.rmu_index_search(None, None, 1, 10, 0, 0, None, None, 0) == -1
     assert librmu.rmu_topk_merge(None, None, 1, 1, 10, 0, None, None, 0) == -1
+    v = ctypes.c_double(0.0)
+    assert librmu.rmu_probe_mfma_rate(0, 0, 100, None) == -1
+    assert librmu.rmu_probe_mfma_rate(2, 0, 100, ctypes.byref(v)) == -1
+    assert librmu.rmu_probe_mfma_rate(1, 1, 100, ctypes.byref(v)) == -1       # (the LDS / DMA skeleton is the f16 kernel's)
+    assert librmu.rmu_probe_mfma_rate(0, 0, 0, ctypes.byref(v)) == -1
 
 
 def test_product_never_imports_the_oracle():
