@@ -1636,6 +1636,50 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int part = s_idx;
     constexpr int GE = DEEP ? 8 : 32;
+    // (round 6, second session) ONE query tile (NWV = 4, batches <= 128 queries): the queries live in the first ceil(nq / 32) waves, and a slot
+    // is sorted by a whole wave, one query after the other (rank_keys: n x ~8 instructions per query) -- a COLD range (the ladder's first: every
+    // row of its tiles is a candidate, n = 32..40) kept ONE wave busy for ~1.6 us per query while three idled: 34 us of the batch-16 search and
+    // 59 us of the batch-32 one (profiles/r06_search_timeline.txt).  The slots are in global memory, so any wave can sort any query: the
+    // counts go through the waves' (now idle) threshold words in LDS and query q is emitted by wave q % 4.  Same keys, same ranks, same bytes.
+    if constexpr (NWV == 4) {
+        if (lane < 32) lds_store_b32(lds_addr(ssm + C::GT_OFF + w * 256) + (u32)lane * 4u, cnt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const u32* call = (const u32*)(ssm + C::GT_OFF);
+        for (int e0 = 0; e0 < 32; e0 += GE) {
+            if (w + 4 * e0 >= a.nq) break;
+            u64 key[GE][C::NPL];
+            u32 nn[GE];
+#pragma unroll
+            for (int e = 0; e < GE; ++e) {
+                const int qq = w + 4 * (e0 + e);
+                const bool ok = qq < a.nq;
+                nn[e] = ok ? (u32)__builtin_amdgcn_readfirstlane((int)call[(qq >> 5) * 64 + (qq & 31)]) : 0u;
+                const u64* slot = a.gcand + ((size_t)s_idx * a.nq + (ok ? qq : 0)) * C::CAP;
+#pragma unroll
+                for (int pp = 0; pp < C::NPL; ++pp)
+                    key[e][pp] = (u32)(lane + 64 * pp) < nn[e] ? __hip_atomic_load(slot + lane + 64 * pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+#pragma unroll
+            for (int e = 0; e < GE; ++e) {
+                const int qq = w + 4 * (e0 + e);
+                if (qq < a.nq) {
+                    u32 rank[C::NPL];
+                    rank_keys<C::NPL>(key[e], nn[e], rank);
+                    u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+#pragma unroll
+                    for (int pp = 0; pp < C::NPL; ++pp) {
+                        const int le = lane + 64 * pp;
+                        if ((u32)le < nn[e]) {
+                            if (rank[pp] < (u32)a.k) dst[rank[pp]] = key[e][pp];
+                        } else if (le < a.k) {
+                            dst[le] = 0ull;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
     for (int j0 = 0; j0 < 32; j0 += GE) {
         if (q_base + j0 >= a.nq) break;
         u64 key[GE][C::NPL];
@@ -1668,6 +1712,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
                 }
             }
         }
+    }
     }
 }
 
