@@ -1109,7 +1109,11 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
         S.prog = nullptr;
         if (S.pace) { S.prog = prog_next; prog_next += (size_t)S.s_chunks * 4; }
         S.partial = base + (size_t)cursor * part_keys;
-        S.gthr = (u32*)t.gthr.p; S.share_thr = sflags; S.dbg = g_dbg; S.q = (const float*)t.qsplit.p;
+        // (round 6) the FIRST launch is cold -- one tile per chunk, every row a candidate -- and its slots leave unsorted (share_thr bit 2; its merge
+        // below is told): sorting 32 keys for each of a workgroup's 256 queries was ~25 us of a launch that scans 2 000 rows.  RMU_EMIT_RAW=0: never.
+        static const int emit_raw = (rmu_env("RMU_EMIT_RAW") && atoi(rmu_env("RMU_EMIT_RAW")) == 0) ? 0 : 4;
+        const int raw = l == 0 ? emit_raw : 0;
+        S.gthr = (u32*)t.gthr.p; S.share_thr = sflags | raw; S.dbg = g_dbg; S.q = (const float*)t.qsplit.p;
         S.gcand = S.kv >= 1 ? (u64*)t.gcand.p : nullptr;
         if (timed) HIP_TRY(hipEventRecord(t.lev[(size_t)(2 * l)], s));
         rc = rmu_screen_launch(&S, s);
@@ -1119,7 +1123,7 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
         if (g_dbg) dbg_dump("screen range", S.n_rows, s);
         u64* merged = l + 1 < nl ? base + (size_t)cursor * part_keys : (u64*)t.ckeys.p;
         rc = rmu_merge_to_keys_launch(base + (size_t)first * part_keys, cursor - first, nb, kp, merged,
-                                      l + 1 < nl ? (u32*)t.gthr.p : nullptr /* merge + seed in one launch */, s);
+                                      l + 1 < nl ? (u32*)t.gthr.p : nullptr /* merge + seed in one launch */, s, raw ? 1 : 0);
         if (rc) return fail(rc, "rmu_index_search: screening merge / threshold seeding");
     }
     *n_launches = nl;

@@ -172,7 +172,8 @@ struct ScanLaunch {
     int nq;
     int k;
     u64* partial;          // [parts, nq, k] keys
-    int share_thr;         // 1 = read the shared thresholds (0: publish only; debugging aid)
+    int share_thr;         // bit 0 = read the shared thresholds (0: publish only; debugging aid); bit 1 = no filter (timing ablation); bit 2 (screening scan) =
+                           // emit slots of <= k entries unsorted (the launch's merge must be told: rmu_merge_to_keys_launch(..., unsorted = 1))
     u32* gthr;             // [nq] shared per-query threshold (order-preserving u32 image, 0 = none), zeroed per launch
     int parts;             // filled by the planner
     u64* dbg;              // optional debug counters (nullptr in production): [0] slow tiles, [1] compactions, [2] appends, [3] tiles
@@ -200,7 +201,7 @@ int rmu_merge_final_launch(const u64* partial, int parts, int64_t nq, int k, int
                            float* out_scores, int64_t* out_rows, const int64_t* scatter /* or null */, const RmuCond* cond /* or null */,
                            hipStream_t s);
 int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr /* or null */,
-                             hipStream_t s);
+                             hipStream_t s, int unsorted = 0 /* the lists are compact but not sorted (ScanLaunch::share_thr bit 2) */);
 // fp16 screening path (scan_screen.hip)
 #define RMU_IMG_ROW_BYTES 768                          /* fp16(64 x) image of a 384-d row */
 int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s, int stride = 384,

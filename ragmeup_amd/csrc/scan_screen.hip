@@ -1636,6 +1636,10 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int part = s_idx;
     constexpr int GE = DEEP ? 8 : 32;
+    // share_thr bit 2 (the ladder's FIRST launch: rmu_api.hip screen_enqueue): slots of at most K' entries are written as they are -- compact,
+    // zeros behind them, NOT sorted -- and that launch's merge runs in its unsorted mode (topk_merge.hip).  A cold range is one tile per chunk,
+    // every row a candidate: sorting 32 keys for each of a workgroup's 256 queries was ~25 us of VALU time in a launch that scans 2 000 rows.
+    const bool emit_raw = (a.share_thr & 4) != 0;
     // (round 6, second session) ONE query tile (NWV = 4, batches <= 128 queries): the queries live in the first ceil(nq / 32) waves, and a slot
     // is sorted by a whole wave, one query after the other (rank_keys: n x ~8 instructions per query) -- a COLD range (the ladder's first: every
     // row of its tiles is a candidate, n = 32..40) kept ONE wave busy for ~1.6 us per query while three idled: 34 us of the batch-16 search and
@@ -1664,9 +1668,17 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
             for (int e = 0; e < GE; ++e) {
                 const int qq = w + 4 * (e0 + e);
                 if (qq < a.nq) {
+                    u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+                    if (emit_raw && nn[e] <= (u32)a.k) {       // (uniform) the slot as it is, zeros behind it: the merge of this launch does not need it sorted
+#pragma unroll
+                        for (int pp = 0; pp < C::NPL; ++pp) {
+                            const int le = lane + 64 * pp;
+                            if (le < a.k) dst[le] = (u32)le < nn[e] ? key[e][pp] : 0ull;
+                        }
+                        continue;
+                    }
                     u32 rank[C::NPL];
                     rank_keys<C::NPL>(key[e], nn[e], rank);
-                    u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
 #pragma unroll
                     for (int pp = 0; pp < C::NPL; ++pp) {
                         const int le = lane + 64 * pp;
@@ -1698,9 +1710,17 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
         for (int e = 0; e < GE; ++e) {
             const int qq = q_base + j0 + e;
             if (qq < a.nq) {
+                u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
+                if (emit_raw && nn[e] <= (u32)a.k) {
+#pragma unroll
+                    for (int pp = 0; pp < C::NPL; ++pp) {
+                        const int le = lane + 64 * pp;
+                        if (le < a.k) dst[le] = (u32)le < nn[e] ? key[e][pp] : 0ull;
+                    }
+                    continue;
+                }
                 u32 rank[C::NPL];
                 rank_keys<C::NPL>(key[e], nn[e], rank);
-                u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
 #pragma unroll
                 for (int pp = 0; pp < C::NPL; ++pp) {
                     const int le = lane + 64 * pp;

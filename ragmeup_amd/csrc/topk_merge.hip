@@ -109,6 +109,7 @@ struct MergeOut {
                           // (the batch's queries: a conditional re-run of the flagged queries scatters into them)
     const float* qnorm2;
     const int64_t* scatter;   // optional: query i writes output row scatter[i] (patching re-run queries into the batch)
+    int unsorted;             // the part lists are compact (zeros last) but NOT sorted: the screening ladder's first launch (scan_screen.hip, share_thr bit 2)
 };
 template <int NPL>
 __global__ __launch_bounds__(1024) void merge_wg_kernel(const u64* __restrict__ partial, int parts, int64_t nq, int k, int wpq,
@@ -200,7 +201,18 @@ __global__ __launch_bounds__(BLOCK) void merge_select_kernel(const u64* __restri
     constexpr int NW = BLOCK / 64;
     const u64* base = partial + q * k;
     const int64_t pstride = nq * k;
-    for (int p = tid; p < parts; p += BLOCK) heads[p] = base[(int64_t)p * pstride];
+    if (o.unsorted) {            // heads = the maximum of each list (LDS atomics), not its first entry
+        for (int p = tid; p < parts; p += BLOCK) heads[p] = 0ull;
+        __syncthreads();
+        const int total = parts * k;
+        for (int i = tid; i < total; i += BLOCK) {
+            const int part = i / k, pos = i - part * k;
+            const u64 key = base[(int64_t)part * pstride + pos];
+            if (key) atomicMax((unsigned long long*)&heads[part], (unsigned long long)key);
+        }
+    } else {
+        for (int p = tid; p < parts; p += BLOCK) heads[p] = base[(int64_t)p * pstride];
+    }
     if (tid == 0) { count = 0u; tau_s = 0ull; }
     __syncthreads();
     if (parts >= k) {
@@ -221,7 +233,10 @@ __global__ __launch_bounds__(BLOCK) void merge_select_kernel(const u64* __restri
             if (part < parts && pos < k) key = base[(int64_t)part * pstride + pos];
             const bool take = key != 0ull && key >= tau;
             const u64 bal = __ballot(take);
-            if (!bal) break;
+            if (!bal) {
+                if (o.unsorted && __ballot(key != 0ull)) continue;     // an unsorted list may hold its keys >= tau further back: only an EMPTY slab ends it
+                break;
+            }
             u32 at = 0;
             if (lane == 0) at = atomicAdd(&count, (u32)__builtin_popcountll(bal));
             at = __shfl(at, 0) + (u32)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
@@ -344,9 +359,9 @@ int rmu_merge_final_launch(const u64* partial, int parts, int64_t nq, int k, int
 }
 
 // merge to keys (screening ladder): out_keys [nq, k]; seed_thr (optional) receives the merged k-th best per query
-int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr, hipStream_t s) {
+int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u64* out_keys, u32* seed_thr, hipStream_t s, int unsorted) {
     MergeOut o{};
-    o.keys = out_keys; o.seed_thr = seed_thr;
+    o.keys = out_keys; o.seed_thr = seed_thr; o.unsorted = unsorted;
     return merge_wg_launch(partial, parts, nq, k, o, RmuCond{}, s);
 }
 
