@@ -1040,19 +1040,35 @@ static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb, int opt_ratio =
     const int lvl_min = opt_first ? opt_first : lvl_min_env ? lvl_min_env : (nb <= 128 ? LADDER_FIRST_SMALL : 256);
     // ratio 3 for full batches; small batches (one query tile, HBM-bound: 7.68 GB image per batch) have few appends to
     // save and pay for every launch gap and merge, so they climb faster
-    const int lvl_ratio = lvl_ratio_env ? lvl_ratio_env : (nb <= 128 ? 8 : 3);
-    std::vector<int64_t> bounds{n};
     // (round 4: from 4 096 rows up -- was 262 144.  A single COLD launch over 200k rows x 1024 queries takes 1.74 ms, twice what the ladder
     // needs for 1M rows: every score that beats a still-empty threshold is appended.  With the ladder: 200k 0.45 ms, 20k 0.27, 8k 0.29.)
     static const int64_t ladder_min = rmu_env("RMU_SCREEN_LADDER_MIN") ? atoll(rmu_env("RMU_SCREEN_LADDER_MIN")) : 4096;
-    if (lvl_ratio > 1 && n >= ladder_min) {
-        int64_t c = n / lvl_ratio / 32 * 32;
-        for (; c >= 65536 && bounds.size() < 24; c = c / lvl_ratio / 32 * 32) bounds.insert(bounds.begin(), c);
-        // below 64k rows a range is a handful of tiles per workgroup and its appends cost next to nothing: ratio 8, down
-        // to a first range so small (<= lvl_min rows) that its cold start -- every score is appended -- does not matter
-        for (c = bounds.front() / 8 / 32 * 32; c >= lvl_min && bounds.size() < 24; c = c / 8 / 32 * 32) bounds.insert(bounds.begin(), c);
-    }
-    return bounds;
+    auto build = [&](int ratio) {
+        std::vector<int64_t> b{n};
+        if (ratio > 1 && n >= ladder_min) {
+            int64_t c = n / ratio / 32 * 32;
+            for (; c >= 65536 && b.size() < 24; c = c / ratio / 32 * 32) b.insert(b.begin(), c);
+            // below 64k rows a range is a handful of tiles per workgroup and its appends cost next to nothing: ratio 8, down
+            // to a first range so small (<= lvl_min rows) that its cold start -- every score is appended -- does not matter
+            for (c = b.front() / 8 / 32 * 32; c >= lvl_min && b.size() < 24; c = c / 8 / 32 * 32) b.insert(b.begin(), c);
+        }
+        return b;
+    };
+    if (lvl_ratio_env) return build(lvl_ratio_env);
+    if (nb <= 128) return build(8);
+    // (round 6, second session) Full batches over a corpus below ~6M rows: a ladder level costs 40-60 us whatever its range (launch, query
+    // fragments, emit, merge) while a seeded level's appends are cheap -- the ratio with the FEWEST levels wins there (ties: the smaller ratio).
+    // tools/ladder_sweep.py, same box, step ms at ratio 3 / 4 / 8: 1M x 1024 0.970 / 1.004 / 0.949, x 512 0.632 / 0.643 / 0.604, x 256 0.434 / 0.445 / 0.402;
+    // 1.25M x 1024 1.169 / 1.144 / 1.161, x 512 0.762 / 0.727 / 0.729, x 256 0.530 / 0.488 / 0.495; 2.5M x 1024 at 3 / 5: 1.97 / 1.92, x 256 0.699 / 0.670;
+    // 4.5M x 1024 at 3 / 6: 3.30 / 3.25, x 256 1.092 / 1.022; but 10M x 1024 6.71 / 6.77 / 6.78 at 3 / 4 / 8 (ratio 6: 6.77): there the appends of a
+    // wider level cost more than the level it saves, and the ratio stays 3.
+    std::vector<int64_t> best = build(3);
+    if (n < 6000000)
+        for (int r : {4, 5, 6, 8}) {
+            std::vector<int64_t> b = build(r);
+            if (b.size() < best.size()) best = std::move(b);
+        }
+    return best;
 }
 
 // Enqueue the screening ladder for `nb` device queries (fp32, [nb, 384]): on return (stream order) t.ckeys holds the best
