@@ -2641,7 +2641,7 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
     float qn2 = 0.f, dq2 = 0.f;
     // (round 6) the row pieces of UN steps are requested TOGETHER, then eaten in order: left as one load pair per step the 48-step chain of a
     // candidate paid a memory round trip per step (24-27 us per launch behind every search; the summation order is untouched)
-    constexpr int UN = NPL == 1 ? 12 : 6;
+    constexpr int UN = NPL == 1 ? 24 : 12;      // (second session: 12 / 6 -> 24 / 12 -- two round trips per candidate instead of four; 192 of the 256 registers a wave may take)
     for (int t0 = 0; t0 < SD / 8; t0 += UN) {
         f32x4 xa[NPL][UN], xb[NPL][UN];
 #pragma unroll
