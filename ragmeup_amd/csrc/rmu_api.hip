@@ -93,6 +93,7 @@ struct Tls {
         return RMU_OK;
     }
     int* hflag = nullptr;          // pinned landing word of the screening path's re-run count
+    int* hflag_dev = nullptr;      // ... as the device sees it (written by k_gather_flagged)
     char* hpin = nullptr;          // pinned landing buffer of search_mmr_on's results (rows | scores in ONE device-to-host copy)
     size_t hpin_cap = 0;
     int ensure_hpin(size_t bytes) {
@@ -151,7 +152,7 @@ struct Tls {
         for (auto& e : lev) (void)hipEventDestroy(e);
         if (hflag) (void)hipHostFree(hflag);
         if (hpin) (void)hipHostFree(hpin);
-        hflag = nullptr; hpin = nullptr; hpin_cap = 0;
+        hflag = nullptr; hflag_dev = nullptr; hpin = nullptr; hpin_cap = 0;
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -253,10 +254,18 @@ __global__ void k_gather_rows(const float* x, int dpad, int dim, const int64_t* 
 }
 
 // the queries the screening path flagged (list `pos`, count *count) -> a dense [count, dpad] block for the exact re-run
+// (round 6, second session) ... and the two other things the conditional re-runs need, in the same launch (every dependent stream operation
+// costs ~4.5 us of kernel boundary behind a search): the shared thresholds of the re-run launches zeroed (was a memset), the count landed in
+// pinned host memory for rmu_last_screened (was a device-to-host copy at the end).  gather_n = 0: a batch of <= 32 queries re-runs as a whole.
 __global__ void k_gather_flagged(const float* __restrict__ q, int dpad, const int64_t* __restrict__ pos, const int* __restrict__ count,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, int gather_n, u32* __restrict__ zero_words, int n_zero, int* __restrict__ host_count) {
     const int64_t r = blockIdx.x;
-    if (r >= *count) return;
+    const int cnt = *count;
+    if (r == 0) {
+        for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
+        if (threadIdx.x == 0 && host_count) *host_count = cnt;
+    }
+    if (r >= gather_n || r >= cnt) return;
     const float* row = q + pos[r] * (int64_t)dpad;
     for (int c = threadIdx.x; c < dpad; c += blockDim.x) out[r * dpad + c] = row[c];
 }
@@ -1079,7 +1088,7 @@ static std::vector<int64_t> ladder_bounds(int64_t n, int64_t nb, int opt_ratio =
 // K' (ratio - 1) per query in total, and every append stalls a whole workgroup for ~1-3k cycles: this cut
 // the filter overhead of the 10M x 1024 scan from 5.2 to ~1.5 ms.
 static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb, hipStream_t s, bool timed, int* n_launches,
-                          ScanLaunch* last_geom, int kp = kScreenKp) {
+                          ScanLaunch* last_geom, int kp = kScreenKp, u32* zero_word = nullptr /* one more word the query conversion zeroes (the re-run count) */) {
     const int dpad = idx->dpad;
     static const int share = rmu_env("RMU_NO_SHARED_THR") ? 0 : 1;
     const std::vector<int64_t> bounds = ladder_bounds(idx->n, nb, idx->ladder_ratio, idx->ladder_first);
@@ -1111,9 +1120,10 @@ static int screen_enqueue(rmu_index* idx, Tls& t, const float* qdev, int64_t nb,
         return fail(RMU_E_OOM, "rmu_index_search: screening workspace");
     static const int nofilter = rmu_env("RMU_SCREEN_NOFILTER") != nullptr ? 2 : 0;
     const int sflags = share | nofilter;
-    HIP_TRY(hipMemsetAsync(t.gthr.p, 0, gbytes, s));
     // (an L2 index holds its queries as (2q, 1): the image is fp16(64 q) all the same)
-    int rc = rmu_split_launch(qdev, t.qsplit.p, nb, s, dpad, idx->metric == RMU_METRIC_L2SQ ? 32.0f : 64.0f);
+    // (round 6) the conversion's first workgroup also zeroes the ladder's thresholds + pacing words and the caller's word: was two memsets
+    int rc = rmu_split_launch(qdev, t.qsplit.p, nb, s, dpad, idx->metric == RMU_METRIC_L2SQ ? 32.0f : 64.0f, (u32*)t.gthr.p,
+                              (int)(gbytes / sizeof(u32)), zero_word, zero_word ? 1 : 0);
     if (rc) return fail(rc, "rmu_index_search: query conversion");
     u64* base = (u64*)t.partial.p;
     int cursor = 0;     // slot index: [merged keys of the ranges so far][this range's parts] ...
@@ -1198,7 +1208,11 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
     bool any_screened = false;
     int rerun_total = 0;
     if (timed) HIP_TRY(hipEventRecord(t.ev[0], s));
-    if (!t.hflag && hipHostMalloc((void**)&t.hflag, sizeof(int)) != hipSuccess) return fail(RMU_E_OOM, "rmu_index_search: pinned flag");
+    if (!t.hflag) {
+        if (hipHostMalloc((void**)&t.hflag, sizeof(int)) != hipSuccess) { t.hflag = nullptr; return fail(RMU_E_OOM, "rmu_index_search: pinned flag"); }
+        *t.hflag = 0;
+        if (hipHostGetDevicePointer((void**)&t.hflag_dev, t.hflag, 0) != hipSuccess) { (void)hipGetLastError(); t.hflag_dev = t.hflag; }   // (unified addressing: the same pointer)
+    }
 
     for (int64_t q0 = 0; q0 < nq; q0 += kMaxQueriesPerLaunch) {
         const int64_t nb = (nq - q0) < kMaxQueriesPerLaunch ? (nq - q0) : kMaxQueriesPerLaunch;
@@ -1303,8 +1317,7 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
             if (t.partial.ensure(need_partial) || t.gthr.ensure(need_gthr)) return fail(RMU_E_OOM, "rmu_index_search: re-run partials");
             int nl = 0;
             ScanLaunch lastg{};
-            HIP_TRY(hipMemsetAsync(t.flag.p, 0, sizeof(int), s));
-            rc = screen_enqueue(idx, t, qdev, nb, s, timed, &nl, &lastg, screen_kp(k));
+            rc = screen_enqueue(idx, t, qdev, nb, s, timed, &nl, &lastg, screen_kp(k), (u32*)t.flag.p);    // (flag[0] = 0 by the query conversion)
             if (rc) return rc;
             // |s~ - s_fp32| <= EPS(q) from the measured image errors (derivation in scan_screen.hip); queries failing the
             // sufficiency test are appended to the list fb_i (count in flag[0])
@@ -1312,16 +1325,17 @@ extern "C" int rmu_index_search(rmu_index_t* idx, const float* q, int64_t nq, in
                                     (int*)t.flag.p, (int64_t*)t.fb_i.p, nullptr, s, dpad, l2 ? (const float*)t.qn.p : nullptr);
             if (rc) return fail(rc, "rmu_index_search: re-score launch");
             t.grid = lastg.grid; t.block = 256; t.lds = lastg.lds_bytes; t.passes += nl;
-            if (lim_small > 0 || mid_n > small_n) {
-                hipLaunchKernelGGL(k_gather_flagged, dim3((unsigned)gather_n), dim3(128), 0, s, qdev, dpad, (const int64_t*)t.fb_i.p, cnt,
-                                   (float*)t.fbq.p);
+            {
+                // gather (batches above 32 queries) + the re-runs' threshold zeroing + the count to the host, one launch (see the kernel)
+                const int g_n = (lim_small > 0 || mid_n > small_n) ? gather_n : 0;
+                hipLaunchKernelGGL(k_gather_flagged, dim3((unsigned)(g_n > 0 ? g_n : 1)), dim3(128), 0, s, qdev, dpad, (const int64_t*)t.fb_i.p, cnt,
+                                   (float*)t.fbq.p, g_n, (u32*)t.gthr.p, (int)(need_gthr / sizeof(u32)), t.hflag_dev);
                 HIP_TRY(hipGetLastError());
             }
-            size_t zero_once = need_gthr;          // the mutually exclusive re-run launches share one zeroing of the thresholds
+            size_t zero_once = 0;                  // (the thresholds of the mutually exclusive re-run launches were zeroed by the launch above)
             if (lim_small > 0) { if ((rc = run_exact(L1, d_s, d_r, (const int64_t*)t.fb_i.p, false, zero_once))) return rc; zero_once = 0; }
             if (mid_n > small_n) { if ((rc = run_exact(L2, d_s, d_r, (const int64_t*)t.fb_i.p, false, zero_once))) return rc; zero_once = 0; }
             if ((rc = run_exact(L3, d_s, d_r, nullptr, false, zero_once))) return rc;
-            HIP_TRY(hipMemcpyAsync(t.hflag, t.flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
             if (timed)
                 for (int l = 0; l < nl; ++l) {
                     HIP_TRY(hipEventSynchronize(t.lev[(size_t)(2 * l + 1)]));

@@ -205,7 +205,7 @@ int rmu_merge_to_keys_launch(const u64* partial, int parts, int64_t nq, int k, u
 // fp16 screening path (scan_screen.hip)
 #define RMU_IMG_ROW_BYTES 768                          /* fp16(64 x) image of a 384-d row */
 int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s, int stride = 384,
-                     float scale = 64.0f);                                             // fp32 [n, 384 of stride] -> fp16(scale x) image
+                     float scale = 64.0f, u32* zero_a = nullptr, int n_zero_a = 0, u32* zero_b = nullptr, int n_zero_b = 0);                                             // fp32 [n, 384 of stride] -> fp16(scale x) image
 int rmu_screen_launch(const ScanLaunch* p, hipStream_t s);                             // x/q = split images, k = K'
 int rmu_screen_lds_bytes(int qg);
 int rmu_screen_plan(ScanLaunch* p);                      // geometry of one screening launch (k = K' <= 32)

@@ -76,7 +76,14 @@ extern __shared__ __attribute__((aligned(16))) char ssm[];
 
 // fp32 rows [n, 384 of `stride` floats] -> screening image [n, 768 B] = fp16(scale * x); one thread per group of 8 k.  scale = 64, or 32 for the
 // L2 index's queries, which are stored doubled (rmu_api.hip: k_l2_aug_queries)
-__global__ void k_split_rows(const float* __restrict__ src, char* __restrict__ dst, int64_t n_groups, int stride, float scale) {
+// (round 6, second session) zero_a / zero_b: words the FIRST workgroup zeroes on the way -- the query conversion opens every screened search, and
+// the ladder's shared thresholds and the re-run count used to be two memsets in front of it (~4.5 us of kernel boundary each)
+__global__ void k_split_rows(const float* __restrict__ src, char* __restrict__ dst, int64_t n_groups, int stride, float scale,
+                             u32* __restrict__ zero_a, int n_zero_a, u32* __restrict__ zero_b, int n_zero_b) {
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < n_zero_a; i += blockDim.x) zero_a[i] = 0u;
+        for (int i = threadIdx.x; i < n_zero_b; i += blockDim.x) zero_b[i] = 0u;
+    }
     const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gidx >= n_groups) return;
     const float* s = src + (gidx / (SD / 8)) * stride + (gidx % (SD / 8)) * 8;
@@ -2724,11 +2731,13 @@ __global__ __launch_bounds__(256) void k_rescore(const u64* __restrict__ cand, i
 
 }  // namespace
 
-int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s, int stride, float scale) {
+int rmu_split_launch(const float* src, void* dst, int64_t n_rows, hipStream_t s, int stride, float scale, u32* zero_a, int n_zero_a, u32* zero_b,
+                     int n_zero_b) {
     const int64_t groups = n_rows * (SD / 8);
-    if (groups <= 0) return RMU_OK;
+    if (groups <= 0) return (n_zero_a > 0 || n_zero_b > 0) ? RMU_E_INVALID : RMU_OK;      // (the zeroing rides on a launch that exists)
     if (stride < SD) return RMU_E_INVALID;
-    hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, (char*)dst, groups, stride, scale);
+    hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, src, (char*)dst, groups, stride, scale, zero_a,
+                       zero_a ? n_zero_a : 0, zero_b, zero_b ? n_zero_b : 0);
     return hipGetLastError() == hipSuccess ? RMU_OK : RMU_E_HIP;
 }
 
