@@ -305,6 +305,14 @@ def test_full_size_properties_1m(rmu):
     # idempotence
     s2, r2 = idx.search(q, 10)
     assert torch.equal(r, r2) and torch.equal(s, s2)
+    # (round 6) full batches below 6M rows take the ladder ratio with the fewest levels: 1M rows -> 1 952 / 15 616 / 124 992 / 1M (ratio 8)
+    # instead of ratio 3's five; whatever the geometry, the answers are the exact scan's
+    assert idx.last_screened() != 0 and idx.last_geometry()["launches"] == 4
+    for ratio, first, launches in ((3, 256, 5), (8, 2048, 3)):
+        idx.set_ladder(ratio, first)
+        s3, r3 = idx.search(q, 10)
+        assert idx.last_geometry()["launches"] == launches and torch.equal(r, r3) and torch.equal(s, s3)
+    idx.set_ladder(0, 0)
     idx.close()
 
 
