@@ -1505,6 +1505,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    bool direct = false;      // (uniform per wave) this wave's lists are already in a.partial: see the cold tile below
     if (ntiles > 0) {
         refresh_gthr();
         if (L2N) {                                        // (older than every piece: complete at the first counted wait)
@@ -1620,7 +1621,42 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
                 last[r] = last_in_a ? accA[r] : accB[r];
                 inmask |= (rbl + (r & 3) + 8 * (r >> 2) < row_end) ? (1u << r) : 0u;
             }
-            if (!(a.share_thr & 2)) slow_path(last, rbl, inmask);
+            // (round 6, second session) COLD tile of the ladder's first launch -- one tile per chunk, empty thresholds: every row of the tile is a
+            // candidate of every query.  Through slow_path that is 16 store instructions of 64 scattered 8-byte keys per wave (the slots are
+            // query-major, a query's lanes 384 B apart: every lane its own line request -- 112 k of a wave's 174 k cycles in the debug build), a
+            // read-back and a copy.  Here the wave's 32 x 32 keys go through 8 KiB of the (now idle) ring and straight into a.partial, a store
+            // instruction = two queries' lists = 512 contiguous bytes; the slots are never touched and the emit skips this wave.  The lists leave
+            // unsorted (share_thr bit 2: the launch's merge knows).  The barrier is workgroup-uniform (share_thr, ntiles); `cold` is per wave.
+            bool cold = false;
+            if ((a.share_thr & 4) && !(a.share_thr & 2) && ntiles == 1 && a.k >= 32) {
+                __builtin_amdgcn_s_barrier();            // every wave's DMA has landed (the drain above) and nobody reads the ring any more
+                u32 todo = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) todo |= (last[r] > thr_s) ? (1u << r) : 0u;
+                todo &= inmask;
+                cold = __ballot(q_ok && (cnt != 0u || todo != 0xffffu)) == 0ull;
+            }
+            if (cold) {
+                u64* tl = (u64*)(ring + w * 8192);       // [query 0..31][position 0..31]: lane (j, h) owns positions [16 h, +16) of query j
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tl[j * 32 + 16 * h + r] = rmu_make_key(last[r] * (1.0f / 4096.0f) + 0.0f, (u32)(rbl + (r & 3) + 8 * (r >> 2)));
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                u64* const pbase = a.partial + ((size_t)s_idx * a.nq + q_base) * a.k;
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int lin = it * 64 + lane, qq = lin >> 5, pos = lin & 31;
+                    const u64 key = tl[lin];
+                    if (q_base + qq < a.nq) pbase[(size_t)qq * a.k + pos] = key;
+                }
+                const int extra = a.k - 32;                // positions 32 .. K' - 1 of every list: zeros
+                for (int e = lane; e < 32 * extra; e += 64) {
+                    const int qq = e / extra, pos = 32 + e % extra;
+                    if (q_base + qq < a.nq) pbase[(size_t)qq * a.k + pos] = 0ull;
+                }
+                direct = true;
+            } else if (!(a.share_thr & 2)) slow_path(last, rbl, inmask);
         }
     }
     if (DBG) {
@@ -1653,7 +1689,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
     // 59 us of the batch-32 one (profiles/r06_search_timeline.txt).  The slots are in global memory, so any wave can sort any query: the
     // counts go through the waves' (now idle) threshold words in LDS and query q is emitted by wave q % 4.  Same keys, same ranks, same bytes.
     if constexpr (NWV == 4) {
-        if (lane < 32) lds_store_b32(lds_addr(ssm + C::GT_OFF + w * 256) + (u32)lane * 4u, cnt);
+        if (lane < 32) lds_store_b32(lds_addr(ssm + C::GT_OFF + w * 256) + (u32)lane * 4u, direct ? 0xffffffffu : cnt);   // (marker: the list is already written)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const u32* call = (const u32*)(ssm + C::GT_OFF);
@@ -1661,11 +1697,14 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
             if (w + 4 * e0 >= a.nq) break;
             u64 key[GE][C::NPL];
             u32 nn[GE];
+            bool done[GE];
 #pragma unroll
             for (int e = 0; e < GE; ++e) {
                 const int qq = w + 4 * (e0 + e);
                 const bool ok = qq < a.nq;
                 nn[e] = ok ? (u32)__builtin_amdgcn_readfirstlane((int)call[(qq >> 5) * 64 + (qq & 31)]) : 0u;
+                done[e] = nn[e] == 0xffffffffu;
+                if (done[e]) nn[e] = 0u;
                 const u64* slot = a.gcand + ((size_t)s_idx * a.nq + (ok ? qq : 0)) * C::CAP;
 #pragma unroll
                 for (int pp = 0; pp < C::NPL; ++pp)
@@ -1674,7 +1713,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
 #pragma unroll
             for (int e = 0; e < GE; ++e) {
                 const int qq = w + 4 * (e0 + e);
-                if (qq < a.nq) {
+                if (qq < a.nq && !done[e]) {
                     u64* dst = a.partial + ((size_t)part * a.nq + qq) * a.k;
                     if (emit_raw && nn[e] <= (u32)a.k) {       // (uniform) the slot as it is, zeros behind it: the merge of this launch does not need it sorted
 #pragma unroll
@@ -1700,7 +1739,7 @@ __global__ __launch_bounds__(64 * NWV) void scan_screen_lean3_kernel(const ScanL
         }
     } else {
     for (int j0 = 0; j0 < 32; j0 += GE) {
-        if (q_base + j0 >= a.nq) break;
+        if (q_base + j0 >= a.nq || direct) break;
         u64 key[GE][C::NPL];
         u32 nn[GE];
 #pragma unroll
